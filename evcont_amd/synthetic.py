@@ -1,0 +1,125 @@
+"""Seeded synthetic inputs of the shapes the hot path consumes.
+
+Physical AO integrals need PySCF/libcint, which is not part of this build; the
+throughput benchmark and most parity tests therefore run on random tensors with
+the *symmetries* of the real objects:
+
+* ``S_train = A A^T / T + 1`` (well conditioned), ``S_AO = B B^T / N + 1``;
+* one-/two-body t-RDMs symmetric under bra<->ket exchange combined with index
+  transposition and (for the two-body one) under electron-pair exchange
+  (pq)<->(rs), so that all four storage layouts of the reference
+  (``ab_initio_eigenvector_continuation.py:41-68``) describe the same object;
+* ``eri`` 8-fold symmetric; ``hcore`` and ``dhcore`` symmetric.
+
+Everything is float64 and generated with ``numpy.random.default_rng(seed)`` so
+the same arrays can be rebuilt on any machine.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+
+@dataclass
+class AOArrays:
+    """Array-level stand-in for the ``mol`` queries of the reference
+    (``ab_initio_gradients_loewdin.py:25,147,283-284,336-339,369-370``)."""
+
+    S: np.ndarray          # (N,N)        int1e_ovlp
+    hcore: np.ndarray      # (N,N)        scf.hf.get_hcore
+    eri: np.ndarray        # (N,N,N,N)    int2e, chemists' notation
+    ipovlp: np.ndarray     # (3,N,N)      int1e_ipovlp
+    dhcore: np.ndarray     # (A,3,N,N)    hcore_generator()(atom)
+    eri_ip1: np.ndarray    # (3,N,N,N,N)  int2e_ip1
+    aoslices: np.ndarray   # (A,2) int64  [start, stop) of each atom's AOs
+    enuc: float
+    gnuc: np.ndarray       # (A,3)
+
+    @property
+    def nao(self) -> int:
+        return int(self.S.shape[0])
+
+    @property
+    def natm(self) -> int:
+        return int(self.aoslices.shape[0])
+
+
+def equal_aoslices(nao: int, natm: int) -> np.ndarray:
+    """Contiguous AO blocks, as equal as possible (first atoms get the surplus)."""
+    base, extra = divmod(nao, natm)
+    sizes = [base + (1 if a < extra else 0) for a in range(natm)]
+    stops = np.cumsum(sizes)
+    starts = stops - np.array(sizes)
+    return np.stack([starts, stops], axis=1).astype(np.int64)
+
+
+def make_ao_arrays(nao: int, natm: int, seed: int,
+                   ao_sizes: Optional[Sequence[int]] = None,
+                   degenerate_S: bool = False,
+                   with_ip1: bool = True) -> AOArrays:
+    rng = np.random.default_rng(seed)
+    n = nao
+    B = rng.standard_normal((n, n))
+    S = B @ B.T / n + np.eye(n)
+    if degenerate_S:
+        # exactly repeated overlap eigenvalues (symmetric molecules have them)
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        vals = 1.0 + 0.5 * (np.arange(n) // 2)
+        S = (q * vals) @ q.T
+        S = 0.5 * (S + S.T)
+    h = rng.standard_normal((n, n))
+    hcore = 0.5 * (h + h.T)
+    e = 0.1 * rng.standard_normal((n, n, n, n))
+    e = e + e.transpose(1, 0, 2, 3)
+    e = e + e.transpose(0, 1, 3, 2)
+    e = e + e.transpose(2, 3, 0, 1)
+    eri = np.ascontiguousarray(e / 8.0)
+    ipovlp = 0.1 * rng.standard_normal((3, n, n))
+    dh = rng.standard_normal((natm, 3, n, n))
+    dhcore = 0.5 * (dh + dh.transpose(0, 1, 3, 2))
+    if with_ip1:
+        eri_ip1 = 0.1 * rng.standard_normal((3, n, n, n, n))
+    else:
+        eri_ip1 = np.zeros((3, n, n, n, n))
+    if ao_sizes is None:
+        aoslices = equal_aoslices(n, natm)
+    else:
+        assert len(ao_sizes) == natm and sum(ao_sizes) == n
+        stops = np.cumsum(ao_sizes)
+        aoslices = np.stack([stops - np.array(ao_sizes), stops], axis=1).astype(np.int64)
+    enuc = float(rng.standard_normal())
+    gnuc = rng.standard_normal((natm, 3))
+    return AOArrays(S, hcore, eri, ipovlp, dhcore, eri_ip1, aoslices, enuc, gnuc)
+
+
+def make_trdms(nao: int, ntrain: int, seed: int):
+    """(S_train, one_RDM (T,T,N,N), two_RDM (T,T,N,N,N,N)) with the symmetries above."""
+    rng = np.random.default_rng(seed)
+    n, T = nao, ntrain
+    A = rng.standard_normal((T, T))
+    S_train = A @ A.T / T + np.eye(T)
+    d = rng.standard_normal((T, T, n, n)) / n
+    one = 0.5 * (d + d.transpose(1, 0, 3, 2))
+    g = rng.standard_normal((T, T, n, n, n, n)) / (n * n)
+    g = 0.5 * (g + g.transpose(0, 1, 4, 5, 2, 3))          # (pq)<->(rs)
+    g = 0.5 * (g + g.transpose(1, 0, 3, 2, 5, 4))          # bra<->ket with p<->q, r<->s
+    return S_train, np.ascontiguousarray(one), np.ascontiguousarray(g)
+
+
+def pack_rows(two_rdm_full: np.ndarray, pair_sym: bool, elec_sym: bool) -> np.ndarray:
+    """Re-express a (T,T,N,N,N,N) t-RDM in one of the reference's other layouts
+    (``ab_initio_eigenvector_continuation.py:45-68``): pairs (a>=b) in
+    ``np.tril_indices`` order, columns as the row-major lower triangle of the
+    (N^2,N^2) matrix (``electron_integral_utils.py:57``)."""
+    T = two_rdm_full.shape[0]
+    n = two_rdm_full.shape[2]
+    g = two_rdm_full
+    if elec_sym:
+        r, c = np.tril_indices(n * n)
+        g = g.reshape(T, T, n * n, n * n)[:, :, r, c]
+    if pair_sym:
+        a, b = np.tril_indices(T)
+        g = g[a, b]
+    return np.ascontiguousarray(g)
