@@ -1,0 +1,65 @@
+"""Build libevcont_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: plain
+``hipcc -shared -fPIC`` so the library is a C-ABI object usable from any host
+language (``include/evcont_hip.h``)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libevcont_hip.so")
+SOURCES = ["gemv_stream.hip", "transform.hip", "dense_small.hip", "pipeline.hip"]
+HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "evcont_hip.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile (if stale) and return the path of the shared library."""
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+                   "-Wall", "-Wno-unused-function", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    if force or procs or _stale(LIB, objs):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout.decode(errors='replace')}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,74 @@
+// Shared device helpers and host-side error plumbing for libevcont_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/evcont_hip.h"
+
+namespace evc {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- host side -------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define EVC_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            evc::set_error(__VA_ARGS__);  \
+            return -1;                    \
+        }                                 \
+    } while (0)
+
+#define EVC_LAUNCH_CHECK(name)                                                      \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            evc::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return (int)e_;                                                         \
+        }                                                                           \
+    } while (0)
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device side -----------------------------------------------------------------
+// Sum over the 64 lanes of a wave; every lane gets the total.  Fixed butterfly order,
+// so results are reproducible run to run.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Sum over a workgroup of NW waves; result valid in thread 0 (and all threads of wave 0).
+// `scratch` must hold NW doubles of LDS per concurrently reduced value.
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += scratch[w];
+    __syncthreads();
+    return t;
+}
+
+// Index of element (R,C), R>=C, in the row-major lower triangle (np.tril_indices order).
+__device__ __host__ __forceinline__ int64_t tri_index(int64_t R, int64_t C) { return R * (R + 1) / 2 + C; }
+
+// Inverse: packed index m -> row R (largest R with R(R+1)/2 <= m).
+__device__ __forceinline__ int64_t tri_row(int64_t m) {
+    int64_t R = (int64_t)((sqrt(8.0 * (double)m + 1.0) - 1.0) * 0.5);
+    while (R * (R + 1) / 2 > m) --R;
+    while ((R + 1) * (R + 2) / 2 <= m) ++R;
+    return R;
+}
+
+}  // namespace evc

@@ -1,0 +1,388 @@
+// Per-geometry orchestration: enqueues the whole energy(+force) DAG on one HIP stream.
+// Mirrors get_energy_with_grad (gradients_loewdin.py:308-379) and approximate_*_OAO
+// (evcont.py:178-250); split in three phases so a pair-sharded multi-GPU host can put its two
+// small collectives (all-gather of the H rows, all-reduce of the gradient) between them.
+#include <string.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace evc {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct Ws {
+    // N^2-sized
+    double *X, *U, *s, *h1, *Dpred, *Pao, *Y1;
+    // N^4-sized
+    double *B1, *B2, *K3, *G;
+    double *vec2;  // ld2-long vector: packed h2 (phase A) / packed predicted 2-RDM (phase C)
+    // t-RDM contraction
+    double *h2part, *h1part, *h2rows, *w2, *w1;
+    // gradient partials
+    double *y2part, *t2part, *term3;
+    // scratch outputs when the caller passes NULL
+    double *evals, *evecs;
+    size_t bytes;
+    RowProblem rp2, rp1;
+};
+
+static bool is_packed(int layout) { return layout == EVC_LAYOUT_ELEC3 || layout == EVC_LAYOUT_PACK2; }
+static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout == EVC_LAYOUT_PACK2; }
+
+static int check_set(const evc_trdm_set *t) {
+    EVC_REQUIRE(t != nullptr, "trdm_set is NULL");
+    EVC_REQUIRE(t->n >= 1 && t->n <= 64, "trdm_set: n=%d out of range 1..64", t->n);
+    EVC_REQUIRE(t->ntrain >= 1 && t->ntrain <= 64, "trdm_set: ntrain=%d out of range 1..64", t->ntrain);
+    EVC_REQUIRE(t->layout == 6 || t->layout == 5 || t->layout == 3 || t->layout == 2,
+                "trdm_set: layout=%d (must be the ndim of two_RDM: 6, 5, 3 or 2)", t->layout);
+    const int64_t n2 = (int64_t)t->n * t->n;
+    const int64_t cols = is_packed(t->layout) ? n2 * (n2 + 1) / 2 : n2 * n2;
+    const int64_t rows = is_pairs(t->layout) ? (int64_t)t->ntrain * (t->ntrain + 1) / 2
+                                              : (int64_t)t->ntrain * t->ntrain;
+    EVC_REQUIRE(t->cols2 == cols, "trdm_set: cols2=%lld, expected %lld", (long long)t->cols2, (long long)cols);
+    EVC_REQUIRE(t->rows2_total == rows, "trdm_set: rows2_total=%lld, expected %lld", (long long)t->rows2_total,
+                (long long)rows);
+    EVC_REQUIRE(t->rows2 >= 0 && t->row_offset >= 0 && t->row_offset + t->rows2 <= rows,
+                "trdm_set: local rows [%lld,+%lld) outside 0..%lld", (long long)t->row_offset,
+                (long long)t->rows2, (long long)rows);
+    EVC_REQUIRE(t->ld2 >= cols && t->ld2 % 2 == 0, "trdm_set: ld2=%lld must be even and >= cols2",
+                (long long)t->ld2);
+    EVC_REQUIRE(t->rows2 == 0 || (t->two_rdm && aligned16(t->two_rdm)), "trdm_set: two_rdm NULL or misaligned");
+    EVC_REQUIRE(t->one_rdm && aligned16(t->one_rdm) && t->s_train, "trdm_set: one_rdm/s_train NULL or misaligned");
+    return 0;
+}
+
+static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
+    const size_t n = t->n, n2 = n * n, n4 = n2 * n2, T = t->ntrain;
+    size_t off = 0;
+    auto take = [&](size_t doubles) {
+        double *p = base ? reinterpret_cast<double *>(base + off) : nullptr;
+        off += align_up(doubles * sizeof(double), 256);
+        return p;
+    };
+    w.X = take(n2);
+    w.U = take(n2);
+    w.s = take(n);
+    w.h1 = take(n2);
+    w.Dpred = take(n2);
+    w.Pao = take(n2);
+    w.Y1 = take(n2);
+    w.B1 = take(n4);
+    w.B2 = take(n4);
+    w.K3 = take(n4);
+    w.G = take(n4);
+    w.vec2 = take((size_t)t->ld2 + 2);
+    memset(&w.rp2, 0, sizeof(w.rp2));
+    memset(&w.rp1, 0, sizeof(w.rp1));
+    w.rp2.rows = t->rows2;
+    w.rp2.cols = t->cols2;
+    w.rp2.ld = t->ld2;
+    if (t->rows2 > 0) plan_rows(w.rp2);
+    w.rp1.rows = (int64_t)T * T;
+    w.rp1.cols = (int64_t)n2;
+    w.rp1.ld = (int64_t)n2;
+    plan_rows(w.rp1);
+    w.h2part = take((size_t)t->rows2 * (w.rp2.nspans > 0 ? w.rp2.nspans : 1) + 1);
+    w.h1part = take((size_t)T * T * w.rp1.nspans);
+    w.h2rows = take((size_t)t->rows2_total);
+    w.w2 = take((size_t)t->rows2 + 1);
+    w.w1 = take(T * T);
+    w.y2part = take((size_t)y2_slabs((int)n) * n2);
+    w.t2part = take((size_t)n * 3 * ip1_chunks((int)n));
+    w.term3 = take((size_t)(natm > 0 ? natm : 1) * 3);
+    w.evals = take(T);
+    w.evecs = take(T * T);
+    w.bytes = off;
+}
+
+// y[r] = alpha * sum_k partial[r][k]   (tiny; only used on the multi-GPU path)
+__global__ void rows_reduce_kernel(const double *partial, int64_t rows, int nspans, double alpha, double *y) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double s = 0.0;
+    for (int k = 0; k < nspans; ++k) s += partial[r * nspans + k];
+    y[r] = alpha * s;
+}
+
+static int phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, Ws &w, bool reduce_rows,
+                             hipStream_t st) {
+    const int n = t->n;
+    int rc;
+    if ((rc = launch_loewdin(g->S, g->hcore, n, w.X, w.U, w.s, w.h1, st))) return rc;
+    // (ab|cd) -> K3[jkl][a] -> h2[ijkl]
+    if ((rc = launch_quarter_transform(g->eri, w.X, 0, n, w.B1, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B1, w.X, 0, n, w.B2, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B2, w.X, 0, n, w.K3, st))) return rc;
+    if ((rc = launch_quarter_transform(w.K3, w.X, 0, n, w.B1, st))) return rc;
+    const double *v2 = w.B1;
+    if (is_packed(t->layout)) {
+        if ((rc = launch_pack(w.B1, n, 0.5, w.vec2, t->ld2, st))) return rc;
+        v2 = w.vec2;
+    }
+    RowProblem p2 = w.rp2, p1 = w.rp1;
+    p2.A = t->two_rdm;
+    p2.v = v2;
+    p2.partial = w.h2part;
+    if (t->rows2 == 0) p2.nblocks = 0;
+    p1.A = t->one_rdm;
+    p1.v = w.h1;
+    p1.partial = w.h1part;
+    if ((rc = launch_gemv_rows(p2, p1, st))) return rc;
+    if (reduce_rows && t->rows2 > 0) {
+        const double alpha2 = is_packed(t->layout) ? 1.0 : 0.5;
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)ceil_div(t->rows2, 256)), dim3(256), 0, st,
+                           w.h2part, t->rows2, w.rp2.nspans, alpha2, w.h2rows + t->row_offset);
+        EVC_LAUNCH_CHECK("rows_reduce");
+    }
+    return 0;
+}
+
+static int phase_solve(const evc_trdm_set *t, const evc_geometry *g, const double *h2rows_all,
+                       const evc_outputs *out, int nroots, Ws &w, hipStream_t st) {
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.h1part = w.h1part;
+    a.nsp1 = w.rp1.nspans;
+    a.alpha1 = 1.0;
+    if (h2rows_all) {
+        a.h2part = h2rows_all;
+        a.nsp2 = 1;
+        a.alpha2 = 1.0;
+    } else {
+        a.h2part = w.h2part;
+        a.nsp2 = w.rp2.nspans;
+        a.alpha2 = is_packed(t->layout) ? 1.0 : 0.5;
+    }
+    a.S = t->s_train;
+    a.T = t->ntrain;
+    a.layout = t->layout;
+    a.nroots = nroots;
+    a.e_shift = g->enuc;
+    a.evals = (out && out->energy) ? out->energy : w.evals;
+    a.evecs = (out && out->coeffs) ? out->coeffs : w.evecs;
+    a.w2 = w.w2;
+    a.w1 = w.w1;
+    a.Hout = out ? out->hmat : nullptr;
+    a.w2_offset = t->row_offset;
+    a.w2_count = t->rows2;
+    return launch_subspace_solve(a, st);
+}
+
+// Gradient of the energy functional defined by (D, G) [G unpacked, N^4] given X,U,s,K3 in the
+// workspace.  scale1 = 0 drops everything that is not linear in G (multi-GPU partial ranks).
+static int gradient_from_rdms(int n, const evc_geometry *g, const double *D, const double *G, double scale1,
+                              bool add_gnuc, double *grad, Ws &w, hipStream_t st) {
+    int rc;
+    if ((rc = launch_sym_oao_t(G, n, w.B2, st))) return rc;
+    if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, st))) return rc;
+    // G^AO = (X x X x X x X) G, contraction over the SECOND index of X (gradients_loewdin.py:224-232)
+    if ((rc = launch_quarter_transform(G, w.X, 1, n, w.B1, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B1, w.X, 1, n, w.B2, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B2, w.X, 1, n, w.B1, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B1, w.X, 1, n, w.B2, st))) return rc;
+    GradPrepArgs p;
+    p.n = n;
+    p.X = w.X;
+    p.hcore = g->hcore;
+    p.D = D;
+    p.Pao = w.Pao;
+    p.Y1 = w.Y1;
+    p.scale1 = scale1;
+    if ((rc = launch_grad_prep(p, st))) return rc;
+    if ((rc = launch_ip1_dh(g->eri_ip1, w.B2, n, w.t2part, g->dhcore, w.Pao, g->natm, w.term3, st))) return rc;
+    GradFinalArgs f;
+    f.n = n;
+    f.natm = g->natm;
+    f.U = w.U;
+    f.s = w.s;
+    f.Y1 = w.Y1;
+    f.y2part = w.y2part;
+    f.nslab = y2_slabs(n);
+    f.ipovlp = g->ipovlp;
+    f.aoslices = g->aoslices;
+    f.t2part = w.t2part;
+    f.nchunk = ip1_chunks(n);
+    f.term3 = w.term3;
+    f.gnuc = add_gnuc ? g->gnuc : nullptr;
+    f.scale1 = scale1;
+    f.grad = grad;
+    return launch_grad_final(f, st);
+}
+
+static int phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out, int flags,
+                          Ws &w, hipStream_t st) {
+    const int n = t->n;
+    int rc;
+    double *D = out->d_pred ? out->d_pred : w.Dpred;
+    double *G = out->g_pred ? out->g_pred : w.G;
+    ColProblem c2{}, c1{};
+    c2.A = t->two_rdm;
+    c2.w = w.w2;
+    c2.rows = t->rows2;
+    c2.cols = t->cols2;
+    c2.ld = t->ld2;
+    c2.out = is_packed(t->layout) ? w.vec2 : G;
+    c1.A = t->one_rdm;
+    c1.w = w.w1;
+    c1.rows = (int64_t)t->ntrain * t->ntrain;
+    c1.cols = (int64_t)n * n;
+    c1.ld = c1.cols;
+    c1.out = D;
+    if ((rc = launch_gemv_cols(c2, c1, st))) return rc;
+    if (is_packed(t->layout))
+        if ((rc = launch_unpack(w.vec2, n, G, st))) return rc;
+    const bool partial = (flags & EVC_FLAG_PARTIAL_RANK) != 0;
+    return gradient_from_rdms(n, g, D, G, partial ? 0.0 : 1.0, !partial, out->grad, w, st);
+}
+
+static int check_geometry(const evc_geometry *g, bool need_grad) {
+    EVC_REQUIRE(g != nullptr, "geometry is NULL");
+    EVC_REQUIRE(g->S && g->hcore && g->eri, "geometry: S/hcore/eri must be given");
+    if (need_grad) {
+        EVC_REQUIRE(g->natm >= 1, "geometry: natm=%d", g->natm);
+        EVC_REQUIRE(g->ipovlp && g->dhcore && g->eri_ip1 && g->aoslices,
+                    "geometry: ipovlp/dhcore/eri_ip1/aoslices are required for the gradient");
+    }
+    return 0;
+}
+
+}  // namespace evc
+
+using namespace evc;
+
+extern "C" int evc_abi_version(void) { return EVC_ABI_VERSION; }
+extern "C" const char *evc_last_error(void) { return g_err; }
+
+extern "C" size_t evc_workspace_bytes(const evc_trdm_set *t, int natm) {
+    if (check_set(t)) return 0;
+    Ws w;
+    carve(t, natm, nullptr, w);
+    return w.bytes;
+}
+
+#define EVC_SETUP(need_grad)                                                                      \
+    if (check_set(t)) return -1;                                                                  \
+    if (check_geometry(g, need_grad)) return -1;                                                  \
+    EVC_REQUIRE(ws && aligned16(ws), "workspace NULL or misaligned");                             \
+    Ws w;                                                                                         \
+    carve(t, g->natm, static_cast<char *>(ws), w);                                                \
+    EVC_REQUIRE(ws_bytes >= w.bytes, "workspace too small: %zu < %zu", ws_bytes, w.bytes);        \
+    hipStream_t st = as_stream(stream)
+
+extern "C" int evc_phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, void *ws, size_t ws_bytes,
+                                     double **h2rows_local, double **h1rows, void *stream) {
+    EVC_SETUP(false);
+    int rc = phase_hamiltonian(t, g, w, true, st);
+    if (rc) return rc;
+    if (h2rows_local) *h2rows_local = w.h2rows + t->row_offset;
+    if (h1rows) *h1rows = w.h1part;
+    return 0;
+}
+
+extern "C" int evc_phase_solve(const evc_trdm_set *t, const evc_geometry *g, const double *h2rows_all,
+                               const evc_outputs *out, int nroots, void *ws, size_t ws_bytes, void *stream) {
+    EVC_SETUP(false);
+    EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
+    return phase_solve(t, g, h2rows_all ? h2rows_all : w.h2rows, out, nroots, w, st);
+}
+
+extern "C" int evc_phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
+                                  int flags, void *ws, size_t ws_bytes, void *stream) {
+    EVC_SETUP(true);
+    EVC_REQUIRE(out && out->grad, "outputs.grad is required");
+    return phase_gradient(t, g, out, flags, w, st);
+}
+
+extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
+                                    int nroots, int flags, void *ws, size_t ws_bytes, void *stream) {
+    const bool energy_only = (flags & EVC_FLAG_ENERGY_ONLY) != 0;
+    EVC_SETUP(!energy_only);
+    EVC_REQUIRE(out != nullptr, "outputs is NULL");
+    EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
+    EVC_REQUIRE(t->rows2 == t->rows2_total && t->row_offset == 0,
+                "evc_energy_with_grad needs the complete t-RDM on this device (use the phase calls when sharded)");
+    EVC_REQUIRE(energy_only || out->grad, "outputs.grad is required unless EVC_FLAG_ENERGY_ONLY");
+    int rc;
+    if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
+    if ((rc = phase_solve(t, g, nullptr, out, nroots, w, st))) return rc;
+    if (energy_only) return 0;
+    return phase_gradient(t, g, out, flags & ~EVC_FLAG_PARTIAL_RANK, w, st);
+}
+
+extern "C" int evc_subspace_solve(const double *h1rows, const double *h2rows, const double *S_train, int T,
+                                  int layout, int nroots, double e_shift, double *evals, double *evecs,
+                                  double *w2, double *w1, double *Hout, void *stream) {
+    EVC_REQUIRE(h1rows && h2rows && S_train && evals && evecs, "evc_subspace_solve: null pointer");
+    EVC_REQUIRE(T >= 1 && T <= 64, "evc_subspace_solve: T=%d out of range 1..64", T);
+    EVC_REQUIRE(layout == 6 || layout == 5 || layout == 3 || layout == 2, "evc_subspace_solve: layout=%d", layout);
+    EVC_REQUIRE(nroots >= 1 && nroots <= T, "evc_subspace_solve: nroots=%d out of range", nroots);
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.h1part = h1rows;
+    a.nsp1 = 1;
+    a.alpha1 = 1.0;
+    a.h2part = h2rows;
+    a.nsp2 = 1;
+    a.alpha2 = 1.0;
+    a.S = S_train;
+    a.T = T;
+    a.layout = layout;
+    a.nroots = nroots;
+    a.e_shift = e_shift;
+    a.evals = evals;
+    a.evecs = evecs;
+    a.w2 = w2;
+    a.w1 = w1;
+    a.Hout = Hout;
+    a.w2_offset = 0;
+    a.w2_count = is_pairs(layout) ? (int64_t)T * (T + 1) / 2 : (int64_t)T * T;
+    return launch_subspace_solve(a, as_stream(stream));
+}
+
+extern "C" size_t evc_grad_elec_ws_bytes(int n, int natm) {
+    evc_trdm_set t;
+    memset(&t, 0, sizeof(t));
+    t.n = n;
+    t.ntrain = 1;
+    t.layout = EVC_LAYOUT_FULL6;
+    t.rows2 = 0;
+    t.rows2_total = 1;
+    t.cols2 = (int64_t)n * n * n * n;
+    t.ld2 = t.cols2 + (t.cols2 & 1);
+    if (n < 1 || n > 64) return 0;
+    Ws w;
+    carve(&t, natm, nullptr, w);
+    return w.bytes;
+}
+
+extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *one_rdm, const double *two_rdm,
+                                 double *grad, void *ws, size_t ws_bytes, void *stream) {
+    EVC_REQUIRE(n >= 1 && n <= 64, "evc_grad_elec_oao: n=%d out of range 1..64", n);
+    if (check_geometry(g, true)) return -1;
+    EVC_REQUIRE(one_rdm && two_rdm && grad && ws && aligned16(ws), "evc_grad_elec_oao: null/misaligned pointer");
+    evc_trdm_set t;
+    memset(&t, 0, sizeof(t));
+    t.n = n;
+    t.ntrain = 1;
+    t.layout = EVC_LAYOUT_FULL6;
+    t.rows2_total = 1;
+    t.cols2 = (int64_t)n * n * n * n;
+    t.ld2 = t.cols2 + (t.cols2 & 1);
+    Ws w;
+    carve(&t, g->natm, static_cast<char *>(ws), w);
+    EVC_REQUIRE(ws_bytes >= w.bytes, "evc_grad_elec_oao: workspace too small: %zu < %zu", ws_bytes, w.bytes);
+    hipStream_t st = as_stream(stream);
+    int rc;
+    if ((rc = launch_loewdin(g->S, g->hcore, n, w.X, w.U, w.s, w.h1, st))) return rc;
+    if ((rc = launch_quarter_transform(g->eri, w.X, 0, n, w.B1, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B1, w.X, 0, n, w.B2, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B2, w.X, 0, n, w.K3, st))) return rc;
+    return gradient_from_rdms(n, g, one_rdm, two_rdm, 1.0, false, grad, w, st);
+}

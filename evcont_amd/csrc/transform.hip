@@ -1,0 +1,354 @@
+// Four-index basis rotations on the FP64 matrix cores and the N^4-sized helpers around them.
+//   K3/K14  quarter transform (v_mfma_f64_16x16x4_f64)          electron_integral_utils.py:136,
+//                                                              gradients_loewdin.py:224-232,339
+//   a4/a5   pack / unpack of the electron-exchange symmetry     electron_integral_utils.py:38-88
+//   K13     Gs^T symmetrisation + Y2 = K3 . Gs contraction      gradients_loewdin.py:210-222
+//   K15     int2e_ip1 diagonal contraction                      gradients_loewdin.py:234-252
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace evc {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md §3):
+//   A[i][k]: lane l holds i = l&15, k = l>>4        B[k][j]: k = l>>4, j = l&15
+//   D[i][j]: j = l&15, i = (l>>4) + 4*reg
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ quarter transform
+// out[q][row] = sum_d in[row][d] * C[d][q],  row = (a,b,c) flattened, rows = n^3.
+// MFMA roles: M <-> q (rotated index, C from LDS), N <-> row (16 tensor rows per wave step),
+// K <-> d.  Rows of `in` are n contiguous doubles, so the 16 rows a wave consumes form one
+// contiguous 16*n*8-byte block; the output is written as 128-byte row segments.
+template <int NPAD>
+__global__ __launch_bounds__(256) void qt_kernel(const double *__restrict__ in, const double *__restrict__ C,
+                                                 int ct, int n, int64_t rows, double *__restrict__ out) {
+    constexpr int LDX = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;  // keeps the two 16-lane halves on disjoint banks
+    constexpr int KSTEPS = NPAD / 4;
+    constexpr int NT = NPAD / 16;
+    __shared__ double Xs[NPAD * LDX];
+    for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += 256) {
+        const int d = idx / NPAD, q = idx % NPAD;
+        double v = 0.0;
+        if (d < n && q < n) v = ct ? C[q * n + d] : C[d * n + q];
+        Xs[d * LDX + q] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t ntiles = (rows + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 16 + l15;
+        const bool rok = row < rows;
+        double b[KSTEPS];
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int d = 4 * kk + l4;
+            b[kk] = (rok && d < n) ? in[row * n + d] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t * 16 < n) {
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk)
+                    acc = mfma_f64(Xs[(4 * kk + l4) * LDX + t * 16 + l15], b[kk], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = t * 16 + l4 + 4 * r;
+                    if (rok && q < n) out[(int64_t)q * rows + row] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+template <int NPAD>
+static int qt_launch(const double *in, const double *C, int ct, int n, double *out, hipStream_t st) {
+    const int64_t rows = (int64_t)n * n * n;
+    const int64_t ntiles = (rows + 15) / 16;
+    int64_t blocks = (ntiles + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(qt_kernel<NPAD>, dim3((unsigned)blocks), dim3(256), 0, st, in, C, ct, n, rows, out);
+    EVC_LAUNCH_CHECK("quarter_transform");
+    return 0;
+}
+
+int launch_quarter_transform(const double *in, const double *C, int ct, int n, double *out, hipStream_t st) {
+    const int npad = (n + 15) / 16 * 16;
+    switch (npad) {
+        case 16: return qt_launch<16>(in, C, ct, n, out, st);
+        case 32: return qt_launch<32>(in, C, ct, n, out, st);
+        case 48: return qt_launch<48>(in, C, ct, n, out, st);
+        case 64: return qt_launch<64>(in, C, ct, n, out, st);
+        case 80: return qt_launch<80>(in, C, ct, n, out, st);
+        case 96: return qt_launch<96>(in, C, ct, n, out, st);
+        default: break;
+    }
+    set_error("quarter_transform: n=%d not supported (1..96)", n);
+    return -1;
+}
+
+// ------------------------------------------------------------------ pack / unpack
+__global__ void pack_kernel(const double *__restrict__ h2, int n, double mult, double *__restrict__ out,
+                            int64_t M, int64_t out_len) {
+    const int64_t n2 = (int64_t)n * n;
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < out_len;
+         m += (int64_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (m < M) {
+            const int64_t R = tri_row(m), Cc = m - R * (R + 1) / 2;
+            v = h2[R * n2 + Cc];
+            if (R == Cc) v *= mult;
+        }
+        out[m] = v;
+    }
+}
+
+__global__ void unpack_kernel(const double *__restrict__ p, int n, double *__restrict__ out) {
+    const int64_t n2 = (int64_t)n * n, n4 = n2 * n2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t R = idx / n2, Cc = idx - R * n2;
+        out[idx] = R >= Cc ? p[tri_index(R, Cc)] : p[tri_index(Cc, R)];
+    }
+}
+
+static unsigned grid_for(int64_t work, int block) {
+    int64_t g = (work + block - 1) / block;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int launch_pack(const double *h2, int n, double mult, double *out, int64_t out_len, hipStream_t st) {
+    const int64_t n2 = (int64_t)n * n, M = n2 * (n2 + 1) / 2;
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(out_len, 256)), dim3(256), 0, st, h2, n, mult, out, M, out_len);
+    EVC_LAUNCH_CHECK("pack_pair_sym");
+    return 0;
+}
+
+int launch_unpack(const double *p, int n, double *out, hipStream_t st) {
+    const int64_t n4 = (int64_t)n * n * n * n;
+    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, st, p, n, out);
+    EVC_LAUNCH_CHECK("unpack_pair_sym");
+    return 0;
+}
+
+// ------------------------------------------------------------------ OAO symmetrisation (transposed)
+// GsT[(j,k,l)][i] = G[i,j,k,l] + G[j,i,k,l] + G[l,k,j,i] + G[k,l,i,j]
+__global__ void sym_oao_t_kernel(const double *__restrict__ G, int n, double *__restrict__ out) {
+    const int64_t n2 = (int64_t)n * n, n3 = n2 * n, n4 = n2 * n2;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n4;
+         o += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(o % n);
+        int64_t r = o / n;
+        const int l = (int)(r % n);
+        r /= n;
+        const int k = (int)(r % n);
+        const int j = (int)(r / n);
+        out[o] = G[i * n3 + j * n2 + k * n + l] + G[j * n3 + i * n2 + k * n + l] +
+                 G[l * n3 + k * n2 + j * n + i] + G[k * n3 + l * n2 + i * n + j];
+    }
+}
+
+int launch_sym_oao_t(const double *G, int n, double *out, hipStream_t st) {
+    const int64_t n4 = (int64_t)n * n * n * n;
+    hipLaunchKernelGGL(sym_oao_t_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, st, G, n, out);
+    EVC_LAUNCH_CHECK("sym_oao_t");
+    return 0;
+}
+
+// ------------------------------------------------------------------ Y2 contraction (split-K MFMA GEMM)
+// partial[slab][i][a] = sum_{k in slab} GsT[k][i] * K3[k][a],  k = (j,k,l) flattened, n^3 long.
+// Both operands are [k][n] row-major, so each MFMA fragment load is 16 contiguous doubles.
+constexpr int kY2Slabs = 128;
+int y2_slabs(int) { return kY2Slabs; }
+
+template <int NT>
+__global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT, const double *__restrict__ K3,
+                                                 int n, int64_t ktot, double *__restrict__ partial) {
+    __shared__ double red[4][NT * 16][NT * 16 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t ksteps = (ktot + 3) / 4;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int64_t per = (ksteps + nw - 1) / nw;
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t ks0 = w * per, ks1 = min(ksteps, ks0 + per);
+    d4 acc[NT][NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int64_t ks = ks0; ks < ks1; ++ks) {
+        const int64_t k = ks * 4 + l4;
+        const bool kok = k < ktot;
+        double af[NT], bf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = t * 16 + l15;
+            const bool ok = kok && c < n;
+            af[t] = ok ? GsT[k * n + c] : 0.0;
+            bf[t] = ok ? K3[k * n + c] : 0.0;
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(af[ti], bf[ta], acc[ti][ta]);
+    }
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
+    __syncthreads();
+    double *dst = partial + (int64_t)blockIdx.x * n * n;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, a = idx % n;
+        dst[idx] = (red[0][i][a] + red[1][i][a]) + (red[2][i][a] + red[3][i][a]);
+    }
+}
+
+int launch_y2(const double *GsT, const double *K3, int n, double *partial, hipStream_t st) {
+    const int64_t ktot = (int64_t)n * n * n;
+    const int nt = (n + 15) / 16;
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(y2_kernel<1>, dim3(kY2Slabs), dim3(256), 0, st, GsT, K3, n, ktot, partial); break;
+        case 2: hipLaunchKernelGGL(y2_kernel<2>, dim3(kY2Slabs), dim3(256), 0, st, GsT, K3, n, ktot, partial); break;
+        case 3: hipLaunchKernelGGL(y2_kernel<3>, dim3(kY2Slabs), dim3(256), 0, st, GsT, K3, n, ktot, partial); break;
+        case 4: hipLaunchKernelGGL(y2_kernel<4>, dim3(kY2Slabs), dim3(256), 0, st, GsT, K3, n, ktot, partial); break;
+        default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
+    }
+    EVC_LAUNCH_CHECK("y2");
+    return 0;
+}
+
+// ------------------------------------------------------------------ ip1 contraction + dhcore dots
+// t2part[(m*3+x)*nchunk + ch] = sum_{e in chunk ch} ip1[x][m][e] * GsAO[m][e],  e = (b,c,d)
+// GsAO[m,b,c,d] = G[m,b,c,d] + G[b,m,d,c] + G[c,d,m,b] + G[d,c,b,m]   (G = 2-RDM in the AO basis)
+// Extra blocks (blockIdx.x >= n*nchunk): term3[A*3+x] = sum_ab dhcore[A,x,a,b] * Pao[a,b].
+constexpr int kIp1PerThread = 4;
+int ip1_chunks(int n) {
+    const int64_t n3 = (int64_t)n * n * n;
+    return (int)ceil_div(n3, 256 * kIp1PerThread);
+}
+
+__global__ __launch_bounds__(256) void ip1_dh_kernel(const double *__restrict__ ip1, const double *__restrict__ G,
+                                                     int n, int nchunk, double *__restrict__ t2part,
+                                                     const double *__restrict__ dh, const double *__restrict__ Pao,
+                                                     int natm, double *__restrict__ term3) {
+    __shared__ double scr[3][4];
+    const int64_t n2 = (int64_t)n * n, n3 = n2 * n, n4 = n2 * n2;
+    const int nb1 = n * nchunk;
+    if ((int)blockIdx.x < nb1) {
+        const int m = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        const int64_t e0 = (int64_t)ch * 256 * kIp1PerThread;
+#pragma unroll
+        for (int u = 0; u < kIp1PerThread; ++u) {
+            const int64_t e = e0 + u * 256 + threadIdx.x;
+            if (e < n3) {
+                const int d = (int)(e % n);
+                const int c = (int)((e / n) % n);
+                const int b = (int)(e / n2);
+                const double gs = G[m * n3 + e] + G[b * n3 + m * n2 + d * n + c] +
+                                  G[c * n3 + d * n2 + m * n + b] + G[d * n3 + c * n2 + b * n + m];
+                const int64_t off = m * n3 + e;
+                a0 = fma(ip1[off], gs, a0);
+                a1 = fma(ip1[n4 + off], gs, a1);
+                a2 = fma(ip1[2 * n4 + off], gs, a2);
+            }
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+            scr[0][wave] = a0;
+            scr[1][wave] = a1;
+            scr[2][wave] = a2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int x = threadIdx.x;
+            t2part[((int64_t)m * 3 + x) * nchunk + ch] = (scr[x][0] + scr[x][1]) + (scr[x][2] + scr[x][3]);
+        }
+    } else {
+        const int ax = blockIdx.x - nb1;  // A*3 + x
+        if (ax >= natm * 3) return;
+        const double *p = dh + (int64_t)ax * n2;
+        double s = 0.0;
+        for (int64_t e = threadIdx.x; e < n2; e += 256) s = fma(p[e], Pao[e], s);
+        s = block_sum<4>(s, &scr[0][0]);
+        if (threadIdx.x == 0) term3[ax] = s;
+    }
+}
+
+int launch_ip1_dh(const double *ip1, const double *Gao, int n, double *t2part, const double *dhcore,
+                  const double *Pao, int natm, double *term3, hipStream_t st) {
+    const int nchunk = ip1_chunks(n);
+    const int blocks = n * nchunk + natm * 3;
+    hipLaunchKernelGGL(ip1_dh_kernel, dim3(blocks), dim3(256), 0, st, ip1, Gao, n, nchunk, t2part, dhcore, Pao,
+                       natm, term3);
+    EVC_LAUNCH_CHECK("ip1_dh");
+    return 0;
+}
+
+}  // namespace evc
+
+// ------------------------------------------------------------------ C ABI
+using namespace evc;
+
+extern "C" int evc_quarter_transform(const double *in, const double *C, int c_transposed, int n, double *out,
+                                     void *stream) {
+    EVC_REQUIRE(in && C && out, "evc_quarter_transform: null pointer");
+    EVC_REQUIRE(n >= 1 && n <= 96, "evc_quarter_transform: n=%d out of range 1..96", n);
+    EVC_REQUIRE(in != out, "evc_quarter_transform: in and out must not alias");
+    return launch_quarter_transform(in, C, c_transposed, n, out, as_stream(stream));
+}
+
+extern "C" int evc_four_index_transform(const double *in, const double *C, int c_transposed, int n, double *out,
+                                        double *tmp, double *three_quarter, void *stream) {
+    EVC_REQUIRE(in && C && out && tmp, "evc_four_index_transform: null pointer");
+    EVC_REQUIRE(n >= 1 && n <= 96, "evc_four_index_transform: n=%d out of range 1..96", n);
+    EVC_REQUIRE(in != out && in != tmp && out != tmp && three_quarter != out && three_quarter != tmp &&
+                    three_quarter != in,
+                "evc_four_index_transform: buffers must not alias");
+    hipStream_t st = as_stream(stream);
+    // in -> out -> tmp -> (three_quarter | out) -> out ; the third result must survive in
+    // `three_quarter` when requested, otherwise ping-pong between out and tmp.
+    int rc;
+    if ((rc = launch_quarter_transform(in, C, c_transposed, n, out, st))) return rc;
+    if ((rc = launch_quarter_transform(out, C, c_transposed, n, tmp, st))) return rc;
+    double *third = three_quarter ? three_quarter : out;
+    if ((rc = launch_quarter_transform(tmp, C, c_transposed, n, third, st))) return rc;
+    if (three_quarter) return launch_quarter_transform(third, C, c_transposed, n, out, st);
+    if ((rc = launch_quarter_transform(third, C, c_transposed, n, tmp, st))) return rc;
+    // result sits in tmp: copy back (device-to-device, same stream)
+    hipError_t e = hipMemcpyAsync(out, tmp, sizeof(double) * (size_t)n * n * n * n, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        set_error("evc_four_index_transform: copy failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+extern "C" int evc_pack_pair_sym(const double *h2, int n, double diag_mult, double *out, int64_t out_len,
+                                 void *stream) {
+    EVC_REQUIRE(h2 && out, "evc_pack_pair_sym: null pointer");
+    EVC_REQUIRE(n >= 1 && n <= 215, "evc_pack_pair_sym: n=%d out of range", n);
+    const int64_t n2 = (int64_t)n * n, M = n2 * (n2 + 1) / 2;
+    EVC_REQUIRE(out_len >= M, "evc_pack_pair_sym: out_len=%lld < M=%lld", (long long)out_len, (long long)M);
+    return launch_pack(h2, n, diag_mult, out, out_len, as_stream(stream));
+}
+
+extern "C" int evc_unpack_pair_sym(const double *packed, int n, double *out, void *stream) {
+    EVC_REQUIRE(packed && out, "evc_unpack_pair_sym: null pointer");
+    EVC_REQUIRE(n >= 1 && n <= 215, "evc_unpack_pair_sym: n=%d out of range", n);
+    return launch_unpack(packed, n, out, as_stream(stream));
+}

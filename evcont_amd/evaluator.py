@@ -1,0 +1,235 @@
+"""Device-resident continuation evaluator.
+
+``DeviceTRDMs`` uploads the training data (overlap, one- and two-body transition RDMs,
+``FCI_EVCont.py:106-131``) ONCE, in whichever of the reference's four layouts the caller
+holds (``ab_initio_eigenvector_continuation.py:41-68``), as a ``(rows, ld)`` float64
+matrix in HBM with 128-byte-aligned rows.  ``DeviceAO`` holds the AO integrals of one
+geometry.  ``ContinuationEvaluator`` owns the workspace and the output buffers and
+enqueues the per-geometry DAG through the C ABI (``include/evcont_hip.h``); results stay
+on the device until the caller reads them.
+
+PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import TrdmSet, Geometry, Outputs, check
+
+F64 = torch.float64
+
+
+def _dev(device=None) -> torch.device:
+    if device is None:
+        if not torch.cuda.is_available():
+            raise _lib.EvcontHipError("no HIP device visible: evcont_amd needs an MI355X (there is no CPU fallback)")
+        return torch.device("cuda", torch.cuda.current_device())
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise _lib.EvcontHipError(f"device {d} is not a HIP device")
+    return d
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def layout_shape(layout: int, T: int, n: int) -> Tuple[int, int]:
+    """(rows, cols) of the matrix view of a two-body t-RDM in the given layout."""
+    n2 = n * n
+    rows = T * (T + 1) // 2 if layout in (5, 2) else T * T
+    cols = n2 * (n2 + 1) // 2 if layout in (3, 2) else n2 * n2
+    return rows, cols
+
+
+def infer_layout(two_RDM, T: int, n: int) -> int:
+    nd = two_RDM.ndim
+    assert nd in (6, 5, 3, 2), "two_RDM must have 6, 5, 3 or 2 dimensions"  # evcont.py:70-71
+    rows, cols = layout_shape(nd, T, n)
+    got = (int(np.prod(two_RDM.shape[: 2 if nd in (6, 3) else 1])), int(np.prod(two_RDM.shape[2 if nd in (6, 3) else 1:])))
+    if got != (rows, cols):
+        raise ValueError(f"two_RDM shape {tuple(two_RDM.shape)} inconsistent with T={T}, N={n} (layout ndim {nd})")
+    return nd
+
+
+def _upload_rows(src: np.ndarray, rows: int, cols: int, r0: int, r1: int, device) -> Tuple[torch.Tensor, int]:
+    """Copy rows [r0,r1) of the (rows, cols) view of `src` into a zero-padded (r1-r0, ld) device matrix."""
+    ld = (cols + 15) // 16 * 16
+    out = torch.zeros((max(r1 - r0, 1), ld), dtype=F64, device=device)
+    lead = src.shape[: src.ndim - (4 if src.ndim in (6, 5) else 1)]
+    step = max(1, (256 << 20) // (cols * 8))
+    for a in range(r0, r1, step):
+        b = min(r1, a + step)
+        idx = np.unravel_index(np.arange(a, b), lead)
+        block = np.ascontiguousarray(src[idx], dtype=np.float64).reshape(b - a, cols)
+        out[a - r0:b - r0, :cols].copy_(torch.from_numpy(block), non_blocking=False)
+    return out, ld
+
+
+class DeviceTRDMs:
+    """Training data resident in HBM.  ``row_range`` selects the slice of two-body rows this
+    rank owns (pair sharding); the one-body t-RDM and S are replicated."""
+
+    def __init__(self, one_RDM, two_RDM, S, device=None, row_range: Optional[Tuple[int, int]] = None):
+        self.device = _dev(device)
+        one_RDM = np.asarray(one_RDM) if not torch.is_tensor(one_RDM) else one_RDM
+        S = np.asarray(S) if not torch.is_tensor(S) else S
+        T = int(S.shape[0])
+        n = int(one_RDM.shape[-1])
+        assert tuple(one_RDM.shape) == (T, T, n, n), "one_RDM must be (T,T,N,N)"
+        self.T, self.n = T, n
+        if torch.is_tensor(two_RDM):
+            self.layout = infer_layout(two_RDM, T, n)
+            rows, cols = layout_shape(self.layout, T, n)
+            r0, r1 = row_range if row_range is not None else (0, rows)
+            mat = two_RDM.reshape(rows, cols)[r0:r1].to(self.device, F64)
+            ld = (cols + 15) // 16 * 16
+            self.two = torch.zeros((max(r1 - r0, 1), ld), dtype=F64, device=self.device)
+            self.two[: r1 - r0, :cols].copy_(mat)
+        else:
+            two_RDM = np.asarray(two_RDM)
+            self.layout = infer_layout(two_RDM, T, n)
+            rows, cols = layout_shape(self.layout, T, n)
+            r0, r1 = row_range if row_range is not None else (0, rows)
+            self.two, ld = _upload_rows(two_RDM, rows, cols, r0, r1, self.device)
+        assert 0 <= r0 <= r1 <= rows
+        self.rows_total, self.cols, self.ld = rows, cols, ld
+        self.row_offset, self.rows_local = r0, r1 - r0
+        as_t = lambda x: (x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)))
+        self.one = as_t(one_RDM).to(self.device, F64).reshape(T * T, n * n).contiguous()
+        self.S = as_t(S).to(self.device, F64).contiguous()
+        self.cstruct = TrdmSet(n=n, ntrain=T, layout=self.layout, reserved=0, rows2=self.rows_local,
+                               row_offset=self.row_offset, rows2_total=rows, cols2=cols, ld2=ld,
+                               two_rdm=self.two.data_ptr(), one_rdm=self.one.data_ptr(),
+                               s_train=self.S.data_ptr())
+
+    @property
+    def nbytes_streamed_per_pass(self) -> int:
+        """Algorithmic bytes one pass over the local two-body rows reads."""
+        return self.rows_local * self.cols * 8
+
+
+@dataclass
+class DeviceAO:
+    """AO integrals of one geometry on the device (fields as in include/evcont_hip.h evc_geometry)."""
+    S: torch.Tensor
+    hcore: torch.Tensor
+    eri: torch.Tensor
+    enuc: float
+    natm: int = 0
+    ipovlp: Optional[torch.Tensor] = None
+    dhcore: Optional[torch.Tensor] = None
+    eri_ip1: Optional[torch.Tensor] = None
+    gnuc: Optional[torch.Tensor] = None
+    aoslices: Optional[torch.Tensor] = None
+
+    @property
+    def nao(self) -> int:
+        return int(self.S.shape[0])
+
+    @staticmethod
+    def from_arrays(ao, device=None, energy_only: bool = False) -> "DeviceAO":
+        """From any object with the AOArrays fields (numpy)."""
+        d = _dev(device)
+        up = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(d)
+        out = DeviceAO(S=up(ao.S), hcore=up(ao.hcore), eri=up(ao.eri), enuc=float(ao.enuc),
+                       natm=int(np.asarray(ao.aoslices).shape[0]))
+        if not energy_only:
+            out.ipovlp, out.dhcore, out.eri_ip1, out.gnuc = up(ao.ipovlp), up(ao.dhcore), up(ao.eri_ip1), up(ao.gnuc)
+            out.aoslices = torch.from_numpy(np.ascontiguousarray(ao.aoslices, dtype=np.int64)).to(d)
+        return out
+
+    def cstruct(self) -> Geometry:
+        p = lambda t: (t.data_ptr() if t is not None else None)
+        return Geometry(natm=self.natm, reserved=0, enuc=self.enuc, S=p(self.S), hcore=p(self.hcore),
+                        eri=p(self.eri), ipovlp=p(self.ipovlp), dhcore=p(self.dhcore), eri_ip1=p(self.eri_ip1),
+                        gnuc=p(self.gnuc), aoslices=p(self.aoslices))
+
+
+class ContinuationEvaluator:
+    """Energy / energy+force of the continuation at one geometry per call
+    (``get_energy_with_grad``, ``ab_initio_gradients_loewdin.py:308-379``)."""
+
+    def __init__(self, trdms: DeviceTRDMs, natm: int):
+        self.t = trdms
+        self.natm = int(natm)
+        self.lib = _lib.load()
+        d, n, T = trdms.device, trdms.n, trdms.T
+        nbytes = self.lib.evc_workspace_bytes(C.byref(trdms.cstruct), self.natm)
+        if nbytes == 0:
+            raise _lib.EvcontHipError("evc_workspace_bytes: " + self.lib.evc_last_error().decode())
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+        self.ws_bytes = nbytes
+        self.energy = torch.zeros(T, dtype=F64, device=d)
+        self.coeffs = torch.zeros((T, T), dtype=F64, device=d)
+        self.grad = torch.zeros((max(self.natm, 1), 3), dtype=F64, device=d)
+        self.d_pred = torch.zeros((n, n), dtype=F64, device=d)
+        self.g_pred = torch.zeros((n, n, n, n), dtype=F64, device=d)
+        self.hmat = torch.zeros((T, T), dtype=F64, device=d)
+        self.out = Outputs(energy=self.energy.data_ptr(), coeffs=self.coeffs.data_ptr(), grad=self.grad.data_ptr(),
+                           d_pred=self.d_pred.data_ptr(), g_pred=self.g_pred.data_ptr(), hmat=self.hmat.data_ptr())
+
+    # -- single-device fused path -------------------------------------------------------------
+    def enqueue(self, ao: DeviceAO, nroots: int = 1, energy_only: bool = False) -> None:
+        """Enqueue one evaluation on torch's current stream; no synchronisation."""
+        g = ao.cstruct()
+        flags = _lib.FLAG_ENERGY_ONLY if energy_only else 0
+        rc = self.lib.evc_energy_with_grad(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out), int(nroots), flags,
+                                           self.ws.data_ptr(), self.ws_bytes, _stream_ptr(self.t.device))
+        check(rc, "evc_energy_with_grad")
+
+    def energy_with_grad(self, ao: DeviceAO, return_density_matrices: bool = False):
+        self.enqueue(ao, 1, False)
+        torch.cuda.current_stream(self.t.device).synchronize()
+        e = float(self.energy[0].item())
+        self._raise_if_nan(e)
+        g = self.grad[: self.natm].cpu().numpy().copy()
+        if return_density_matrices:
+            return e, g, self.d_pred.cpu().numpy().copy(), self.g_pred.cpu().numpy().copy()
+        return e, g
+
+    def energies(self, ao: DeviceAO, nroots: int = 1):
+        """Lowest ``nroots`` total energies and their coefficient vectors (rows)."""
+        self.enqueue(ao, nroots, True)
+        torch.cuda.current_stream(self.t.device).synchronize()
+        e = self.energy[:nroots].cpu().numpy().copy()
+        self._raise_if_nan(e[0])
+        return e, self.coeffs.reshape(-1)[: nroots * self.t.T].reshape(nroots, self.t.T).cpu().numpy().copy()
+
+    @staticmethod
+    def _raise_if_nan(e):
+        if not np.isfinite(e):
+            # scipy.linalg.eigh raises LinAlgError when S is not positive definite (evcont.py:75)
+            raise np.linalg.LinAlgError("generalised eigenproblem failed: overlap matrix not positive definite "
+                                        "or non-finite input")
+
+    # -- phase API for the pair-sharded multi-GPU host (evcont_amd/distributed.py) -----------------
+    def phase_hamiltonian(self, ao: DeviceAO) -> torch.Tensor:
+        """Returns a view of this rank's scaled two-body rows (length rows_local) in the workspace."""
+        g = ao.cstruct()
+        p_rows, p_h1 = C.c_void_p(), C.c_void_p()
+        rc = self.lib.evc_phase_hamiltonian(C.byref(self.t.cstruct), C.byref(g), self.ws.data_ptr(), self.ws_bytes,
+                                            C.byref(p_rows), C.byref(p_h1), _stream_ptr(self.t.device))
+        check(rc, "evc_phase_hamiltonian")
+        off = p_rows.value - self.ws.data_ptr()
+        return self.ws[off: off + 8 * self.t.rows_local].view(F64)
+
+    def phase_solve(self, ao: DeviceAO, rows_all: torch.Tensor, nroots: int = 1) -> None:
+        g = ao.cstruct()
+        assert rows_all.dtype == F64 and rows_all.numel() == self.t.rows_total and rows_all.is_contiguous()
+        rc = self.lib.evc_phase_solve(C.byref(self.t.cstruct), C.byref(g), rows_all.data_ptr(), C.byref(self.out),
+                                      int(nroots), self.ws.data_ptr(), self.ws_bytes, _stream_ptr(self.t.device))
+        check(rc, "evc_phase_solve")
+
+    def phase_gradient(self, ao: DeviceAO, partial_rank: bool) -> None:
+        g = ao.cstruct()
+        rc = self.lib.evc_phase_gradient(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out),
+                                         _lib.FLAG_PARTIAL_RANK if partial_rank else 0, self.ws.data_ptr(),
+                                         self.ws_bytes, _stream_ptr(self.t.device))
+        check(rc, "evc_phase_gradient")

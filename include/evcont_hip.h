@@ -1,0 +1,190 @@
+/*
+ * evcont_hip.h -- C ABI of libevcont_hip.so: the MI355X (gfx950) kernels behind the
+ * eigenvector-continuation energy/force hot path of BoothGroup/evcont.
+ *
+ * The reference has no FFI layer (it is pure numpy/scipy/PySCF); its boundary for this
+ * path is the Python API of three modules.  Every entry point below replaces one dense
+ * operation of those modules and cites it as file:line under /root/reference/evcont.
+ * The host-side mirror of the Python API (the evcont_amd Python modules) binds these symbols with
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float64 (int64 for aoslices) unless noted;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises, nothing allocates, there is no global state besides a thread-local
+ *     error string;
+ *   - return value 0 = success; <0 = argument error (nothing enqueued);
+ *     >0 = hipError_t of a failed launch;
+ *   - matrices are row-major (C order), exactly as numpy hands them to the reference.
+ */
+#ifndef EVCONT_HIP_H
+#define EVCONT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVC_ABI_VERSION 1
+
+/* t-RDM storage layouts = ndim of the reference's two_RDM argument
+ * (ab_initio_eigenvector_continuation.py:41-68). */
+#define EVC_LAYOUT_FULL6 6 /* (T,T,N,N,N,N)  rows=T*T        cols=N^4          */
+#define EVC_LAYOUT_PAIR5 5 /* (P,N,N,N,N)    rows=T(T+1)/2   cols=N^4          */
+#define EVC_LAYOUT_ELEC3 3 /* (T,T,M)        rows=T*T        cols=N^2(N^2+1)/2 */
+#define EVC_LAYOUT_PACK2 2 /* (P,M)          rows=T(T+1)/2   cols=M            */
+
+int evc_abi_version(void);
+/* Message of the last failing call on this host thread ("" if none). */
+const char *evc_last_error(void);
+
+/* ---------------------------------------------------------------------------------
+ * K5/K4  H2 = Gamma . h2   -- streaming row GEMV (HBM bound)
+ *   y[r] = alpha * sum_{c<cols} A[r*ld + c] * v[c]            r < rows
+ * replaces np.tensordot(two_RDM, h2, axes=4) / two_RDM.dot(h2_compressed) and
+ * np.tensordot(one_RDM, h1, axes=2)   (ab_initio_eigenvector_continuation.py:38,43,47,57,64)
+ * Requirements: A and v 16-byte aligned, ld even, ld >= cols.  `ws` holds the
+ * per-span partial sums (deterministic two-stage reduction, no atomics).
+ * --------------------------------------------------------------------------------- */
+size_t evc_gemv_rows_ws_bytes(int64_t rows, int64_t cols);
+int evc_gemv_rows(const double *A, int64_t rows, int64_t cols, int64_t ld, const double *v,
+                  double alpha, double *y, void *ws, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * K8/K7  Gamma_pred = w . Gamma  -- streaming column GEMV (GEMV-T, HBM bound)
+ *   out[c] = sum_{r<rows} w[r] * A[r*ld + c]                  c < cols
+ * replaces np.tensordot(weights, two_RDM) (ab_initio_gradients_loewdin.py:343,351-356).
+ * Requirements: A and out 16-byte aligned, ld even.
+ * --------------------------------------------------------------------------------- */
+int evc_gemv_cols(const double *A, int64_t rows, int64_t cols, int64_t ld, const double *w,
+                  double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * a4/a5  electron-exchange-symmetry codecs (electron_integral_utils.py:38-66, 69-88)
+ *   pack  : (n,n,n,n) -> row-major lower triangle of the (n^2,n^2) matrix, diagonal * diag_mult;
+ *           elements [M, out_len) of `out` are zero-filled (padding for the streaming GEMV).
+ *   unpack: (M,) -> (n,n,n,n), both triangles.
+ * Out of place (the reference scales the caller's diagonal in place and restores it).
+ * --------------------------------------------------------------------------------- */
+int evc_pack_pair_sym(const double *h2, int n, double diag_mult, double *out, int64_t out_len,
+                      void *stream);
+int evc_unpack_pair_sym(const double *packed, int n, double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * K3/K14  four-index basis rotation, FP64 MFMA (v_mfma_f64_16x16x4_f64)
+ *   quarter step: out[q, a,b,c] = sum_d in[a,b,c,d] * C[d,q]     (c_transposed == 0)
+ *                                 sum_d in[a,b,c,d] * C[q,d]     (c_transposed != 0)
+ *   i.e. the LAST index is rotated and moved to the FRONT; four steps rotate all four
+ *   indices and restore their order.
+ *   full: out[i,j,k,l] = sum_abcd in[a,b,c,d] C[a,i] C[b,j] C[c,k] C[d,l]
+ *   replaces pyscf.ao2mo.kernel + ao2mo.restore(1,..) (electron_integral_utils.py:136,
+ *   ab_initio_gradients_loewdin.py:339) and the OAO->AO back-rotation of the 2-RDM (:224-232,
+ *   with c_transposed=1).  If `three_quarter` is non-NULL it receives the tensor after three
+ *   steps, K[j,k,l,a] = sum_bcd in[a,b,c,d] C[b,j] C[c,k] C[d,l]  (used by K13, :210-222).
+ *   `tmp` is scratch of n^4 doubles; in/out/tmp/three_quarter must not alias.  n <= 128.
+ * --------------------------------------------------------------------------------- */
+int evc_quarter_transform(const double *in, const double *C, int c_transposed, int n,
+                          double *out, void *stream);
+int evc_four_index_transform(const double *in, const double *C, int c_transposed, int n,
+                             double *out, double *tmp, double *three_quarter, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * K1/K2  Loewdin orthogonalisation on one workgroup (parallel cyclic Jacobi in LDS)
+ *   S = U diag(s) U^T ; X = U diag(s>1e-15 ? s^-1/2 : 0) U^T ; h1 = X^T hcore X
+ *   replaces get_loewdin_trafo (electron_integral_utils.py:6-18) and the h1 rotation
+ *   (:135, ab_initio_gradients_loewdin.py:338).  hcore/h1 may be NULL.  n <= 96.
+ * --------------------------------------------------------------------------------- */
+int evc_loewdin(const double *S, const double *hcore, int n, double *X, double *U, double *s,
+                double *h1, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * K6  subspace generalised eigenproblem H c = E S c on one workgroup
+ *   H is assembled from the one-body part h1rows (T*T) and the two-body rows
+ *   (rows2 = T*T or T(T+1)/2 values, already scaled) exactly as
+ *   ab_initio_eigenvector_continuation.py:38-68 does, then solved like scipy.linalg.eigh(H,S)
+ *   (LAPACK dsygvd: lower triangles, Cholesky of S, c^T S c = 1) (:73-88, :157-173).
+ *   Outputs: evals[nroots] ascending (+ e_shift), evecs[nroots*T] (row k = k-th vector),
+ *   w2[rows2] / w1[T*T]: weights of the two-/one-body t-RDM rows for the predicted RDMs of
+ *   root 0 (ab_initio_gradients_loewdin.py:343-356), Hout[T*T] (may be NULL): the matrix handed
+ *   to the eigensolver.  T <= 64.  Hermitian branch only.
+ * --------------------------------------------------------------------------------- */
+int evc_subspace_solve(const double *h1rows, const double *h2rows, const double *S_train, int T,
+                       int layout, int nroots, double e_shift, double *evals, double *evecs,
+                       double *w2, double *w1, double *Hout, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused per-geometry pipeline (ab_initio_gradients_loewdin.py:308-379 get_energy_with_grad,
+ * ab_initio_eigenvector_continuation.py:178-250 *_OAO)
+ * --------------------------------------------------------------------------------- */
+typedef struct evc_trdm_set {
+    int32_t n;           /* orbitals N */
+    int32_t ntrain;      /* training states T */
+    int32_t layout;      /* EVC_LAYOUT_* */
+    int32_t reserved;
+    int64_t rows2;       /* rows of the two-body matrix view held by THIS rank */
+    int64_t row_offset;  /* index of the first local row in the global row numbering */
+    int64_t rows2_total; /* global number of rows (T*T or T(T+1)/2) */
+    int64_t cols2;       /* N^4 or M */
+    int64_t ld2;         /* leading dimension of two_rdm (even, >= cols2) */
+    const double *two_rdm; /* (rows2, ld2) */
+    const double *one_rdm; /* (T*T, N*N) contiguous, replicated on every rank */
+    const double *s_train; /* (T,T) */
+} evc_trdm_set;
+
+typedef struct evc_geometry {
+    int32_t natm;
+    int32_t reserved;
+    double enuc;             /* mol.energy_nuc() */
+    const double *S;         /* (N,N)       int1e_ovlp */
+    const double *hcore;     /* (N,N)       scf.hf.get_hcore */
+    const double *eri;       /* (N,N,N,N)   int2e */
+    const double *ipovlp;    /* (3,N,N)     int1e_ipovlp             (NULL: energy only) */
+    const double *dhcore;    /* (A,3,N,N)   hcore_generator()(atom)  (NULL: energy only) */
+    const double *eri_ip1;   /* (3,N,N,N,N) int2e_ip1                (NULL: energy only) */
+    const double *gnuc;      /* (A,3)       grad_nuc()               (NULL: energy only) */
+    const int64_t *aoslices; /* (A,2) [start,stop)                   (NULL: energy only) */
+} evc_geometry;
+
+typedef struct evc_outputs {
+    double *energy;  /* [nroots]  total energies (electronic + enuc) */
+    double *coeffs;  /* [nroots*T] */
+    double *grad;    /* [A*3] or NULL */
+    double *d_pred;  /* [N*N]  predicted 1-RDM (always written by the gradient phase) */
+    double *g_pred;  /* [N^4]  predicted 2-RDM, unpacked (always written by the gradient phase) */
+    double *hmat;    /* [T*T] or NULL: matrix handed to the eigensolver */
+} evc_outputs;
+
+/* flags */
+#define EVC_FLAG_ENERGY_ONLY 1  /* stop after the eigensolve */
+#define EVC_FLAG_PARTIAL_RANK 2 /* multi-GPU: this rank is not rank 0 -> its partial gradient carries
+                                   only the two-body contribution of its rows */
+
+size_t evc_workspace_bytes(const evc_trdm_set *t, int natm);
+
+/* Phase A: Loewdin + integrals + H rows.  Writes h2rows_local[rows2] (scaled two-body rows of this
+ * rank) and h1rows[T*T] into the workspace; pointers are returned through the out arguments so a
+ * multi-GPU host can all-gather the rows between the phases. */
+int evc_phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, void *ws, size_t ws_bytes,
+                          double **h2rows_local, double **h1rows, void *stream);
+/* Phase B: eigensolve from the complete row vector h2rows_all[rows2_total]. */
+int evc_phase_solve(const evc_trdm_set *t, const evc_geometry *g, const double *h2rows_all,
+                    const evc_outputs *out, int nroots, void *ws, size_t ws_bytes, void *stream);
+/* Phase C: predicted RDMs of root 0 + Loewdin-response nuclear gradient. */
+int evc_phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
+                       int flags, void *ws, size_t ws_bytes, void *stream);
+/* A+B(+C) back to back on one device. */
+int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
+                         int nroots, int flags, void *ws, size_t ws_bytes, void *stream);
+
+/* Gradient of given (not predicted) RDMs: get_grad_elec_OAO (ab_initio_gradients_loewdin.py:255-305)
+ * with the Loewdin trafo of g->S; writes the ELECTRONIC gradient (no grad_nuc) to grad[A*3]. */
+int evc_grad_elec_oao(int n, const evc_geometry *g, const double *one_rdm, const double *two_rdm,
+                      double *grad, void *ws, size_t ws_bytes, void *stream);
+size_t evc_grad_elec_ws_bytes(int n, int natm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVCONT_HIP_H */
