@@ -69,6 +69,9 @@ SIGNATURES = {
     "evc_grad_elec_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "evc_grad_elec_oao": (C.c_int, [C.c_int, C.POINTER(Geometry), C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "evc_profile_begin": (C.c_int, [C.c_int]),
+    "evc_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_int)]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -11,7 +11,7 @@ namespace evc {
 // ------------------------------------------------------------------ rows GEMV
 // Workgroup = 256 lanes x 16 B = one 512-column chunk of RB rows per step; a block owns a
 // span of `cps` chunks, keeps v for the chunk in registers and RB accumulators per lane.
-// Partials go to ws[row][span]; the consumer sums the spans in fixed order (deterministic).
+// Partials go to ws[span][row]; the consumer sums the spans in fixed order (deterministic).
 constexpr int kRB = 8;
 constexpr int kChunk = 512;  // columns per workgroup step
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvRowsLaunch L) {
     __syncthreads();
     if (tid < nrows) {
         const double s = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
-        P.partial[(row0 + tid) * P.nspans + span] = s;
+        P.partial[(int64_t)span * P.rows + row0 + tid] = s;
     }
 }
 
@@ -86,7 +86,7 @@ __global__ void gemv_rows_reduce_kernel(const double *partial, int64_t rows, int
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     double s = 0.0;
-    for (int k = 0; k < nspans; ++k) s += partial[r * nspans + k];
+    for (int k = 0; k < nspans; ++k) s += partial[(int64_t)k * rows + r];
     y[r] = alpha * s;
 }
 

@@ -43,8 +43,10 @@ int y2_slabs(int n);
 int launch_y2(const double *GsT, const double *K3, int n, double *partial, hipStream_t st);
 // ip1 contraction with on-the-fly AO symmetrisation (gradients_loewdin.py:234-252) + dhcore:P_ao dots
 int ip1_chunks(int n);
+// ... and the fixed-order sum of the Y2 slabs (third block family of the same launch)
 int launch_ip1_dh(const double *ip1, const double *Gao, int n, double *t2_partial, const double *dhcore,
-                  const double *Pao, int natm, double *term3, hipStream_t st);
+                  const double *Pao, int natm, double *term3, const double *y2part, int nslab, double *y2,
+                  hipStream_t st);
 
 // ---- dense_small.hip ---------------------------------------------------------------
 int launch_loewdin(const double *S, const double *hcore, int n, double *X, double *U, double *s, double *h1,
@@ -75,8 +77,7 @@ struct GradFinalArgs {
     int n, natm;
     const double *U, *s;          // eigen-decomposition of S_AO
     const double *Y1;             // (n,n) [a][i]
-    const double *y2part;         // (nslab, n, n) as [i][a]
-    int nslab;
+    const double *y2;             // (n, n) as [i][a]  (slabs already summed)
     const double *ipovlp;         // (3,n,n)
     const int64_t *aoslices;      // (A,2)
     const double *t2part;         // (n, 3, nchunk) partial sums of T2diag[x,m]

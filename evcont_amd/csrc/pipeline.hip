@@ -17,6 +17,16 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// Optional in-stream timing of the two streaming kernels (bench.py's roofline leg): hipEvents are
+// recorded on the launch stream right before/after the kernel, so the figure is the kernel's own
+// duration inside the real per-geometry DAG.  Process-wide, off by default.
+struct Prof {
+    bool on = false;
+    int cap = 0, n_rows = 0, n_cols = 0;
+    hipEvent_t *ev = nullptr;  // [cap][4]: rows start/stop, cols start/stop
+};
+static Prof g_prof;
+
 struct Ws {
     // N^2-sized
     double *X, *U, *s, *h1, *Dpred, *Pao, *Y1;
@@ -26,7 +36,7 @@ struct Ws {
     // t-RDM contraction
     double *h2part, *h1part, *h2rows, *w2, *w1;
     // gradient partials
-    double *y2part, *t2part, *term3;
+    double *y2part, *y2, *t2part, *term3;
     // scratch outputs when the caller passes NULL
     double *evals, *evecs;
     size_t bytes;
@@ -95,6 +105,7 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.w2 = take((size_t)t->rows2 + 1);
     w.w1 = take(T * T);
     w.y2part = take((size_t)y2_slabs((int)n) * n2);
+    w.y2 = take(n2);
     w.t2part = take((size_t)n * 3 * ip1_chunks((int)n));
     w.term3 = take((size_t)(natm > 0 ? natm : 1) * 3);
     w.evals = take(T);
@@ -107,7 +118,7 @@ __global__ void rows_reduce_kernel(const double *partial, int64_t rows, int nspa
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     double s = 0.0;
-    for (int k = 0; k < nspans; ++k) s += partial[r * nspans + k];
+    for (int k = 0; k < nspans; ++k) s += partial[(int64_t)k * rows + r];
     y[r] = alpha * s;
 }
 
@@ -134,7 +145,10 @@ static int phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, Ws &w
     p1.A = t->one_rdm;
     p1.v = w.h1;
     p1.partial = w.h1part;
+    const bool prof = g_prof.on && g_prof.n_rows < g_prof.cap;
+    if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_rows + 0], st);
     if ((rc = launch_gemv_rows(p2, p1, st))) return rc;
+    if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_rows++ + 1], st);
     if (reduce_rows && t->rows2 > 0) {
         const double alpha2 = is_packed(t->layout) ? 1.0 : 0.5;
         hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)ceil_div(t->rows2, 256)), dim3(256), 0, st,
@@ -196,15 +210,16 @@ static int gradient_from_rdms(int n, const evc_geometry *g, const double *D, con
     p.Y1 = w.Y1;
     p.scale1 = scale1;
     if ((rc = launch_grad_prep(p, st))) return rc;
-    if ((rc = launch_ip1_dh(g->eri_ip1, w.B2, n, w.t2part, g->dhcore, w.Pao, g->natm, w.term3, st))) return rc;
+    if ((rc = launch_ip1_dh(g->eri_ip1, w.B2, n, w.t2part, g->dhcore, w.Pao, g->natm, w.term3, w.y2part,
+                            y2_slabs(n), w.y2, st)))
+        return rc;
     GradFinalArgs f;
     f.n = n;
     f.natm = g->natm;
     f.U = w.U;
     f.s = w.s;
     f.Y1 = w.Y1;
-    f.y2part = w.y2part;
-    f.nslab = y2_slabs(n);
+    f.y2 = w.y2;
     f.ipovlp = g->ipovlp;
     f.aoslices = g->aoslices;
     f.t2part = w.t2part;
@@ -235,7 +250,10 @@ static int phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const ev
     c1.cols = (int64_t)n * n;
     c1.ld = c1.cols;
     c1.out = D;
+    const bool prof = g_prof.on && g_prof.n_cols < g_prof.cap;
+    if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_cols + 2], st);
     if ((rc = launch_gemv_cols(c2, c1, st))) return rc;
+    if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_cols++ + 3], st);
     if (is_packed(t->layout))
         if ((rc = launch_unpack(w.vec2, n, G, st))) return rc;
     const bool partial = (flags & EVC_FLAG_PARTIAL_RANK) != 0;
@@ -259,6 +277,48 @@ using namespace evc;
 
 extern "C" int evc_abi_version(void) { return EVC_ABI_VERSION; }
 extern "C" const char *evc_last_error(void) { return g_err; }
+
+extern "C" int evc_profile_begin(int max_samples) {
+    EVC_REQUIRE(!g_prof.on, "evc_profile_begin: already profiling");
+    EVC_REQUIRE(max_samples > 0 && max_samples <= 1 << 20, "evc_profile_begin: max_samples=%d", max_samples);
+    g_prof.ev = new hipEvent_t[4 * (size_t)max_samples];
+    for (int i = 0; i < 4 * max_samples; ++i) {
+        hipError_t e = hipEventCreate(&g_prof.ev[i]);
+        if (e != hipSuccess) {
+            set_error("evc_profile_begin: hipEventCreate: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    g_prof.cap = max_samples;
+    g_prof.n_rows = g_prof.n_cols = 0;
+    g_prof.on = true;
+    return 0;
+}
+
+extern "C" int evc_profile_end(double *rows_ms, int *rows_n, double *cols_ms, int *cols_n) {
+    EVC_REQUIRE(g_prof.on, "evc_profile_end: not profiling");
+    double tr = 0.0, tc = 0.0;
+    for (int i = 0; i < g_prof.n_rows; ++i) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(g_prof.ev[4 * i + 1]);
+        (void)hipEventElapsedTime(&ms, g_prof.ev[4 * i + 0], g_prof.ev[4 * i + 1]);
+        tr += ms;
+    }
+    for (int i = 0; i < g_prof.n_cols; ++i) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(g_prof.ev[4 * i + 3]);
+        (void)hipEventElapsedTime(&ms, g_prof.ev[4 * i + 2], g_prof.ev[4 * i + 3]);
+        tc += ms;
+    }
+    if (rows_ms) *rows_ms = tr;
+    if (rows_n) *rows_n = g_prof.n_rows;
+    if (cols_ms) *cols_ms = tc;
+    if (cols_n) *cols_n = g_prof.n_cols;
+    for (int i = 0; i < 4 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    delete[] g_prof.ev;
+    g_prof = Prof();
+    return 0;
+}
 
 extern "C" size_t evc_workspace_bytes(const evc_trdm_set *t, int natm) {
     if (check_set(t)) return 0;

@@ -241,7 +241,9 @@ int ip1_chunks(int n) {
 __global__ __launch_bounds__(256) void ip1_dh_kernel(const double *__restrict__ ip1, const double *__restrict__ G,
                                                      int n, int nchunk, double *__restrict__ t2part,
                                                      const double *__restrict__ dh, const double *__restrict__ Pao,
-                                                     int natm, double *__restrict__ term3) {
+                                                     int natm, double *__restrict__ term3,
+                                                     const double *__restrict__ y2part, int nslab,
+                                                     double *__restrict__ y2) {
     __shared__ double scr[3][4];
     const int64_t n2 = (int64_t)n * n, n3 = n2 * n, n4 = n2 * n2;
     const int nb1 = n * nchunk;
@@ -278,23 +280,41 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(const double *__restrict__ 
             const int x = threadIdx.x;
             t2part[((int64_t)m * 3 + x) * nchunk + ch] = (scr[x][0] + scr[x][1]) + (scr[x][2] + scr[x][3]);
         }
-    } else {
+    } else if ((int)blockIdx.x < nb1 + natm * 3) {
         const int ax = blockIdx.x - nb1;  // A*3 + x
-        if (ax >= natm * 3) return;
         const double *p = dh + (int64_t)ax * n2;
         double s = 0.0;
         for (int64_t e = threadIdx.x; e < n2; e += 256) s = fma(p[e], Pao[e], s);
         s = block_sum<4>(s, &scr[0][0]);
         if (threadIdx.x == 0) term3[ax] = s;
+    } else {
+        // y2[e] = sum_slab y2part[slab][e]: 64 elements per block, 4 slab groups per element
+        const int b = blockIdx.x - nb1 - natm * 3;
+        const int e = b * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+        __shared__ double part[4][64];
+        double s0 = 0.0, s1 = 0.0;
+        if (e < n2) {
+            int sl = grp;
+            for (; sl + 4 < nslab; sl += 8) {
+                s0 += y2part[(int64_t)sl * n2 + e];
+                s1 += y2part[(int64_t)(sl + 4) * n2 + e];
+            }
+            if (sl < nslab) s0 += y2part[(int64_t)sl * n2 + e];
+        }
+        part[grp][threadIdx.x & 63] = s0 + s1;
+        __syncthreads();
+        if (grp == 0 && e < n2) y2[e] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                                        (part[2][threadIdx.x] + part[3][threadIdx.x]);
     }
 }
 
 int launch_ip1_dh(const double *ip1, const double *Gao, int n, double *t2part, const double *dhcore,
-                  const double *Pao, int natm, double *term3, hipStream_t st) {
+                  const double *Pao, int natm, double *term3, const double *y2part, int nslab, double *y2,
+                  hipStream_t st) {
     const int nchunk = ip1_chunks(n);
-    const int blocks = n * nchunk + natm * 3;
+    const int blocks = n * nchunk + natm * 3 + (n * n + 63) / 64;
     hipLaunchKernelGGL(ip1_dh_kernel, dim3(blocks), dim3(256), 0, st, ip1, Gao, n, nchunk, t2part, dhcore, Pao,
-                       natm, term3);
+                       natm, term3, y2part, nslab, y2);
     EVC_LAUNCH_CHECK("ip1_dh");
     return 0;
 }

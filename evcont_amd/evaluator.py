@@ -109,6 +109,37 @@ class DeviceTRDMs:
                                two_rdm=self.two.data_ptr(), one_rdm=self.one.data_ptr(),
                                s_train=self.S.data_ptr())
 
+    @classmethod
+    def from_device_rows(cls, one_RDM: torch.Tensor, two_rows: torch.Tensor, S: torch.Tensor, layout: int,
+                         row_offset: int = 0, rows_total: Optional[int] = None) -> "DeviceTRDMs":
+        """Adopt two-body rows already on the device: ``two_rows`` is the (rows_local, cols) slice
+        [row_offset, row_offset+rows_local) of the layout's matrix view (no host round trip)."""
+        self = cls.__new__(cls)
+        self.device = two_rows.device
+        T, n = int(S.shape[0]), int(one_RDM.shape[-1])
+        self.T, self.n, self.layout = T, n, int(layout)
+        rows, cols = layout_shape(self.layout, T, n)
+        if rows_total is not None:
+            assert rows_total == rows
+        assert two_rows.ndim == 2 and two_rows.shape[1] == cols and two_rows.dtype == F64
+        r0, r1 = int(row_offset), int(row_offset) + int(two_rows.shape[0])
+        assert 0 <= r0 <= r1 <= rows
+        ld = (cols + 15) // 16 * 16
+        if ld == cols and two_rows.is_contiguous() and two_rows.shape[0] > 0:
+            self.two = two_rows
+        else:
+            self.two = torch.zeros((max(r1 - r0, 1), ld), dtype=F64, device=self.device)
+            self.two[: r1 - r0, :cols].copy_(two_rows)
+        self.rows_total, self.cols, self.ld = rows, cols, ld
+        self.row_offset, self.rows_local = r0, r1 - r0
+        self.one = one_RDM.to(self.device, F64).reshape(T * T, n * n).contiguous()
+        self.S = S.to(self.device, F64).contiguous()
+        self.cstruct = TrdmSet(n=n, ntrain=T, layout=self.layout, reserved=0, rows2=self.rows_local,
+                               row_offset=self.row_offset, rows2_total=rows, cols2=cols, ld2=ld,
+                               two_rdm=self.two.data_ptr(), one_rdm=self.one.data_ptr(),
+                               s_train=self.S.data_ptr())
+        return self
+
     @property
     def nbytes_streamed_per_pass(self) -> int:
         """Algorithmic bytes one pass over the local two-body rows reads."""
@@ -156,9 +187,13 @@ class ContinuationEvaluator:
     """Energy / energy+force of the continuation at one geometry per call
     (``get_energy_with_grad``, ``ab_initio_gradients_loewdin.py:308-379``)."""
 
-    def __init__(self, trdms: DeviceTRDMs, natm: int):
+    def __init__(self, trdms: DeviceTRDMs, natm: int, stream: Optional["torch.cuda.Stream"] = None):
+        """``stream``: HIP stream every call of this evaluator is enqueued on (default: torch's current
+        stream at call time).  Several evaluators on different streams may share one ``DeviceTRDMs``:
+        each owns its workspace and outputs, so independent geometries overlap on the device."""
         self.t = trdms
         self.natm = int(natm)
+        self.stream = stream
         self.lib = _lib.load()
         d, n, T = trdms.device, trdms.n, trdms.T
         nbytes = self.lib.evc_workspace_bytes(C.byref(trdms.cstruct), self.natm)
@@ -175,18 +210,24 @@ class ContinuationEvaluator:
         self.out = Outputs(energy=self.energy.data_ptr(), coeffs=self.coeffs.data_ptr(), grad=self.grad.data_ptr(),
                            d_pred=self.d_pred.data_ptr(), g_pred=self.g_pred.data_ptr(), hmat=self.hmat.data_ptr())
 
+    def _sp(self) -> int:
+        return self.stream.cuda_stream if self.stream is not None else _stream_ptr(self.t.device)
+
+    def synchronize(self) -> None:
+        (self.stream if self.stream is not None else torch.cuda.current_stream(self.t.device)).synchronize()
+
     # -- single-device fused path -------------------------------------------------------------
     def enqueue(self, ao: DeviceAO, nroots: int = 1, energy_only: bool = False) -> None:
         """Enqueue one evaluation on torch's current stream; no synchronisation."""
         g = ao.cstruct()
         flags = _lib.FLAG_ENERGY_ONLY if energy_only else 0
         rc = self.lib.evc_energy_with_grad(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out), int(nroots), flags,
-                                           self.ws.data_ptr(), self.ws_bytes, _stream_ptr(self.t.device))
+                                           self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_energy_with_grad")
 
     def energy_with_grad(self, ao: DeviceAO, return_density_matrices: bool = False):
         self.enqueue(ao, 1, False)
-        torch.cuda.current_stream(self.t.device).synchronize()
+        self.synchronize()
         e = float(self.energy[0].item())
         self._raise_if_nan(e)
         g = self.grad[: self.natm].cpu().numpy().copy()
@@ -197,7 +238,7 @@ class ContinuationEvaluator:
     def energies(self, ao: DeviceAO, nroots: int = 1):
         """Lowest ``nroots`` total energies and their coefficient vectors (rows)."""
         self.enqueue(ao, nroots, True)
-        torch.cuda.current_stream(self.t.device).synchronize()
+        self.synchronize()
         e = self.energy[:nroots].cpu().numpy().copy()
         self._raise_if_nan(e[0])
         return e, self.coeffs.reshape(-1)[: nroots * self.t.T].reshape(nroots, self.t.T).cpu().numpy().copy()
@@ -215,7 +256,7 @@ class ContinuationEvaluator:
         g = ao.cstruct()
         p_rows, p_h1 = C.c_void_p(), C.c_void_p()
         rc = self.lib.evc_phase_hamiltonian(C.byref(self.t.cstruct), C.byref(g), self.ws.data_ptr(), self.ws_bytes,
-                                            C.byref(p_rows), C.byref(p_h1), _stream_ptr(self.t.device))
+                                            C.byref(p_rows), C.byref(p_h1), self._sp())
         check(rc, "evc_phase_hamiltonian")
         off = p_rows.value - self.ws.data_ptr()
         return self.ws[off: off + 8 * self.t.rows_local].view(F64)
@@ -224,12 +265,12 @@ class ContinuationEvaluator:
         g = ao.cstruct()
         assert rows_all.dtype == F64 and rows_all.numel() == self.t.rows_total and rows_all.is_contiguous()
         rc = self.lib.evc_phase_solve(C.byref(self.t.cstruct), C.byref(g), rows_all.data_ptr(), C.byref(self.out),
-                                      int(nroots), self.ws.data_ptr(), self.ws_bytes, _stream_ptr(self.t.device))
+                                      int(nroots), self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_phase_solve")
 
     def phase_gradient(self, ao: DeviceAO, partial_rank: bool) -> None:
         g = ao.cstruct()
         rc = self.lib.evc_phase_gradient(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out),
                                          _lib.FLAG_PARTIAL_RANK if partial_rank else 0, self.ws.data_ptr(),
-                                         self.ws_bytes, _stream_ptr(self.t.device))
+                                         self.ws_bytes, self._sp())
         check(rc, "evc_phase_gradient")

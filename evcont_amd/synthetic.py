@@ -123,3 +123,63 @@ def pack_rows(two_rdm_full: np.ndarray, pair_sym: bool, elec_sym: bool) -> np.nd
         a, b = np.tril_indices(T)
         g = g[a, b]
     return np.ascontiguousarray(g)
+
+
+# --------------------------------------------------------------------------
+# Device-side generators for the throughput benchmark: same
+# symmetries, generated with torch.Generator(device) so that multi-GB inputs
+# never cross PCIe.  Imported lazily so that the numpy part works without torch.
+# --------------------------------------------------------------------------
+def make_device_ao(nao: int, natm: int, seed: int, device, ao_sizes: Optional[Sequence[int]] = None):
+    """One synthetic geometry resident on the device (evaluator.DeviceAO)."""
+    import torch
+    from .evaluator import DeviceAO
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    n = nao
+    rn = lambda *s: torch.randn(*s, generator=g, device=device, dtype=torch.float64)
+    B = rn(n, n)
+    S = B @ B.T / n + torch.eye(n, device=device, dtype=torch.float64)
+    h = rn(n, n)
+    hcore = 0.5 * (h + h.T)
+    e = 0.1 * rn(n, n, n, n)
+    e = e + e.permute(1, 0, 2, 3)
+    e = e + e.permute(0, 1, 3, 2)
+    e = (e + e.permute(2, 3, 0, 1)) / 8.0
+    ipovlp = 0.1 * rn(3, n, n)
+    dh = rn(natm, 3, n, n)
+    dhcore = 0.5 * (dh + dh.transpose(2, 3))
+    ip1 = 0.1 * rn(3, n, n, n, n)
+    if ao_sizes is None:
+        sl = equal_aoslices(n, natm)
+    else:
+        stops = np.cumsum(ao_sizes)
+        sl = np.stack([stops - np.array(ao_sizes), stops], axis=1).astype(np.int64)
+    enuc = float(rn(1).item())
+    gnuc = rn(natm, 3)
+    return DeviceAO(S=S.contiguous(), hcore=hcore.contiguous(), eri=e.contiguous(), enuc=enuc, natm=natm,
+                    ipovlp=ipovlp.contiguous(), dhcore=dhcore.contiguous(), eri_ip1=ip1.contiguous(),
+                    gnuc=gnuc.contiguous(), aoslices=torch.from_numpy(sl).to(device))
+
+
+def make_device_trdm_rows(nao: int, ntrain: int, layout: int, seed: int, device, row_range=None):
+    """(S_train, one_RDM (T,T,N,N), two-body rows [r0:r1) as a (r1-r0, cols) tensor) on the device.
+
+    Row r of the two-body matrix is generated from its own seed, so a rank that owns a slice
+    of the rows builds exactly the rows the single-device run would hold."""
+    import torch
+    from .evaluator import layout_shape
+    n, T = nao, ntrain
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    A = torch.randn(T, T, generator=g, device=device, dtype=torch.float64)
+    S_train = A @ A.T / T + torch.eye(T, device=device, dtype=torch.float64)
+    d = torch.randn(T, T, n, n, generator=g, device=device, dtype=torch.float64) / n
+    one = 0.5 * (d + d.permute(1, 0, 3, 2))
+    rows, cols = layout_shape(layout, T, n)
+    r0, r1 = row_range if row_range is not None else (0, rows)
+    two = torch.empty((r1 - r0, cols), dtype=torch.float64, device=device)
+    gr = torch.Generator(device=device)
+    for r in range(r0, r1):
+        gr.manual_seed(int(seed) * 100003 + r)
+        torch.randn(cols, generator=gr, device=device, dtype=torch.float64, out=two[r - r0])
+    two.mul_(1.0 / (n * n))
+    return S_train.contiguous(), one.contiguous(), two

@@ -12,7 +12,7 @@
  *   - every pointer is a DEVICE pointer to float64 (int64 for aoslices) unless noted;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
  *     synchronises, nothing allocates, there is no global state besides a thread-local
- *     error string;
+ *     error string (and the opt-in evc_profile_* measurement hook);
  *   - return value 0 = success; <0 = argument error (nothing enqueued);
  *     >0 = hipError_t of a failed launch;
  *   - matrices are row-major (C order), exactly as numpy hands them to the reference.
@@ -83,7 +83,7 @@ int evc_unpack_pair_sym(const double *packed, int n, double *out, void *stream);
  *   ab_initio_gradients_loewdin.py:339) and the OAO->AO back-rotation of the 2-RDM (:224-232,
  *   with c_transposed=1).  If `three_quarter` is non-NULL it receives the tensor after three
  *   steps, K[j,k,l,a] = sum_bcd in[a,b,c,d] C[b,j] C[c,k] C[d,l]  (used by K13, :210-222).
- *   `tmp` is scratch of n^4 doubles; in/out/tmp/three_quarter must not alias.  n <= 128.
+ *   `tmp` is scratch of n^4 doubles; in/out/tmp/three_quarter must not alias.  n <= 96.
  * --------------------------------------------------------------------------------- */
 int evc_quarter_transform(const double *in, const double *C, int c_transposed, int n,
                           double *out, void *stream);
@@ -94,7 +94,7 @@ int evc_four_index_transform(const double *in, const double *C, int c_transposed
  * K1/K2  Loewdin orthogonalisation on one workgroup (parallel cyclic Jacobi in LDS)
  *   S = U diag(s) U^T ; X = U diag(s>1e-15 ? s^-1/2 : 0) U^T ; h1 = X^T hcore X
  *   replaces get_loewdin_trafo (electron_integral_utils.py:6-18) and the h1 rotation
- *   (:135, ab_initio_gradients_loewdin.py:338).  hcore/h1 may be NULL.  n <= 96.
+ *   (:135, ab_initio_gradients_loewdin.py:338).  hcore/h1 may be NULL.  n <= 80.
  * --------------------------------------------------------------------------------- */
 int evc_loewdin(const double *S, const double *hcore, int n, double *X, double *U, double *s,
                 double *h1, void *stream);
@@ -183,6 +183,15 @@ int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g, const evc
 int evc_grad_elec_oao(int n, const evc_geometry *g, const double *one_rdm, const double *two_rdm,
                       double *grad, void *ws, size_t ws_bytes, void *stream);
 size_t evc_grad_elec_ws_bytes(int n, int natm);
+
+/* ---------------------------------------------------------------------------------
+ * Measurement hook (bench.py): while enabled, the fused pipeline records hipEvents on the launch
+ * stream immediately before and after the K5 (rows GEMV) and K8 (cols GEMV) launches of up to
+ * max_samples evaluations.  evc_profile_end synchronises those events, returns the summed
+ * durations in milliseconds with the number of launches, and frees them.  Process-wide state.
+ * --------------------------------------------------------------------------------- */
+int evc_profile_begin(int max_samples);
+int evc_profile_end(double *rows_ms, int *rows_n, double *cols_ms, int *cols_n);
 
 #ifdef __cplusplus
 }
