@@ -68,7 +68,7 @@ def cpu_baseline(workload, layout_nd, trd, aos, samples):
         two = two.reshape(-1, n, n, n, n)
     elif layout_nd == 3:
         two = two.reshape(T, T, -1)
-    one = trd.one.cpu().numpy().reshape(T, T, n, n)
+    one = trd.one[:, : n * n].cpu().numpy().reshape(T, T, n, n)
     S = trd.S.cpu().numpy()
     times = []
     for k in range(samples + 1):

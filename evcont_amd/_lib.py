@@ -22,7 +22,7 @@ c_double_p = C.c_void_p  # device pointers travel as integers
 class TrdmSet(C.Structure):
     _fields_ = [("n", C.c_int32), ("ntrain", C.c_int32), ("layout", C.c_int32), ("reserved", C.c_int32),
                 ("rows2", C.c_int64), ("row_offset", C.c_int64), ("rows2_total", C.c_int64),
-                ("cols2", C.c_int64), ("ld2", C.c_int64),
+                ("cols2", C.c_int64), ("ld2", C.c_int64), ("ld1", C.c_int64),
                 ("two_rdm", C.c_void_p), ("one_rdm", C.c_void_p), ("s_train", C.c_void_p)]
 
 
@@ -67,8 +67,17 @@ SIGNATURES = {
     "evc_energy_with_grad": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(Geometry), C.POINTER(Outputs), C.c_int,
                                        C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_grad_elec_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "evc_grad_elec_oao": (C.c_int, [C.c_int, C.POINTER(Geometry), C.c_void_p, C.c_void_p, C.c_void_p,
+    "evc_grad_elec_oao": (C.c_int, [C.c_int, C.POINTER(Geometry), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "evc_loewdin_trafo_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "evc_derivative_ao_mo_trafo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    "evc_one_el_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p]),
+    "evc_two_el_grad_ws_bytes": (C.c_size_t, [C.c_int]),
+    "evc_two_el_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "evc_contract_nnA3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "evc_profile_begin": (C.c_int, [C.c_int]),
     "evc_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                   C.POINTER(C.c_int)]),

@@ -1,0 +1,97 @@
+"""Device-backed mirror of ``evcont/ab_initio_gradients_loewdin.py`` (same public names,
+signatures and array layouts)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import gradients as G
+from . import ops
+from .ab_initio_eigenvector_continuation import _evaluator, _nonhermitian_unsupported, approximate_ground_state  # noqa: F401
+from .electron_integral_utils import get_loewdin_trafo, restore_electron_exchange_symmetry  # noqa: F401
+from .evaluator import DeviceAO, _dev
+from .integrals import ao_arrays, grad_nuc, is_array_mol
+
+
+def _dao(mol) -> DeviceAO:
+    return DeviceAO.from_arrays(ao_arrays(mol, need_grad=True), _dev())
+
+
+def get_overlap_grad(mol):
+    """dS[mu,nu,A,x] (reference :13-38).  Pure index bookkeeping of int1e_ipovlp: done on the host."""
+    ao = ao_arrays(mol, need_grad=True)
+    n, A = ao.S.shape[0], len(ao.aoslices)
+    d = np.zeros((3, A, n, n))
+    for a, (p0, p1) in enumerate(np.asarray(ao.aoslices)):
+        d[:, a, p0:p1, :] -= ao.ipovlp[:, p0:p1, :]
+    d = d + d.transpose(0, 1, 3, 2)
+    return np.ascontiguousarray(d.transpose(2, 3, 1, 0))
+
+
+def loewdin_trafo_grad(overlap_mat):
+    """d X / d S for all symmetrised unit perturbations, (N,N,N,N) (reference :41-112).
+
+    Evaluated in closed (Daleckii-Krein divided-difference) form, which equals the reference's
+    degenerate perturbation theory for non-degenerate and exactly degenerate spectra."""
+    S = ops.to_device(np.asarray(overlap_mat, dtype=np.float64), _dev())
+    return G.loewdin_trafo_grad_device(S).cpu().numpy()
+
+
+def get_derivative_ao_mo_trafo(mol):
+    """dX[k,l,A,x] (reference :115-134)."""
+    return G.derivative_ao_mo_trafo_device(_dao(mol)).cpu().numpy()
+
+
+def get_one_el_grad_ao(mol):
+    """(N,N,A,3) AO derivative of hcore (reference :137-152): a transposition of PySCF's output."""
+    ao = ao_arrays(mol, need_grad=True)
+    return np.ascontiguousarray(np.asarray(ao.dhcore).transpose(2, 3, 0, 1))
+
+
+def get_one_el_grad(mol, ao_mo_trafo=None, ao_mo_trafo_grad=None):
+    """d h1^OAO / dR, (N,N,A,3) (reference :155-187)."""
+    dao = _dao(mol)
+    d = dao.S.device
+    X = ops.loewdin(dao.S)[0] if ao_mo_trafo is None else ops.to_device(ao_mo_trafo, d)
+    dX = G.derivative_ao_mo_trafo_device(dao) if ao_mo_trafo_grad is None else ops.to_device(ao_mo_trafo_grad, d)
+    return G.one_el_grad_device(dao, X, dX).cpu().numpy()
+
+
+def two_el_grad(h2_ao, two_rdm, ao_mo_trafo, ao_mo_trafo_grad, h2_ao_deriv, atm_slices):
+    """Two-electron gradient (A,3) (reference :190-252)."""
+    d = _dev()
+    sl = torch.from_numpy(np.ascontiguousarray(np.asarray(atm_slices, dtype=np.int64).reshape(-1, 2))).to(d)
+    up = lambda x: ops.to_device(np.asarray(x, dtype=np.float64), d)
+    n = np.asarray(ao_mo_trafo).shape[0]
+    return G.two_el_grad_device(up(h2_ao).reshape((n,) * 4), up(two_rdm), up(ao_mo_trafo), up(ao_mo_trafo_grad),
+                                up(h2_ao_deriv).reshape((3,) + (n,) * 4), sl).cpu().numpy()
+
+
+def get_grad_elec_OAO(mol, one_rdm, two_rdm, ao_mo_trafo=None, ao_mo_trafo_grad=None):
+    """Electronic gradient of given OAO RDMs, (A,3) (reference :255-305)."""
+    dao = _dao(mol)
+    d = dao.S.device
+    D = ops.to_device(np.asarray(one_rdm, dtype=np.float64), d)
+    Gm = ops.to_device(np.asarray(two_rdm, dtype=np.float64), d)
+    if ao_mo_trafo_grad is None:
+        X = None if ao_mo_trafo is None else ops.to_device(ao_mo_trafo, d)
+        return G.grad_elec_oao_device(dao, D, Gm, X).cpu().numpy()
+    # explicit trafo derivative supplied: assemble from the tensor-valued pieces (reference :279-303)
+    X = ops.loewdin(dao.S)[0] if ao_mo_trafo is None else ops.to_device(ao_mo_trafo, d)
+    dX = ops.to_device(ao_mo_trafo_grad, d)
+    h1_jac = G.one_el_grad_device(dao, X, dX)
+    g2 = G.two_el_grad_device(dao.eri, Gm, X, dX, dao.eri_ip1, dao.aoslices)
+    return (G.contract_nnA3_device(h1_jac, D) + 0.5 * g2).cpu().numpy()
+
+
+def get_energy_with_grad(mol, one_RDM, two_RDM, S, hermitian=True, return_density_matrices=False):
+    """Total energy and nuclear gradient of the continuation at ``mol``'s geometry (reference :308-379).
+
+    The t-RDMs are uploaded once (``evcont_amd.cache``) and stay resident; each call ships only
+    the AO integrals of the new geometry and enqueues one fused device pipeline."""
+    if not hermitian:
+        _nonhermitian_unsupported()
+    ao = ao_arrays(mol, need_grad=True)
+    ev = _evaluator(one_RDM, two_RDM, S, int(np.asarray(ao.aoslices).shape[0]))
+    dao = DeviceAO.from_arrays(ao, ev.t.device)
+    return ev.energy_with_grad(dao, return_density_matrices=return_density_matrices)

@@ -1,0 +1,58 @@
+"""Upload cache for the training data.
+
+The reference API passes the (possibly multi-GB) t-RDM arrays to every call
+(``get_energy_with_grad(mol, one_RDM, two_RDM, S)`` once per MD step,
+``MD_utils.py:43-50``).  The device path must not re-upload them each time, so the host
+arrays are fingerprinted (address, shape, strides, dtype + a strided content sample) and
+the corresponding ``DeviceTRDMs``/``ContinuationEvaluator`` are kept in a small LRU.
+Callers that mutate an array in place between calls should call :func:`clear`.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import Tuple
+
+import numpy as np
+
+_MAX = int(os.environ.get("EVCONT_AMD_CACHE_ENTRIES", "4"))
+_cache: "OrderedDict[tuple, object]" = OrderedDict()
+
+
+def _fingerprint(a: np.ndarray) -> tuple:
+    a = np.asarray(a)
+    flat_len = a.size
+    if flat_len == 0:
+        return (a.shape, a.dtype.str)
+    # ~4096 samples spread over the array + both ends; cheap even for a 2.6 GB array
+    step = max(1, flat_len // 4096)
+    if a.flags.c_contiguous:
+        sample = a.reshape(-1)[::step]
+    else:
+        idx = np.unravel_index(np.arange(0, flat_len, step), a.shape)
+        sample = a[idx]
+    return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str,
+            float(np.sum(sample, dtype=np.float64)), float(np.sum(np.abs(sample), dtype=np.float64)))
+
+
+def key_of(one_RDM, two_RDM, S, extra: Tuple = ()) -> tuple:
+    return (_fingerprint(one_RDM), _fingerprint(two_RDM), _fingerprint(S)) + tuple(extra)
+
+
+def get(key):
+    if key in _cache:
+        _cache.move_to_end(key)
+        return _cache[key]
+    return None
+
+
+def put(key, value):
+    _cache[key] = value
+    _cache.move_to_end(key)
+    while len(_cache) > _MAX:
+        _cache.popitem(last=False)
+    return value
+
+
+def clear() -> None:
+    _cache.clear()

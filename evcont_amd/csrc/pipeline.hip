@@ -64,6 +64,7 @@ static int check_set(const evc_trdm_set *t) {
                 (long long)t->rows2, (long long)rows);
     EVC_REQUIRE(t->ld2 >= cols && t->ld2 % 2 == 0, "trdm_set: ld2=%lld must be even and >= cols2",
                 (long long)t->ld2);
+    EVC_REQUIRE(t->ld1 >= n2 && t->ld1 % 2 == 0, "trdm_set: ld1=%lld must be even and >= N*N", (long long)t->ld1);
     EVC_REQUIRE(t->rows2 == 0 || (t->two_rdm && aligned16(t->two_rdm)), "trdm_set: two_rdm NULL or misaligned");
     EVC_REQUIRE(t->one_rdm && aligned16(t->one_rdm) && t->s_train, "trdm_set: one_rdm/s_train NULL or misaligned");
     return 0;
@@ -97,7 +98,7 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     if (t->rows2 > 0) plan_rows(w.rp2);
     w.rp1.rows = (int64_t)T * T;
     w.rp1.cols = (int64_t)n2;
-    w.rp1.ld = (int64_t)n2;
+    w.rp1.ld = t->ld1;
     plan_rows(w.rp1);
     w.h2part = take((size_t)t->rows2 * (w.rp2.nspans > 0 ? w.rp2.nspans : 1) + 1);
     w.h1part = take((size_t)T * T * w.rp1.nspans);
@@ -248,7 +249,7 @@ static int phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const ev
     c1.w = w.w1;
     c1.rows = (int64_t)t->ntrain * t->ntrain;
     c1.cols = (int64_t)n * n;
-    c1.ld = c1.cols;
+    c1.ld = t->ld1;
     c1.out = D;
     const bool prof = g_prof.on && g_prof.n_cols < g_prof.cap;
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_cols + 2], st);
@@ -416,14 +417,15 @@ extern "C" size_t evc_grad_elec_ws_bytes(int n, int natm) {
     t.rows2_total = 1;
     t.cols2 = (int64_t)n * n * n * n;
     t.ld2 = t.cols2 + (t.cols2 & 1);
+    t.ld1 = (int64_t)n * n + ((n * n) & 1);
     if (n < 1 || n > 64) return 0;
     Ws w;
     carve(&t, natm, nullptr, w);
     return w.bytes;
 }
 
-extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *one_rdm, const double *two_rdm,
-                                 double *grad, void *ws, size_t ws_bytes, void *stream) {
+extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *trafo, const double *one_rdm,
+                                 const double *two_rdm, double *grad, void *ws, size_t ws_bytes, void *stream) {
     EVC_REQUIRE(n >= 1 && n <= 64, "evc_grad_elec_oao: n=%d out of range 1..64", n);
     if (check_geometry(g, true)) return -1;
     EVC_REQUIRE(one_rdm && two_rdm && grad && ws && aligned16(ws), "evc_grad_elec_oao: null/misaligned pointer");
@@ -435,12 +437,22 @@ extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *one
     t.rows2_total = 1;
     t.cols2 = (int64_t)n * n * n * n;
     t.ld2 = t.cols2 + (t.cols2 & 1);
+    t.ld1 = (int64_t)n * n + ((n * n) & 1);
     Ws w;
     carve(&t, g->natm, static_cast<char *>(ws), w);
     EVC_REQUIRE(ws_bytes >= w.bytes, "evc_grad_elec_oao: workspace too small: %zu < %zu", ws_bytes, w.bytes);
     hipStream_t st = as_stream(stream);
     int rc;
     if ((rc = launch_loewdin(g->S, g->hcore, n, w.X, w.U, w.s, w.h1, st))) return rc;
+    if (trafo) {
+        // caller-supplied ao_mo_trafo (gradients_loewdin.py:271-272); its derivative is still the
+        // Loewdin response of g->S, exactly as the reference computes it when none is passed (:274-277)
+        hipError_t e = hipMemcpyAsync(w.X, trafo, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) {
+            set_error("evc_grad_elec_oao: copy failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
     if ((rc = launch_quarter_transform(g->eri, w.X, 0, n, w.B1, st))) return rc;
     if ((rc = launch_quarter_transform(w.B1, w.X, 0, n, w.B2, st))) return rc;
     if ((rc = launch_quarter_transform(w.B2, w.X, 0, n, w.K3, st))) return rc;

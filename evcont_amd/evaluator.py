@@ -72,6 +72,16 @@ def _upload_rows(src: np.ndarray, rows: int, cols: int, r0: int, r1: int, device
     return out, ld
 
 
+def _pad_even(mat: torch.Tensor) -> torch.Tensor:
+    """(rows, cols) -> contiguous (rows, ld) with ld even (16-byte aligned rows), zero padded."""
+    rows, cols = mat.shape
+    if cols % 2 == 0:
+        return mat.contiguous()
+    out = torch.zeros((rows, cols + 1), dtype=F64, device=mat.device)
+    out[:, :cols].copy_(mat)
+    return out
+
+
 class DeviceTRDMs:
     """Training data resident in HBM.  ``row_range`` selects the slice of two-body rows this
     rank owns (pair sharding); the one-body t-RDM and S are replicated."""
@@ -102,10 +112,11 @@ class DeviceTRDMs:
         self.rows_total, self.cols, self.ld = rows, cols, ld
         self.row_offset, self.rows_local = r0, r1 - r0
         as_t = lambda x: (x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)))
-        self.one = as_t(one_RDM).to(self.device, F64).reshape(T * T, n * n).contiguous()
+        self.one = _pad_even(as_t(one_RDM).to(self.device, F64).reshape(T * T, n * n))
         self.S = as_t(S).to(self.device, F64).contiguous()
         self.cstruct = TrdmSet(n=n, ntrain=T, layout=self.layout, reserved=0, rows2=self.rows_local,
                                row_offset=self.row_offset, rows2_total=rows, cols2=cols, ld2=ld,
+                               ld1=self.one.shape[1],
                                two_rdm=self.two.data_ptr(), one_rdm=self.one.data_ptr(),
                                s_train=self.S.data_ptr())
 
@@ -132,10 +143,11 @@ class DeviceTRDMs:
             self.two[: r1 - r0, :cols].copy_(two_rows)
         self.rows_total, self.cols, self.ld = rows, cols, ld
         self.row_offset, self.rows_local = r0, r1 - r0
-        self.one = one_RDM.to(self.device, F64).reshape(T * T, n * n).contiguous()
+        self.one = _pad_even(one_RDM.to(self.device, F64).reshape(T * T, n * n))
         self.S = S.to(self.device, F64).contiguous()
         self.cstruct = TrdmSet(n=n, ntrain=T, layout=self.layout, reserved=0, rows2=self.rows_local,
                                row_offset=self.row_offset, rows2_total=rows, cols2=cols, ld2=ld,
+                               ld1=self.one.shape[1],
                                two_rdm=self.two.data_ptr(), one_rdm=self.one.data_ptr(),
                                s_train=self.S.data_ptr())
         return self

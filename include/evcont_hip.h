@@ -128,8 +128,9 @@ typedef struct evc_trdm_set {
     int64_t rows2_total; /* global number of rows (T*T or T(T+1)/2) */
     int64_t cols2;       /* N^4 or M */
     int64_t ld2;         /* leading dimension of two_rdm (even, >= cols2) */
+    int64_t ld1;         /* leading dimension of one_rdm (even, >= N*N) */
     const double *two_rdm; /* (rows2, ld2) */
-    const double *one_rdm; /* (T*T, N*N) contiguous, replicated on every rank */
+    const double *one_rdm; /* (T*T, ld1), replicated on every rank */
     const double *s_train; /* (T,T) */
 } evc_trdm_set;
 
@@ -178,11 +179,36 @@ int evc_phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_o
 int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
                          int nroots, int flags, void *ws, size_t ws_bytes, void *stream);
 
-/* Gradient of given (not predicted) RDMs: get_grad_elec_OAO (ab_initio_gradients_loewdin.py:255-305)
- * with the Loewdin trafo of g->S; writes the ELECTRONIC gradient (no grad_nuc) to grad[A*3]. */
-int evc_grad_elec_oao(int n, const evc_geometry *g, const double *one_rdm, const double *two_rdm,
-                      double *grad, void *ws, size_t ws_bytes, void *stream);
+/* Gradient of given (not predicted) RDMs: get_grad_elec_OAO (ab_initio_gradients_loewdin.py:255-305).
+ * `trafo` = caller's ao_mo_trafo (N,N) or NULL for the Loewdin trafo of g->S; the trafo derivative is
+ * the Loewdin response of g->S in both cases (:274-277).  Writes the ELECTRONIC gradient (no grad_nuc)
+ * to grad[A*3]. */
+int evc_grad_elec_oao(int n, const evc_geometry *g, const double *trafo, const double *one_rdm,
+                      const double *two_rdm, double *grad, void *ws, size_t ws_bytes, void *stream);
 size_t evc_grad_elec_ws_bytes(int n, int natm);
+
+/* ---------------------------------------------------------------------------------
+ * Tensor-valued building blocks of ab_initio_gradients_loewdin.py (off the fused path, which uses
+ * the adjoint form and never materialises them).  Layouts are the reference's: (N,N,N,N) and
+ * (N,N,A,3), C order.  n <= 64 (evc_one_el_grad: n <= 60).
+ *   evc_loewdin_trafo_grad      loewdin_trafo_grad(S)            (:41-112)  LG[p,q,a,b] = dX_pq/dS_ab(sym)
+ *                               in Daleckii-Krein closed form; ws = 2n^2+n doubles
+ *   evc_derivative_ao_mo_trafo  get_derivative_ao_mo_trafo(mol)  (:115-134) dX[k,l,A,x]; ws as above
+ *   evc_one_el_grad             get_one_el_grad(mol, X, dX)      (:155-187) h1_jac[j,n,A,x]
+ *   evc_two_el_grad             two_el_grad(h2_ao, G, X, dX, ip1, slices) (:190-252) -> (A,3)
+ *   evc_contract_nnA3           out[A,x] = sum_ij T[i,j,A,x] * (transposed ? M[j,i] : M[i,j])  (:300)
+ * --------------------------------------------------------------------------------- */
+int evc_loewdin_trafo_grad(const double *S, int n, double *LG, double *ws, void *stream);
+int evc_derivative_ao_mo_trafo(const double *S, const double *ipovlp, const int64_t *aoslices, int n,
+                               int natm, double *dX, double *ws, void *stream);
+int evc_one_el_grad(const double *X, const double *hcore, const double *dhcore, const double *dX, int n,
+                    int natm, double *out, void *stream);
+size_t evc_two_el_grad_ws_bytes(int n);
+int evc_two_el_grad(const double *h2_ao, const double *two_rdm, const double *X, const double *dX,
+                    const double *ip1, const int64_t *aoslices, int n, int natm, double *out, void *ws,
+                    size_t ws_bytes, void *stream);
+int evc_contract_nnA3(const double *T, const double *M, int transposed, int n, int natm, double *out,
+                      void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Measurement hook (bench.py): while enabled, the fused pipeline records hipEvents on the launch
