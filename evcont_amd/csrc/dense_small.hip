@@ -87,8 +87,6 @@ __device__ __forceinline__ void jacobi_rotation(double app, double aqq, double a
     }
 }
 
-__device__ int g_dbg_sweeps = 0;
-
 __device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double *red) {
     const int tid = threadIdx.x;
     const int tk = tid & 15, tj = tid >> 4;
@@ -106,10 +104,7 @@ __device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double
             }
         off = block_sum<4>(off, red);
         dg = block_sum<4>(dg, red + 4);
-        if (!(off > 1.0e-32 * dg)) {  // converged (or NaN input)
-            if (tid == 0) g_dbg_sweeps = sweep;
-            break;
-        }
+        if (!(off > 1.0e-32 * dg)) break;  // converged (or NaN input)
         for (int step = 0; step < m - 1; ++step) {
             if (tid < half) {
                 int p, q;
@@ -532,12 +527,6 @@ int launch_grad_final(const GradFinalArgs &a, hipStream_t st) {
 
 // ------------------------------------------------------------------ C ABI
 using namespace evc;
-
-extern "C" int evc_debug_last_sweeps(void) {
-    int v = -1;
-    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_dbg_sweeps), sizeof(int));
-    return v;
-}
 
 extern "C" int evc_loewdin(const double *S, const double *hcore, int n, double *X, double *U, double *s,
                            double *h1, void *stream) {

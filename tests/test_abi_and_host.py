@@ -1,0 +1,151 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/evcont_hip.h declares
+(no compute calls: there is no GPU here), argument validation that happens on the host side of
+the ABI, and the pure-host logic (layouts, sharding, cache, array-level mol adapter)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from evcont_amd import build, _lib
+    build.build()                       # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "evcont_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(evc_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound(lib):
+    from evcont_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/evcont_hip.h but not exported"
+    assert set(syms) == set(_lib.SIGNATURES), (set(syms) ^ set(_lib.SIGNATURES))
+    assert lib.evc_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    from evcont_amd._lib import TrdmSet, Geometry, Outputs
+    # sizes implied by the C declarations (x86-64): 4 int32 + 6 int64 + 3 ptr ; 2 int32 + double + 8 ptr ; 6 ptr
+    assert C.sizeof(TrdmSet) == 16 + 6 * 8 + 3 * 8
+    assert C.sizeof(Geometry) == 8 + 8 + 8 * 8
+    assert C.sizeof(Outputs) == 6 * 8
+
+
+def test_argument_validation_without_gpu(lib):
+    """Argument errors are detected before anything is enqueued (rc < 0, message set)."""
+    from evcont_amd._lib import TrdmSet
+    assert lib.evc_gemv_rows(None, 4, 4, 4, None, 1.0, None, None, 0, None) < 0
+    assert b"null pointer" in lib.evc_last_error()
+    assert lib.evc_gemv_rows(16, 4, 5, 5, 16, 1.0, 16, 16, 1 << 20, None) < 0       # odd ld
+    assert b"even" in lib.evc_last_error()
+    assert lib.evc_quarter_transform(16, 16, 0, 500, 32, None) < 0
+    assert lib.evc_loewdin(16, None, 200, 16, 16, 16, None, None) < 0
+    t = TrdmSet(n=30, ntrain=20, layout=4, rows2=1, rows2_total=1, cols2=1, ld2=2, ld1=900)
+    assert lib.evc_workspace_bytes(C.byref(t), 30) == 0
+    assert b"layout" in lib.evc_last_error()
+    t = TrdmSet(n=30, ntrain=20, layout=2, rows2=210, row_offset=0, rows2_total=210, cols2=405450, ld2=405456,
+                ld1=900, two_rdm=256, one_rdm=256, s_train=256)
+    nbytes = lib.evc_workspace_bytes(C.byref(t), 30)
+    assert 4 * 810000 * 8 < nbytes < 200 << 20
+    assert lib.evc_gemv_rows_ws_bytes(210, 405450) >= 210 * 8
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from evcont_amd import _lib
+    with pytest.raises(_lib.EvcontHipError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_no_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from evcont_amd import _lib
+    from evcont_amd.evaluator import DeviceTRDMs
+    with pytest.raises(_lib.EvcontHipError):
+        DeviceTRDMs(np.zeros((2, 2, 3, 3)), np.zeros((2, 2, 3, 3, 3, 3)), np.eye(2))
+    import evcont_amd.electron_integral_utils as eiu
+    with pytest.raises(_lib.EvcontHipError):
+        eiu.get_loewdin_trafo(np.eye(3))
+
+
+def test_layout_shapes_and_inference():
+    from evcont_amd.evaluator import layout_shape, infer_layout
+    assert layout_shape(6, 20, 30) == (400, 810000)
+    assert layout_shape(5, 20, 30) == (210, 810000)
+    assert layout_shape(3, 20, 30) == (400, 405450)
+    assert layout_shape(2, 20, 30) == (210, 405450)
+    assert infer_layout(np.zeros((3, 3, 2, 2, 2, 2)), 3, 2) == 6
+    assert infer_layout(np.zeros((6, 10)), 3, 2) == 2
+    with pytest.raises(ValueError):
+        infer_layout(np.zeros((6, 11)), 3, 2)
+    with pytest.raises(AssertionError):
+        infer_layout(np.zeros((6, 2, 2, 2)), 3, 2)
+
+
+def test_shard_rows_cover_and_balance():
+    from evcont_amd.distributed import shard_rows
+    for rows, world in [(210, 8), (210, 1), (400, 8), (15, 4), (3, 8), (465, 8)]:
+        got = [shard_rows(rows, world, r) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == rows
+        assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+        sizes = [b - a for a, b in got]
+        assert max(sizes) == -(-rows // world)
+
+
+def test_cache_fingerprint():
+    from evcont_amd import cache
+    cache.clear()
+    a = np.random.default_rng(0).standard_normal((3, 3, 4, 4))
+    b = np.random.default_rng(1).standard_normal((3, 3, 4, 4, 4, 4))
+    S = np.eye(3)
+    k1 = cache.key_of(a, b, S)
+    assert cache.key_of(a, b, S) == k1
+    assert cache.key_of(a, b[:2, :2], S) != k1        # a view is a different object
+    b[0, 0, 0, 0, 0, 0] += 1.0
+    assert cache.key_of(a, b, S) != k1                # in-place change seen by the content sample
+    cache.put(k1, "x")
+    assert cache.get(k1) == "x" and cache.get(("other",)) is None
+    for i in range(10):
+        cache.put(("k", i), i)
+    assert cache.get(k1) is None                      # LRU eviction
+    cache.clear()
+
+
+def test_array_level_mol_adapter():
+    from evcont_amd.integrals import ao_arrays, is_array_mol, energy_nuc, grad_nuc, nao_of
+    from evcont_amd.synthetic import make_ao_arrays
+    ao = make_ao_arrays(5, 2, 3, ao_sizes=(2, 3))
+    assert is_array_mol(ao) and ao_arrays(ao) is ao and nao_of(ao) == 5
+    assert energy_nuc(ao) == ao.enuc and np.array_equal(grad_nuc(ao), ao.gnuc)
+
+    class FakePyscfMol:      # has .intor -> treated as a PySCF molecule
+        def intor(self, *a, **k):
+            raise RuntimeError("would call libcint")
+        S = hcore = eri = None
+    assert not is_array_mol(FakePyscfMol())
+
+
+def test_synthetic_layouts_consistent():
+    """The four layouts built by pack_rows describe the same object (oracle energies agree)."""
+    from evcont_amd.synthetic import make_ao_arrays, make_trdms, pack_rows
+    from oracle import evcont_oracle as orc
+    ao = make_ao_arrays(4, 2, 5)
+    S, one, two = make_trdms(4, 3, 6)
+    b = orc.AOBundle(ao.S, ao.hcore, ao.eri, ao.ipovlp, ao.dhcore, ao.eri_ip1, ao.aoslices, ao.enuc, ao.gnuc)
+    ref = orc.energy_with_grad(b, one, two, S)
+    for p, e in [(True, False), (False, True), (True, True)]:
+        E, g = orc.energy_with_grad(b, one, pack_rows(two, p, e), S)
+        assert abs(E - ref[0]) < 1e-12
+        np.testing.assert_allclose(g, ref[1], rtol=0, atol=1e-11)

@@ -271,3 +271,34 @@ def test_h30_layouts_agree(dev):
     for lname, (E, g) in res.items():
         assert abs(E - E0) < 1e-10, lname
         np.testing.assert_allclose(g, g0, rtol=0, atol=1e-9, err_msg=lname)
+
+
+@pytest.mark.parametrize("lname", ["pack2", "full6"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_phase_api_emulated_pair_sharding(lname, world, load_golden, dev):
+    """The three-phase C entry points on row slices (what each rank of the pair-sharded multi-GPU run
+    executes), with the two collectives emulated on one device: concatenate the H rows, sum the
+    partial gradients.  Must reproduce the reference's single-process result."""
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator, layout_shape
+    from evcont_amd.distributed import shard_rows
+    g = load_golden("n5t4a2")
+    ao = DeviceAO.from_arrays(ao_from_golden(g), dev)
+    two = layout(g["two_RDM"], lname)
+    T, n = 4, 5
+    rows, _ = layout_shape(two.ndim, T, n)
+    evs = []
+    for r in range(world):
+        r0, r1 = shard_rows(rows, world, r)
+        evs.append(ContinuationEvaluator(DeviceTRDMs(g["one_RDM"], two, g["S_train"], dev, row_range=(r0, r1)), ao.natm))
+    parts = [ev.phase_hamiltonian(ao).clone() for ev in evs]
+    rows_all = torch.cat(parts).contiguous()
+    assert rows_all.numel() == rows
+    total = torch.zeros_like(evs[0].grad)
+    for r, ev in enumerate(evs):
+        ev.phase_solve(ao, rows_all, 1)
+        ev.phase_gradient(ao, partial_rank=(r != 0))
+        total += ev.grad
+    torch.cuda.synchronize()
+    for ev in evs:
+        assert abs(ev.energy[0].item() - float(g[f"ewg_E_{lname}"])) < 1e-10
+    np.testing.assert_allclose(total.cpu().numpy(), g[f"ewg_grad_{lname}"], rtol=0, atol=1e-9)

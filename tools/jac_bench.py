@@ -2,7 +2,6 @@ import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, ''+__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))+'')
 from evcont_amd import ops, _lib
 lib = _lib.load()
-lib.evc_debug_last_sweeps.restype = C.c_int
 dev = torch.device('cuda:0')
 for n in (10, 20, 30, 58):
     rng = np.random.default_rng(n)
@@ -14,4 +13,4 @@ for n in (10, 20, 30, 58):
     e0.record()
     for _ in range(20): ops.loewdin(Sd)
     e1.record(); torch.cuda.synchronize()
-    print(n, "loewdin us:", e0.elapsed_time(e1) / 20 * 1e3, "sweeps:", lib.evc_debug_last_sweeps())
+    print(n, "loewdin us:", e0.elapsed_time(e1) / 20 * 1e3)
