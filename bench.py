@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-samples", type=int, default=0, help="geometries timed on the host (0 = auto)")
     p.add_argument("--energy-only", action="store_true")
+    p.add_argument("--batch", type=int, default=1,
+                   help="geometries per step: every launch covers the batch and the t-RDM is streamed once per "
+                        "8 geometries (evc_energy_with_grad_batch); 1 = one geometry per step as in an MD run")
     p.add_argument("--streams", type=int, default=1,
                    help="independent geometries in flight (one HIP stream + workspace each); 1 = strictly "
                         "sequential evaluations as in an MD run")
@@ -110,7 +113,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from evcont_amd import _lib
-    from evcont_amd.evaluator import DeviceTRDMs, ContinuationEvaluator, layout_shape
+    from evcont_amd.evaluator import (DeviceTRDMs, ContinuationEvaluator, BatchedEvaluator, DeviceAOBatch,
+                                      layout_shape)
     from evcont_amd.distributed import PairShardedContinuation, shard_rows
     from evcont_amd.synthetic import make_device_ao, make_device_trdm_rows
 
@@ -124,8 +128,14 @@ def main():
     del two_rows
     aos = [make_device_ao(n, A, seed * 1000 + k, dev, sizes) for k in range(a.geoms)]
     nslots = max(1, a.streams) if world == 1 else 1
-    evs = [ContinuationEvaluator(trd, A, stream=(torch.cuda.Stream(dev) if nslots > 1 else None))
-           for _ in range(nslots)]
+    G = max(1, a.batch) if world == 1 else 1
+    mk_stream = lambda: (torch.cuda.Stream(dev) if nslots > 1 else None)
+    if G > 1:
+        nb = max(1, len(aos) // G)
+        batches = [DeviceAOBatch.stack(aos[i * G:(i + 1) * G]) for i in range(nb)]
+        evs = [BatchedEvaluator(trd, A, G, stream=mk_stream()) for _ in range(nslots)]
+    else:
+        evs = [ContinuationEvaluator(trd, A, stream=mk_stream()) for _ in range(nslots)]
     ev = evs[0]
     runner = PairShardedContinuation(ev, rows) if world > 1 else None
     lib = _lib.load()
@@ -133,6 +143,8 @@ def main():
     def step(k):
         if runner is not None:
             runner.enqueue(aos[k % len(aos)], 1, a.energy_only)
+        elif G > 1:
+            evs[k % nslots].enqueue(batches[k % len(batches)], 1, a.energy_only)
         else:
             evs[k % nslots].enqueue(aos[k % len(aos)], 1, a.energy_only)
 
@@ -155,7 +167,7 @@ def main():
     rows_n, cols_n = C.c_int(), C.c_int()
     _lib.check(lib.evc_profile_end(C.byref(rows_ms), C.byref(rows_n), C.byref(cols_ms), C.byref(cols_n)),
                "evc_profile_end")
-    e_last = float(ev.energy[0].item())
+    e_last = float(ev.energy.reshape(-1)[0].item())
     assert np.isfinite(e_last), "non-finite energy in the timed region"
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -165,10 +177,13 @@ def main():
     if rank == 0:
         # dominant kernel = K5, the 2-RDM x ERI contraction (rows GEMV); algorithmic bytes per
         # launch = local two-body rows x cols x 8 B + one-body rows + the two vectors
-        bytes_rows = trd.rows_local * cols * 8 + T * T * n * n * 8 + cols * 8 + n * n * 8
-        bytes_cols = trd.rows_local * cols * 8 + T * T * n * n * 8 + cols * 8 + n * n * 8
-        k5_ms = rows_ms.value / max(rows_n.value, 1)
-        k8_ms = cols_ms.value / max(cols_n.value, 1) if cols_n.value else None
+        # (+ per geometry of the batch: the h2 / predicted-RDM vector).  A batch of G > 8 is G/8 launches.
+        gl = min(G, 8)                      # geometries per launch
+        launches_per_step = -(-G // 8)
+        bytes_rows = trd.rows_local * cols * 8 + T * T * n * n * 8 + gl * (cols * 8 + n * n * 8)
+        bytes_cols = bytes_rows
+        k5_ms = rows_ms.value / max(rows_n.value, 1) / launches_per_step
+        k8_ms = cols_ms.value / max(cols_n.value, 1) / launches_per_step if cols_n.value else None
         ach = bytes_rows / (k5_ms * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -184,7 +199,7 @@ def main():
             "metric": "continuation geometries/sec (energy+force), H30 STO-3G, 20 training states"
             if a.workload == "H30" and not a.energy_only else
             f"continuation geometries/sec ({'energy' if a.energy_only else 'energy+force'}), {a.workload}",
-            "value": a.steps / dt,
+            "value": a.steps * G / dt,
             "unit": "geometries/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -199,11 +214,11 @@ def main():
                                    f"two-body t-RDM layout {a.layout} ({rows}x{cols} f64, "
                                    f"{rows * cols * 8 / 1e9:.3f} GB resident in HBM), {a.geoms} resident geometries",
                        "parallelism": f"pairs{world}" if world > 1 else "single",
-                       "streams": nslots},
+                       "streams": nslots, "geometries_per_step": G},
             "roofline": {"bound": "hbm", "kernel": "gemv_rows_kernel (K5: H_ab = Gamma.h2)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": bytes_rows, "ms_per_launch": k5_ms,
-                         "launches": rows_n.value},
+                         "launches": rows_n.value * launches_per_step, "geometries_per_launch": gl},
             "kernels": {"gemv_rows_ms": k5_ms, "gemv_cols_ms": k8_ms,
                         "gemv_cols_GBs": (bytes_cols / (k8_ms * 1e-3) / 1e9) if k8_ms else None},
             "last_energy": e_last,

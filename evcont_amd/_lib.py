@@ -38,6 +38,18 @@ class Outputs(C.Structure):
                 ("d_pred", C.c_void_p), ("g_pred", C.c_void_p), ("hmat", C.c_void_p)]
 
 
+class GeometryBatch(C.Structure):
+    _fields_ = [("natm", C.c_int32), ("count", C.c_int32), ("enuc", C.c_void_p),
+                ("S", C.c_void_p), ("hcore", C.c_void_p), ("eri", C.c_void_p), ("ipovlp", C.c_void_p),
+                ("dhcore", C.c_void_p), ("eri_ip1", C.c_void_p), ("gnuc", C.c_void_p),
+                ("aoslices", C.c_void_p)]
+
+
+class OutputsBatch(C.Structure):
+    _fields_ = [("energy", C.c_void_p), ("coeffs", C.c_void_p), ("grad", C.c_void_p),
+                ("d_pred", C.c_void_p), ("g_pred", C.c_void_p), ("hmat", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes); also the list the CPU test checks against the header
 SIGNATURES = {
     "evc_abi_version": (C.c_int, []),
@@ -66,6 +78,9 @@ SIGNATURES = {
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_energy_with_grad": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(Geometry), C.POINTER(Outputs), C.c_int,
                                        C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "evc_workspace_bytes_batch": (C.c_size_t, [C.POINTER(TrdmSet), C.c_int, C.c_int]),
+    "evc_energy_with_grad_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.POINTER(OutputsBatch),
+                                             C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_grad_elec_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "evc_grad_elec_oao": (C.c_int, [C.c_int, C.POINTER(Geometry), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -157,9 +157,15 @@ __device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double
 }
 
 // ------------------------------------------------------------------ Loewdin
-__global__ __launch_bounds__(kThreads) void loewdin_kernel(const double *__restrict__ S, const double *__restrict__ h,
-                                                           int n, double *__restrict__ X, double *__restrict__ U,
-                                                           double *__restrict__ sv, double *__restrict__ h1) {
+__global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
+    const int n = a.n;
+    const int64_t g = blockIdx.x;
+    const double *__restrict__ S = a.S + g * a.sS;
+    const double *__restrict__ h = a.h ? a.h + g * a.sh : nullptr;
+    double *__restrict__ X = a.X + g * a.sws;
+    double *__restrict__ U = a.U + g * a.sws;
+    double *__restrict__ sv = a.s + g * a.sws;
+    double *__restrict__ h1 = a.h1 ? a.h1 + g * a.sws : nullptr;
     extern __shared__ __align__(16) double sm[];
     const int m = (n + 1) & ~1;
     double *A = sm;              // m*m   (later: hcore)
@@ -221,13 +227,12 @@ static void allow_big_lds(K kernel, bool &done) {
     }
 }
 
-int launch_loewdin(const double *S, const double *hcore, int n, double *X, double *U, double *s, double *h1,
-                   hipStream_t st) {
-    const int m = (n + 1) & ~1;
+int launch_loewdin(const LoewdinArgs &a, int count, hipStream_t st) {
+    const int m = (a.n + 1) & ~1;
     const size_t lds = sizeof(double) * (size_t)3 * m * m + jacobi_aux_bytes(m);
     static bool attr_set = false;
     allow_big_lds(loewdin_kernel, attr_set);
-    hipLaunchKernelGGL(loewdin_kernel, dim3(1), dim3(kThreads), lds, st, S, hcore, n, X, U, s, h1);
+    hipLaunchKernelGGL(loewdin_kernel, dim3(count), dim3(kThreads), lds, st, a);
     EVC_LAUNCH_CHECK("loewdin");
     return 0;
 }
@@ -235,6 +240,17 @@ int launch_loewdin(const double *S, const double *hcore, int n, double *X, doubl
 // ------------------------------------------------------------------ subspace solve
 __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     extern __shared__ __align__(16) double sm[];
+    {
+        const int64_t g = blockIdx.x;
+        a.h1part += g * a.sh1;
+        a.h2part += g * a.sh2;
+        a.evals += g * a.sev;
+        a.evecs += g * a.svec;
+        if (a.Hout) a.Hout += g * a.sH;
+        if (a.w1) a.w1 += g * a.sw;
+        if (a.w2) a.w2 += g * a.sw;
+        if (a.e_shift_dev) a.e_shift = a.e_shift_dev[g];
+    }
     const int T = a.T;
     const int m = (T + 1) & ~1;
     double *H = sm;             // T*T  assembled H; later the coefficient vectors
@@ -381,12 +397,12 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     }
 }
 
-int launch_subspace_solve(const SolveArgs &a, hipStream_t st) {
+int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st) {
     const int m = (a.T + 1) & ~1;
     const size_t lds = sizeof(double) * (size_t)4 * m * m + sizeof(int) * m + jacobi_aux_bytes(m);
     static bool attr_set = false;
     allow_big_lds(subspace_kernel, attr_set);
-    hipLaunchKernelGGL(subspace_kernel, dim3(1), dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL(subspace_kernel, dim3(count), dim3(kThreads), lds, st, a);
     EVC_LAUNCH_CHECK("subspace_solve");
     return 0;
 }
@@ -396,6 +412,14 @@ int launch_subspace_solve(const SolveArgs &a, hipStream_t st) {
 __global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) {
     extern __shared__ __align__(16) double sm[];
     const int n = a.n;
+    {
+        const int64_t g = blockIdx.x;
+        a.X += g * a.sws;
+        a.hcore += g * a.sh;
+        a.D += g * a.sD;
+        a.Pao += g * a.sws;
+        a.Y1 += g * a.sws;
+    }
     double *Xs = sm;            // n*n
     double *Ds = Xs + n * n;    // n*n
     double *Hs = Ds + n * n;    // n*n
@@ -418,11 +442,11 @@ __global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) {
          [&](int i, int j, double v) { a.Y1[i * n + j] = a.scale1 * v; });
 }
 
-int launch_grad_prep(const GradPrepArgs &a, hipStream_t st) {
+int launch_grad_prep(const GradPrepArgs &a, int count, hipStream_t st) {
     const size_t lds = sizeof(double) * (size_t)4 * a.n * a.n;
     static bool attr_set = false;
     allow_big_lds(grad_prep_kernel, attr_set);
-    hipLaunchKernelGGL(grad_prep_kernel, dim3(1), dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL(grad_prep_kernel, dim3(count), dim3(kThreads), lds, st, a);
     EVC_LAUNCH_CHECK("grad_prep");
     return 0;
 }
@@ -434,6 +458,18 @@ int launch_grad_prep(const GradPrepArgs &a, hipStream_t st) {
 __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     extern __shared__ __align__(16) double sm[];
     const int n = a.n;
+    {
+        const int64_t g = blockIdx.x;
+        a.U += g * a.sws;
+        a.s += g * a.sws;
+        a.Y1 += g * a.sws;
+        a.y2 += g * a.sws;
+        a.t2part += g * a.sws;
+        a.term3 += g * a.sws;
+        a.ipovlp += g * a.sip;
+        if (a.gnuc) a.gnuc += g * a.sgn;
+        a.grad += g * a.sgrad;
+    }
     double *Y = sm;            // n*n
     double *Q = Y + n * n;     // n*n
     double *W = Q + n * n;     // n*n
@@ -514,11 +550,11 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     }
 }
 
-int launch_grad_final(const GradFinalArgs &a, hipStream_t st) {
+int launch_grad_final(const GradFinalArgs &a, int count, hipStream_t st) {
     const size_t lds = sizeof(double) * ((size_t)4 * a.n * a.n + 6 * a.n);
     static bool attr_set = false;
     allow_big_lds(grad_final_kernel, attr_set);
-    hipLaunchKernelGGL(grad_final_kernel, dim3(1), dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL(grad_final_kernel, dim3(count), dim3(kThreads), lds, st, a);
     EVC_LAUNCH_CHECK("grad_final");
     return 0;
 }
@@ -533,5 +569,13 @@ extern "C" int evc_loewdin(const double *S, const double *hcore, int n, double *
     EVC_REQUIRE(S && X && U && s, "evc_loewdin: null pointer");
     EVC_REQUIRE(n >= 1 && n <= 80, "evc_loewdin: n=%d out of range 1..80", n);
     EVC_REQUIRE((hcore == nullptr) == (h1 == nullptr), "evc_loewdin: hcore and h1 must both be given or both NULL");
-    return launch_loewdin(S, hcore, n, X, U, s, h1, as_stream(stream));
+    LoewdinArgs a{};
+    a.S = S;
+    a.h = hcore;
+    a.X = X;
+    a.U = U;
+    a.s = s;
+    a.h1 = h1;
+    a.n = n;
+    return launch_loewdin(a, 1, as_stream(stream));
 }

@@ -1,86 +1,111 @@
 // Streaming t-RDM contractions (HBM-bandwidth bound):
-//   K5/K4  rows GEMV   y[r]   = sum_c A[r,c] v[c]      (H_ab build,      evcont.py:38-68)
-//   K8/K7  cols GEMV   out[c] = sum_r w[r] A[r,c]      (predicted RDMs,  gradients_loewdin.py:343-356)
-// Each launch carries TWO problems (the two-body and the one-body t-RDM) so the small
-// one rides along with the big one instead of costing a kernel boundary.
+//   K5/K4  rows GEMV   y[g][r]   = sum_c A[r,c] v[g][c]     (H_ab build,      evcont.py:38-68)
+//   K8/K7  cols GEMV   out[g][c] = sum_r w[g][r] A[r,c]     (predicted RDMs,  gradients_loewdin.py:343-356)
+// A (the t-RDM) is shared by a batch of G <= 8 geometries, so one pass over the 0.68-2.6 GB matrix
+// serves G evaluations; at G = 8 the kernels are still HBM bound (16 flop per 8 bytes, ~20 % VALU).
+// Each launch carries TWO problems (the two-body and the one-body t-RDM) so the small one rides
+// along with the big one instead of costing a kernel boundary.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace evc {
 
-// ------------------------------------------------------------------ rows GEMV
-// Workgroup = 256 lanes x 16 B = one 512-column chunk of RB rows per step; a block owns a
-// span of `cps` chunks, keeps v for the chunk in registers and RB accumulators per lane.
-// Partials go to ws[span][row]; the consumer sums the spans in fixed order (deterministic).
-constexpr int kRB = 8;
-constexpr int kChunk = 512;  // columns per workgroup step
+constexpr int kChunk = 512;  // columns per workgroup step (256 lanes x 16 B)
 
 __device__ __forceinline__ double2 ld_stream(const double *p) {
     return *reinterpret_cast<const double2 *>(p);
 }
 
-__global__ __launch_bounds__(256) void gemv_rows_kernel(GemvRowsLaunch L) {
-    __shared__ double red[kRB][4];
+// Wave reduction of N (power of two <= 64) per-lane values with N-1 shuffles instead of 6N: at each
+// butterfly step a lane sends the half of its values it does not keep.  On return every lane holds
+// the wave-wide sum of value index lane >> (6 - log2 N).
+template <int N>
+__device__ __forceinline__ double multi_reduce(double (&v)[N], int lane) {
+    int off = 32;
+#pragma unroll
+    for (int m = N; m > 1; m >>= 1) {
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < m / 2; ++i) {
+            const double send = up ? v[i] : v[i + m / 2];
+            const double keep = up ? v[i + m / 2] : v[i];
+            v[i] = keep + __shfl_xor(send, off, kWave);
+        }
+        off >>= 1;
+    }
+    for (; off >= 1; off >>= 1) v[0] += __shfl_xor(v[0], off, kWave);
+    return v[0];
+}
+
+// ------------------------------------------------------------------ rows GEMV
+// Workgroup = 256 lanes x 16 B = one 512-column chunk of RB rows per step; a block owns a span of
+// `cps` chunks, keeps v[g] for the chunk in registers and RB*G accumulators per lane.
+// Partials go to ws[g][span][row]; the consumer sums the spans in fixed order (deterministic).
+template <int RB, int G>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(GemvRowsLaunch L, int g0) {
+    constexpr int NV = RB * G;
+    __shared__ double red[NV][4];
     int bid = blockIdx.x;
     const int which = bid >= L.nblk0 ? 1 : 0;
     if (which) bid -= L.nblk0;
     const RowProblem &P = L.p[which];
     const int span = bid % P.nspans;
     const int rb = bid / P.nspans;
-    const int64_t row0 = (int64_t)rb * kRB;
-    const int nrows = (int)min((int64_t)kRB, P.rows - row0);
+    const int64_t row0 = (int64_t)rb * RB;
+    const int nrows = (int)min((int64_t)RB, P.rows - row0);
     const int tid = threadIdx.x;
 
     int64_t c = ((int64_t)span * P.cps) * kChunk + tid * 2;
     const int64_t cend = min(P.cols, ((int64_t)(span + 1) * P.cps) * kChunk);
-    const double *__restrict__ A = P.A + row0 * P.ld;
-    const double *__restrict__ v = P.v;
     const int64_t ld = P.ld;
+    const double *__restrict__ v = P.v + (int64_t)g0 * P.vstride;
+    const int64_t vs = P.vstride;
+    // rows past the end of a ragged last block re-read the last valid row (results discarded)
+    const double *__restrict__ Ar[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) Ar[r] = P.A + (row0 + (r < nrows ? r : nrows - 1)) * ld;
 
-    double acc[kRB];
+    double acc[NV];
 #pragma unroll
-    for (int r = 0; r < kRB; ++r) acc[r] = 0.0;
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
 
-    if (nrows == kRB) {
-        // full row block, whole chunks: no predicates in the steady state
-        for (; c + 1 < cend; c += kChunk) {
-            const double2 vv = ld_stream(v + c);
-            double2 a[kRB];
+    for (; c + 1 < cend; c += kChunk) {
+        double2 a[RB], vv[G];
 #pragma unroll
-            for (int r = 0; r < kRB; ++r) a[r] = ld_stream(A + r * ld + c);
+        for (int r = 0; r < RB; ++r) a[r] = ld_stream(Ar[r] + c);
 #pragma unroll
-            for (int r = 0; r < kRB; ++r) acc[r] = fma(a[r].y, vv.y, fma(a[r].x, vv.x, acc[r]));
-        }
-        if (c < cend) {  // odd `cols`: last single column
-            const double vx = v[c];
+        for (int g = 0; g < G; ++g) vv[g] = ld_stream(v + g * vs + c);
 #pragma unroll
-            for (int r = 0; r < kRB; ++r) acc[r] = fma(A[r * ld + c], vx, acc[r]);
-        }
-    } else {
-        for (; c < cend; c += kChunk) {
-            const bool two = c + 1 < cend;
-            const double vx = v[c], vy = two ? v[c + 1] : 0.0;
-            for (int r = 0; r < nrows; ++r) {
-                const double ax = A[r * ld + c], ay = two ? A[r * ld + c + 1] : 0.0;
-                acc[r] = fma(ay, vy, fma(ax, vx, acc[r]));
-            }
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[r * G + g] = fma(a[r].y, vv[g].y, fma(a[r].x, vv[g].x, acc[r * G + g]));
+    }
+    if (c < cend) {  // odd `cols`: last single column
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const double ax = Ar[r][c];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[r * G + g] = fma(ax, v[g * vs + c], acc[r * G + g]);
         }
     }
 
     const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int r = 0; r < kRB; ++r) {
-        const double s = wave_sum(acc[r]);
-        if (lane == 0) red[r][wave] = s;
-    }
+    const double s = multi_reduce<NV>(acc, lane);
+    constexpr int kShift = (NV >= 64) ? 0 : (NV == 32 ? 1 : NV == 16 ? 2 : NV == 8 ? 3 : NV == 4 ? 4 : NV == 2 ? 5 : 6);
+    if ((lane & ((1 << kShift) - 1)) == 0) red[lane >> kShift][wave] = s;
     __syncthreads();
-    if (tid < nrows) {
-        const double s = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
-        P.partial[(int64_t)span * P.rows + row0 + tid] = s;
+    if (tid < NV) {
+        const int r = tid / G, g = tid - r * G;
+        if (r < nrows) {
+            const double t = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+            P.partial[(int64_t)(g0 + g) * P.pstride + (int64_t)span * P.rows + row0 + r] = t;
+        }
     }
 }
 
-// y[r] = alpha * sum_span partial[r][span]
+// y[r] = alpha * sum_span partial[span][r]
 __global__ void gemv_rows_reduce_kernel(const double *partial, int64_t rows, int nspans, double alpha,
                                         double *y) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,11 +115,19 @@ __global__ void gemv_rows_reduce_kernel(const double *partial, int64_t rows, int
     y[r] = alpha * s;
 }
 
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+constexpr int kRBPlan = 8;  // row-block height the workspace/partials are planned for (all variants use it)
+
 void plan_rows(RowProblem &P) {
     const int64_t nchunks = ceil_div(P.cols, kChunk);
-    const int64_t nrb = ceil_div(P.rows, kRB);
+    const int64_t nrb = ceil_div(P.rows, kRBPlan);
     // aim at >= ~2048 workgroups (8 per CU) while keeping spans >= 4 chunks when possible
-    int64_t want_spans = ceil_div(2048, nrb);
+    static const int target = env_int("EVC_ROWS_TARGET_WGS", 2048);
+    int64_t want_spans = ceil_div(target, nrb);
     int64_t cps = nchunks / want_spans;
     if (cps < 4) cps = nchunks < 4 ? nchunks : 4;
     if (cps < 1) cps = 1;
@@ -111,70 +144,169 @@ size_t rows_ws_doubles(int64_t rows, int64_t cols) {
     return (size_t)rows * P.nspans;
 }
 
-int launch_gemv_rows(RowProblem p0, RowProblem p1, hipStream_t st) {
+// The span decomposition (cps, nspans -> layout of the partials) is fixed by plan_rows; the row-block
+// height RB is a property of the kernel variant only: nblocks = ceil(rows/RB) * nspans.
+template <int RB, int G>
+static void rows_launch(GemvRowsLaunch L, int g0, hipStream_t st) {
+    for (int k = 0; k < 2; ++k)
+        L.p[k].nblocks = L.p[k].nblocks ? (int)(ceil_div(L.p[k].rows, RB) * L.p[k].nspans) : 0;
+    L.nblk0 = L.p[0].nblocks;
+    hipLaunchKernelGGL((gemv_rows_kernel<RB, G>), dim3(L.p[0].nblocks + L.p[1].nblocks), dim3(256), 0, st, L, g0);
+}
+
+int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     GemvRowsLaunch L;
     L.p[0] = p0;
     L.p[1] = p1;
     L.nblk0 = p0.nblocks;
-    const int total = p0.nblocks + p1.nblocks;
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(gemv_rows_kernel, dim3(total), dim3(256), 0, st, L);
-    EVC_LAUNCH_CHECK("gemv_rows");
+    if (p0.nblocks + p1.nblocks == 0 || count <= 0) return 0;
+    static const int rb8 = env_int("EVC_ROWS_RB_G8", 4);
+    static const int rb4 = env_int("EVC_ROWS_RB_G4", 8);
+    int g0 = 0;
+    while (g0 < count) {
+        const int left = count - g0;
+        if (left >= 8) {
+            if (rb8 == 8) rows_launch<8, 8>(L, g0, st);
+            else if (rb8 == 2) rows_launch<2, 8>(L, g0, st);
+            else rows_launch<4, 8>(L, g0, st);
+            g0 += 8;
+        } else if (left >= 4) {
+            if (rb4 == 4) rows_launch<4, 4>(L, g0, st);
+            else rows_launch<8, 4>(L, g0, st);
+            g0 += 4;
+        } else if (left >= 2) {
+            rows_launch<8, 2>(L, g0, st);
+            g0 += 2;
+        } else {
+            rows_launch<8, 1>(L, g0, st);
+            g0 += 1;
+        }
+        EVC_LAUNCH_CHECK("gemv_rows");
+    }
     return 0;
 }
 
 // ------------------------------------------------------------------ cols GEMV
-// Each lane owns two adjacent columns and walks down the rows with kU independent
-// 16-byte loads in flight; the row weights are wave-uniform (scalar loads).
+// Each lane owns two adjacent columns and walks down the rows with kU independent 16-byte loads in
+// flight.  G = 1: the row weights are wave-uniform scalar loads.  G > 1: the weights of a 512-row
+// tile are staged in LDS as wl[row][g] and read back as broadcasts.
 constexpr int kU = 16;
+constexpr int kWTile = 512;
 
-__global__ __launch_bounds__(256) void gemv_cols_kernel(GemvColsLaunch L) {
+template <int G>
+__global__ __launch_bounds__(256) void gemv_cols_kernel(GemvColsLaunch L, int g0) {
+    __shared__ double wl[(G > 1) ? kWTile * G : 1];
     int bid = blockIdx.x;
     const int which = bid >= L.nblk0 ? 1 : 0;
     if (which) bid -= L.nblk0;
     const ColProblem &P = L.p[which];
     const int64_t c = (int64_t)bid * kChunk + threadIdx.x * 2;
-    if (c >= P.cols) return;
-    const double *__restrict__ A = P.A + c;
-    const double *__restrict__ w = P.w;
+    const bool active = c < P.cols;
+    const bool two = c + 1 < P.cols;
+    const double *__restrict__ A = P.A + (active ? c : 0);
+    const double *__restrict__ w = P.w + (int64_t)g0 * P.wstride;
     const int64_t ld = P.ld;
     const int64_t rows = P.rows;
-    double sx = 0.0, sy = 0.0;
-    if (c + 1 < P.cols) {
-        int64_t r = 0;
-        for (; r + kU <= rows; r += kU) {
-            double2 a[kU];
+    double sx[G], sy[G];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) a[u] = ld_stream(A + (r + u) * ld);
+    for (int g = 0; g < G; ++g) sx[g] = sy[g] = 0.0;
+
+    if constexpr (G == 1) {
+        if (active && two) {
+            int64_t r = 0;
+            for (; r + kU <= rows; r += kU) {
+                double2 a[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const double wr = w[r + u];
-                sx = fma(wr, a[u].x, sx);
-                sy = fma(wr, a[u].y, sy);
+                for (int u = 0; u < kU; ++u) a[u] = ld_stream(A + (r + u) * ld);
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const double wr = w[r + u];
+                    sx[0] = fma(wr, a[u].x, sx[0]);
+                    sy[0] = fma(wr, a[u].y, sy[0]);
+                }
+            }
+            for (; r < rows; ++r) {
+                const double2 a = ld_stream(A + r * ld);
+                const double wr = w[r];
+                sx[0] = fma(wr, a.x, sx[0]);
+                sy[0] = fma(wr, a.y, sy[0]);
+            }
+        } else if (active) {
+            for (int64_t r = 0; r < rows; ++r) sx[0] = fma(w[r], A[r * ld], sx[0]);
+        }
+    } else {
+        for (int64_t r0 = 0; r0 < rows; r0 += kWTile) {
+            const int nr = (int)min((int64_t)kWTile, rows - r0);
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < nr * G; idx += 256) {
+                const int r = idx / G, g = idx - r * G;
+                wl[idx] = w[(int64_t)g * P.wstride + r0 + r];
+            }
+            __syncthreads();
+            if (active && two) {
+                int r = 0;
+                for (; r + kU <= nr; r += kU) {
+                    double2 a[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) a[u] = ld_stream(A + (r0 + r + u) * ld);
+#pragma unroll
+                    for (int u = 0; u < kU; ++u)
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const double wr = wl[(r + u) * G + g];
+                            sx[g] = fma(wr, a[u].x, sx[g]);
+                            sy[g] = fma(wr, a[u].y, sy[g]);
+                        }
+                }
+                for (; r < nr; ++r) {
+                    const double2 a = ld_stream(A + (r0 + r) * ld);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const double wr = wl[r * G + g];
+                        sx[g] = fma(wr, a.x, sx[g]);
+                        sy[g] = fma(wr, a.y, sy[g]);
+                    }
+                }
+            } else if (active) {
+                for (int r = 0; r < nr; ++r) {
+                    const double ax = A[(r0 + r) * ld];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) sx[g] = fma(wl[r * G + g], ax, sx[g]);
+                }
             }
         }
-        for (; r < rows; ++r) {
-            const double2 a = ld_stream(A + r * ld);
-            const double wr = w[r];
-            sx = fma(wr, a.x, sx);
-            sy = fma(wr, a.y, sy);
+    }
+    if (active) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            double *o = P.out + (int64_t)(g0 + g) * P.ostride + c;
+            if (two) *reinterpret_cast<double2 *>(o) = make_double2(sx[g], sy[g]);
+            else *o = sx[g];
         }
-        *reinterpret_cast<double2 *>(P.out + c) = make_double2(sx, sy);
-    } else {
-        for (int64_t r = 0; r < rows; ++r) sx = fma(w[r], A[r * ld], sx);
-        P.out[c] = sx;
     }
 }
 
-int launch_gemv_cols(ColProblem p0, ColProblem p1, hipStream_t st) {
+template <int G>
+static void cols_launch(const GemvColsLaunch &L, int total, int g0, hipStream_t st) {
+    hipLaunchKernelGGL((gemv_cols_kernel<G>), dim3(total), dim3(256), 0, st, L, g0);
+}
+
+int launch_gemv_cols(ColProblem p0, ColProblem p1, int count, hipStream_t st) {
     GemvColsLaunch L;
     L.p[0] = p0;
     L.p[1] = p1;
     L.nblk0 = (int)ceil_div(p0.cols, kChunk);
     const int total = L.nblk0 + (int)ceil_div(p1.cols, kChunk);
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(gemv_cols_kernel, dim3(total), dim3(256), 0, st, L);
-    EVC_LAUNCH_CHECK("gemv_cols");
+    if (total == 0 || count <= 0) return 0;
+    int g0 = 0;
+    while (g0 < count) {
+        const int left = count - g0;
+        if (left >= 8) { cols_launch<8>(L, total, g0, st); g0 += 8; }
+        else if (left >= 4) { cols_launch<4>(L, total, g0, st); g0 += 4; }
+        else if (left >= 2) { cols_launch<2>(L, total, g0, st); g0 += 2; }
+        else { cols_launch<1>(L, total, g0, st); g0 += 1; }
+        EVC_LAUNCH_CHECK("gemv_cols");
+    }
     return 0;
 }
 
@@ -206,7 +338,7 @@ extern "C" int evc_gemv_rows(const double *A, int64_t rows, int64_t cols, int64_
     P.ld = ld;
     plan_rows(P);
     RowProblem none{};
-    int rc = launch_gemv_rows(P, none, as_stream(stream));
+    int rc = launch_gemv_rows(P, none, 1, as_stream(stream));
     if (rc) return rc;
     hipLaunchKernelGGL(gemv_rows_reduce_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0,
                        as_stream(stream), P.partial, rows, P.nspans, alpha, y);
@@ -230,5 +362,5 @@ extern "C" int evc_gemv_cols(const double *A, int64_t rows, int64_t cols, int64_
     P.cols = cols;
     P.ld = ld;
     ColProblem none{};
-    return launch_gemv_cols(P, none, as_stream(stream));
+    return launch_gemv_cols(P, none, 1, as_stream(stream));
 }

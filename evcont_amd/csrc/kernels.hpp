@@ -1,15 +1,22 @@
 // Internal launch interfaces shared by the translation units of libevcont_hip.so.
+//
+// Batching: every kernel of the per-geometry pipeline carries a batch index (blockIdx.y for the
+// multi-workgroup kernels, blockIdx.x for the single-workgroup ones).  A pointer `p` that belongs
+// to geometry 0 is paired with a stride `sp` in doubles; geometry g uses p + g*sp.  Workspace
+// buffers all share one stride (the per-geometry workspace size), inputs/outputs have their own.
 #pragma once
 #include "common.hpp"
 
 namespace evc {
 
+constexpr int kMaxBatchG = 8;  // geometries contracted per pass of the streaming kernels
+
 // ---- gemv_stream.hip ---------------------------------------------------------------
 struct RowProblem {
-    const double *A;   // (rows, ld)
-    const double *v;   // (cols)
-    double *partial;   // (rows, nspans)
-    int64_t rows, cols, ld;
+    const double *A;   // (rows, ld)                       shared by the batch
+    const double *v;   // (cols)            + g*vstride
+    double *partial;   // (nspans, rows)    + g*pstride
+    int64_t rows, cols, ld, vstride, pstride;
     int nspans, cps, nblocks;
 };
 struct GemvRowsLaunch {
@@ -17,10 +24,10 @@ struct GemvRowsLaunch {
     int nblk0;
 };
 struct ColProblem {
-    const double *A;  // (rows, ld)
-    const double *w;  // (rows)
-    double *out;      // (cols)
-    int64_t rows, cols, ld;
+    const double *A;  // (rows, ld)                        shared by the batch
+    const double *w;  // (rows)             + g*wstride
+    double *out;      // (cols)             + g*ostride
+    int64_t rows, cols, ld, wstride, ostride;
 };
 struct GemvColsLaunch {
     ColProblem p[2];
@@ -28,65 +35,89 @@ struct GemvColsLaunch {
 };
 void plan_rows(RowProblem &P);
 size_t rows_ws_doubles(int64_t rows, int64_t cols);
-int launch_gemv_rows(RowProblem p0, RowProblem p1, hipStream_t st);
-int launch_gemv_cols(ColProblem p0, ColProblem p1, hipStream_t st);
+// `count` geometries; launched in groups of up to kMaxBatchG that share one read of A.
+int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st);
+int launch_gemv_cols(ColProblem p0, ColProblem p1, int count, hipStream_t st);
 
 // ---- transform.hip -----------------------------------------------------------------
-int launch_quarter_transform(const double *in, const double *C, int c_transposed, int n, double *out,
-                             hipStream_t st);
-int launch_pack(const double *h2, int n, double diag_mult, double *out, int64_t out_len, hipStream_t st);
-int launch_unpack(const double *packed, int n, double *out, hipStream_t st);
+int launch_quarter_transform(const double *in, int64_t sin, const double *C, int64_t sC, int c_transposed, int n,
+                             double *out, int64_t sout, int count, hipStream_t st);
+int launch_pack(const double *h2, int64_t sh2, int n, double diag_mult, double *out, int64_t sout, int64_t out_len,
+                int count, hipStream_t st);
+int launch_unpack(const double *packed, int64_t sp, int n, double *out, int64_t sout, int count, hipStream_t st);
 // Gs^T[jkl][i] = G[i,j,k,l] + G[j,i,k,l] + G[l,k,j,i] + G[k,l,i,j]   (gradients_loewdin.py:213-215)
-int launch_sym_oao_t(const double *G, int n, double *out, hipStream_t st);
-// partial[b][i][a] = sum_{k in slab b} GsT[k][i] * K3[k][a]   (k = jkl);  returns #slabs via nslabs
+int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t sout, int count, hipStream_t st);
+// partial[b][i][a] = sum_{k in slab b} GsT[k][i] * K3[k][a]   (k = jkl)
 int y2_slabs(int n);
-int launch_y2(const double *GsT, const double *K3, int n, double *partial, hipStream_t st);
-// ip1 contraction with on-the-fly AO symmetrisation (gradients_loewdin.py:234-252) + dhcore:P_ao dots
+int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);
+// ip1 contraction with on-the-fly AO symmetrisation (gradients_loewdin.py:234-252), dhcore:P_ao dots
+// and the fixed-order sum of the Y2 slabs (three block families of one launch)
 int ip1_chunks(int n);
-// ... and the fixed-order sum of the Y2 slabs (third block family of the same launch)
-int launch_ip1_dh(const double *ip1, const double *Gao, int n, double *t2_partial, const double *dhcore,
-                  const double *Pao, int natm, double *term3, const double *y2part, int nslab, double *y2,
-                  hipStream_t st);
+struct Ip1Args {
+    const double *ip1;     // (3,n^4)      + g*sip1
+    const double *Gao;     // (n^4)        + g*sws
+    double *t2part;        // (n,3,nchunk) + g*sws
+    const double *dh;      // (A,3,n,n)    + g*sdh      (may be NULL with natm = 0)
+    const double *Pao;     // (n,n)        + g*sws
+    double *term3;         // (A*3)        + g*sws
+    const double *y2part;  // (nslab,n,n)  + g*sws
+    double *y2;            // (n,n)        + g*sws
+    int64_t sip1, sdh, sws;
+    int n, natm, nslab, nchunk;
+};
+int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st);
 
 // ---- dense_small.hip ---------------------------------------------------------------
-int launch_loewdin(const double *S, const double *hcore, int n, double *X, double *U, double *s, double *h1,
-                   hipStream_t st);
+struct LoewdinArgs {
+    const double *S, *h;   // + g*sS, + g*sh   (h may be NULL)
+    double *X, *U, *s, *h1;  // + g*sws        (h1 may be NULL)
+    int64_t sS, sh, sws;
+    int n;
+};
+int launch_loewdin(const LoewdinArgs &a, int count, hipStream_t st);
 struct SolveArgs {
-    const double *h1part;  // (T*T, nsp1) partial sums of the one-body rows
+    const double *h1part;  // (nsp1, T*T) partial sums of the one-body rows      + g*sh1
     int nsp1;
     double alpha1;
-    const double *h2part;  // (rows2_total, nsp2) partial sums of the two-body rows
+    const double *h2part;  // (nsp2, rows2_total) partial sums of two-body rows  + g*sh2
     int nsp2;
     double alpha2;
-    const double *S;  // (T,T)
+    const double *S;  // (T,T) shared
     int T, layout, nroots;
-    double e_shift;
-    double *evals, *evecs, *w2, *w1, *Hout;
+    double e_shift;             // used when e_shift_dev == NULL
+    const double *e_shift_dev;  // [count] or NULL
+    double *evals, *evecs, *Hout;  // + g*sev, + g*svec, + g*sH  (Hout may be NULL)
+    double *w2, *w1;               // + g*sw
+    int64_t sh1, sh2, sev, svec, sH, sw;
     int64_t w2_offset, w2_count;  // slice of the global weight vector to write (multi-GPU)
 };
-int launch_subspace_solve(const SolveArgs &a, hipStream_t st);
+int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st);
 struct GradPrepArgs {
     int n;
-    const double *X, *hcore, *D;  // D = predicted 1-RDM (n,n)
-    double *Pao;                  // X D X^T
-    double *Y1;                   // hcore X (D + D^T)
-    double scale1;                // 1 on the rank that owns the one-body part, else 0
+    const double *X;      // + g*sws
+    const double *hcore;  // + g*sh
+    const double *D;      // predicted 1-RDM (n,n)  + g*sD
+    double *Pao;          // X D X^T                + g*sws
+    double *Y1;           // hcore X (D + D^T)      + g*sws
+    int64_t sws, sh, sD;
+    double scale1;        // 1 on the rank that owns the one-body part, else 0
 };
-int launch_grad_prep(const GradPrepArgs &a, hipStream_t st);
+int launch_grad_prep(const GradPrepArgs &a, int count, hipStream_t st);
 struct GradFinalArgs {
     int n, natm;
-    const double *U, *s;          // eigen-decomposition of S_AO
-    const double *Y1;             // (n,n) [a][i]
-    const double *y2;             // (n, n) as [i][a]  (slabs already summed)
-    const double *ipovlp;         // (3,n,n)
-    const int64_t *aoslices;      // (A,2)
-    const double *t2part;         // (n, 3, nchunk) partial sums of T2diag[x,m]
+    const double *U, *s;          // eigen-decomposition of S_AO   + g*sws
+    const double *Y1;             // (n,n) [a][i]                  + g*sws
+    const double *y2;             // (n,n) [i][a]                  + g*sws
+    const double *ipovlp;         // (3,n,n)                       + g*sip
+    const int64_t *aoslices;      // (A,2) shared
+    const double *t2part;         // (n,3,nchunk)                  + g*sws
     int nchunk;
-    const double *term3;          // (A*3)
-    const double *gnuc;           // (A,3) or NULL
+    const double *term3;          // (A*3)                         + g*sws
+    const double *gnuc;           // (A,3) or NULL                 + g*sgn
     double scale1;                // 1: include term3 + gnuc
-    double *grad;                 // (A,3)
+    double *grad;                 // (A,3)                         + g*sgrad
+    int64_t sws, sip, sgn, sgrad;
 };
-int launch_grad_final(const GradFinalArgs &a, hipStream_t st);
+int launch_grad_final(const GradFinalArgs &a, int count, hipStream_t st);
 
 }  // namespace evc

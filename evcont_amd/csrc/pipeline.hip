@@ -1,7 +1,10 @@
 // Per-geometry orchestration: enqueues the whole energy(+force) DAG on one HIP stream.
 // Mirrors get_energy_with_grad (gradients_loewdin.py:308-379) and approximate_*_OAO
-// (evcont.py:178-250); split in three phases so a pair-sharded multi-GPU host can put its two
-// small collectives (all-gather of the H rows, all-reduce of the gradient) between them.
+// (evcont.py:178-250).  Two generalisations over the reference:
+//   * BATCH: `count` independent geometries go through every launch together (batch index =
+//     blockIdx.y / blockIdx.x) and share ONE pass over the t-RDM in the two streaming kernels;
+//   * PHASES: split in three so a pair-sharded multi-GPU host can put its two small collectives
+//     (all-gather of the H rows, all-reduce of the gradient) between them.
 #include <string.h>
 
 #include "common.hpp"
@@ -27,6 +30,20 @@ struct Prof {
 };
 static Prof g_prof;
 
+// Internal batch view of the geometry inputs / outputs (strides in doubles; 0 for a single geometry).
+struct Geo {
+    int natm, count;
+    const double *S, *hcore, *eri, *ipovlp, *dhcore, *eri_ip1, *gnuc;
+    const int64_t *aoslices;
+    int64_t sS, sh, seri, sip, sdh, sip1, sgn;
+    double enuc;             // used when enuc_dev == NULL
+    const double *enuc_dev;  // [count]
+};
+struct Out {
+    double *energy, *coeffs, *grad, *d_pred, *g_pred, *hmat;
+    int64_t se, sc, sg, sd, sG, sH;
+};
+
 struct Ws {
     // N^2-sized
     double *X, *U, *s, *h1, *Dpred, *Pao, *Y1;
@@ -39,7 +56,8 @@ struct Ws {
     double *y2part, *y2, *t2part, *term3;
     // scratch outputs when the caller passes NULL
     double *evals, *evecs;
-    size_t bytes;
+    size_t bytes;    // of ONE geometry
+    int64_t stride;  // the same in doubles
     RowProblem rp2, rp1;
 };
 
@@ -112,9 +130,10 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.evals = take(T);
     w.evecs = take(T * T);
     w.bytes = off;
+    w.stride = (int64_t)(off / sizeof(double));
 }
 
-// y[r] = alpha * sum_k partial[r][k]   (tiny; only used on the multi-GPU path)
+// y[r] = alpha * sum_k partial[k][r]   (tiny; only used on the multi-GPU path)
 __global__ void rows_reduce_kernel(const double *partial, int64_t rows, int nspans, double alpha, double *y) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
@@ -123,32 +142,45 @@ __global__ void rows_reduce_kernel(const double *partial, int64_t rows, int nspa
     y[r] = alpha * s;
 }
 
-static int phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, Ws &w, bool reduce_rows,
-                             hipStream_t st) {
-    const int n = t->n;
+static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool reduce_rows, hipStream_t st) {
+    const int n = t->n, cnt = g.count;
+    const int64_t sw = w.stride;
     int rc;
-    if ((rc = launch_loewdin(g->S, g->hcore, n, w.X, w.U, w.s, w.h1, st))) return rc;
+    LoewdinArgs la{};
+    la.S = g.S;
+    la.h = g.hcore;
+    la.X = w.X;
+    la.U = w.U;
+    la.s = w.s;
+    la.h1 = w.h1;
+    la.sS = g.sS;
+    la.sh = g.sh;
+    la.sws = sw;
+    la.n = n;
+    if ((rc = launch_loewdin(la, cnt, st))) return rc;
     // (ab|cd) -> K3[jkl][a] -> h2[ijkl]
-    if ((rc = launch_quarter_transform(g->eri, w.X, 0, n, w.B1, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B1, w.X, 0, n, w.B2, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B2, w.X, 0, n, w.K3, st))) return rc;
-    if ((rc = launch_quarter_transform(w.K3, w.X, 0, n, w.B1, st))) return rc;
+    if ((rc = launch_quarter_transform(g.eri, g.seri, w.X, sw, 0, n, w.B1, sw, cnt, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 0, n, w.B2, sw, cnt, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 0, n, w.K3, sw, cnt, st))) return rc;
+    if ((rc = launch_quarter_transform(w.K3, sw, w.X, sw, 0, n, w.B1, sw, cnt, st))) return rc;
     const double *v2 = w.B1;
     if (is_packed(t->layout)) {
-        if ((rc = launch_pack(w.B1, n, 0.5, w.vec2, t->ld2, st))) return rc;
+        if ((rc = launch_pack(w.B1, sw, n, 0.5, w.vec2, sw, t->ld2, cnt, st))) return rc;
         v2 = w.vec2;
     }
     RowProblem p2 = w.rp2, p1 = w.rp1;
     p2.A = t->two_rdm;
     p2.v = v2;
     p2.partial = w.h2part;
+    p2.vstride = p2.pstride = sw;
     if (t->rows2 == 0) p2.nblocks = 0;
     p1.A = t->one_rdm;
     p1.v = w.h1;
     p1.partial = w.h1part;
+    p1.vstride = p1.pstride = sw;
     const bool prof = g_prof.on && g_prof.n_rows < g_prof.cap;
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_rows + 0], st);
-    if ((rc = launch_gemv_rows(p2, p1, st))) return rc;
+    if ((rc = launch_gemv_rows(p2, p1, cnt, st))) return rc;
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_rows++ + 1], st);
     if (reduce_rows && t->rows2 > 0) {
         const double alpha2 = is_packed(t->layout) ? 1.0 : 0.5;
@@ -159,106 +191,159 @@ static int phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, Ws &w
     return 0;
 }
 
-static int phase_solve(const evc_trdm_set *t, const evc_geometry *g, const double *h2rows_all,
-                       const evc_outputs *out, int nroots, Ws &w, hipStream_t st) {
+static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows_all, const Out &out, int nroots,
+                       Ws &w, hipStream_t st) {
     SolveArgs a;
     memset(&a, 0, sizeof(a));
+    const int64_t sw = w.stride;
     a.h1part = w.h1part;
     a.nsp1 = w.rp1.nspans;
     a.alpha1 = 1.0;
+    a.sh1 = sw;
     if (h2rows_all) {
         a.h2part = h2rows_all;
         a.nsp2 = 1;
         a.alpha2 = 1.0;
+        a.sh2 = 0;
     } else {
         a.h2part = w.h2part;
         a.nsp2 = w.rp2.nspans;
         a.alpha2 = is_packed(t->layout) ? 1.0 : 0.5;
+        a.sh2 = sw;
     }
     a.S = t->s_train;
     a.T = t->ntrain;
     a.layout = t->layout;
     a.nroots = nroots;
-    a.e_shift = g->enuc;
-    a.evals = (out && out->energy) ? out->energy : w.evals;
-    a.evecs = (out && out->coeffs) ? out->coeffs : w.evecs;
+    a.e_shift = g.enuc;
+    a.e_shift_dev = g.enuc_dev;
+    if (out.energy) {
+        a.evals = out.energy;
+        a.sev = out.se;
+    } else {
+        a.evals = w.evals;
+        a.sev = sw;
+    }
+    if (out.coeffs) {
+        a.evecs = out.coeffs;
+        a.svec = out.sc;
+    } else {
+        a.evecs = w.evecs;
+        a.svec = sw;
+    }
+    a.Hout = out.hmat;
+    a.sH = out.sH;
     a.w2 = w.w2;
     a.w1 = w.w1;
-    a.Hout = out ? out->hmat : nullptr;
+    a.sw = sw;
     a.w2_offset = t->row_offset;
     a.w2_count = t->rows2;
-    return launch_subspace_solve(a, st);
+    return launch_subspace_solve(a, g.count, st);
 }
 
 // Gradient of the energy functional defined by (D, G) [G unpacked, N^4] given X,U,s,K3 in the
 // workspace.  scale1 = 0 drops everything that is not linear in G (multi-GPU partial ranks).
-static int gradient_from_rdms(int n, const evc_geometry *g, const double *D, const double *G, double scale1,
-                              bool add_gnuc, double *grad, Ws &w, hipStream_t st) {
+static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, const double *G, int64_t sG,
+                              double scale1, bool add_gnuc, double *grad, int64_t sgrad, Ws &w, hipStream_t st) {
+    const int cnt = g.count;
+    const int64_t sw = w.stride;
     int rc;
-    if ((rc = launch_sym_oao_t(G, n, w.B2, st))) return rc;
-    if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, st))) return rc;
+    if ((rc = launch_sym_oao_t(G, sG, n, w.B2, sw, cnt, st))) return rc;
+    if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, sw, cnt, st))) return rc;
     // G^AO = (X x X x X x X) G, contraction over the SECOND index of X (gradients_loewdin.py:224-232)
-    if ((rc = launch_quarter_transform(G, w.X, 1, n, w.B1, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B1, w.X, 1, n, w.B2, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B2, w.X, 1, n, w.B1, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B1, w.X, 1, n, w.B2, st))) return rc;
+    if ((rc = launch_quarter_transform(G, sG, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
     GradPrepArgs p;
     p.n = n;
     p.X = w.X;
-    p.hcore = g->hcore;
+    p.hcore = g.hcore;
     p.D = D;
     p.Pao = w.Pao;
     p.Y1 = w.Y1;
+    p.sws = sw;
+    p.sh = g.sh;
+    p.sD = sD;
     p.scale1 = scale1;
-    if ((rc = launch_grad_prep(p, st))) return rc;
-    if ((rc = launch_ip1_dh(g->eri_ip1, w.B2, n, w.t2part, g->dhcore, w.Pao, g->natm, w.term3, w.y2part,
-                            y2_slabs(n), w.y2, st)))
-        return rc;
+    if ((rc = launch_grad_prep(p, cnt, st))) return rc;
+    Ip1Args ia;
+    ia.ip1 = g.eri_ip1;
+    ia.Gao = w.B2;
+    ia.t2part = w.t2part;
+    ia.dh = g.dhcore;
+    ia.Pao = w.Pao;
+    ia.term3 = w.term3;
+    ia.y2part = w.y2part;
+    ia.y2 = w.y2;
+    ia.sip1 = g.sip1;
+    ia.sdh = g.sdh;
+    ia.sws = sw;
+    ia.n = n;
+    ia.natm = g.natm;
+    ia.nslab = y2_slabs(n);
+    ia.nchunk = ip1_chunks(n);
+    if ((rc = launch_ip1_dh(ia, cnt, st))) return rc;
     GradFinalArgs f;
     f.n = n;
-    f.natm = g->natm;
+    f.natm = g.natm;
     f.U = w.U;
     f.s = w.s;
     f.Y1 = w.Y1;
     f.y2 = w.y2;
-    f.ipovlp = g->ipovlp;
-    f.aoslices = g->aoslices;
+    f.ipovlp = g.ipovlp;
+    f.aoslices = g.aoslices;
     f.t2part = w.t2part;
     f.nchunk = ip1_chunks(n);
     f.term3 = w.term3;
-    f.gnuc = add_gnuc ? g->gnuc : nullptr;
+    f.gnuc = add_gnuc ? g.gnuc : nullptr;
     f.scale1 = scale1;
     f.grad = grad;
-    return launch_grad_final(f, st);
+    f.sws = sw;
+    f.sip = g.sip;
+    f.sgn = g.sgn;
+    f.sgrad = sgrad;
+    return launch_grad_final(f, cnt, st);
 }
 
-static int phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out, int flags,
-                          Ws &w, hipStream_t st) {
-    const int n = t->n;
+static int phase_gradient(const evc_trdm_set *t, const Geo &g, const Out &out, int flags, Ws &w, hipStream_t st) {
+    const int n = t->n, cnt = g.count;
+    const int64_t sw = w.stride;
     int rc;
-    double *D = out->d_pred ? out->d_pred : w.Dpred;
-    double *G = out->g_pred ? out->g_pred : w.G;
+    double *D = out.d_pred ? out.d_pred : w.Dpred;
+    const int64_t sD = out.d_pred ? out.sd : sw;
+    double *G = out.g_pred ? out.g_pred : w.G;
+    const int64_t sG = out.g_pred ? out.sG : sw;
     ColProblem c2{}, c1{};
     c2.A = t->two_rdm;
     c2.w = w.w2;
+    c2.wstride = sw;
     c2.rows = t->rows2;
     c2.cols = t->cols2;
     c2.ld = t->ld2;
-    c2.out = is_packed(t->layout) ? w.vec2 : G;
+    if (is_packed(t->layout)) {
+        c2.out = w.vec2;
+        c2.ostride = sw;
+    } else {
+        c2.out = G;
+        c2.ostride = sG;
+    }
     c1.A = t->one_rdm;
     c1.w = w.w1;
+    c1.wstride = sw;
     c1.rows = (int64_t)t->ntrain * t->ntrain;
     c1.cols = (int64_t)n * n;
     c1.ld = t->ld1;
     c1.out = D;
+    c1.ostride = sD;
     const bool prof = g_prof.on && g_prof.n_cols < g_prof.cap;
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_cols + 2], st);
-    if ((rc = launch_gemv_cols(c2, c1, st))) return rc;
+    if ((rc = launch_gemv_cols(c2, c1, cnt, st))) return rc;
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_cols++ + 3], st);
     if (is_packed(t->layout))
-        if ((rc = launch_unpack(w.vec2, n, G, st))) return rc;
+        if ((rc = launch_unpack(w.vec2, sw, n, G, sG, cnt, st))) return rc;
     const bool partial = (flags & EVC_FLAG_PARTIAL_RANK) != 0;
-    return gradient_from_rdms(n, g, D, G, partial ? 0.0 : 1.0, !partial, out->grad, w, st);
+    return gradient_from_rdms(n, g, D, sD, G, sG, partial ? 0.0 : 1.0, !partial, out.grad, out.sg, w, st);
 }
 
 static int check_geometry(const evc_geometry *g, bool need_grad) {
@@ -270,6 +355,37 @@ static int check_geometry(const evc_geometry *g, bool need_grad) {
                     "geometry: ipovlp/dhcore/eri_ip1/aoslices are required for the gradient");
     }
     return 0;
+}
+
+static Geo geo_single(const evc_geometry *g) {
+    Geo o;
+    memset(&o, 0, sizeof(o));
+    o.natm = g->natm;
+    o.count = 1;
+    o.S = g->S;
+    o.hcore = g->hcore;
+    o.eri = g->eri;
+    o.ipovlp = g->ipovlp;
+    o.dhcore = g->dhcore;
+    o.eri_ip1 = g->eri_ip1;
+    o.gnuc = g->gnuc;
+    o.aoslices = g->aoslices;
+    o.enuc = g->enuc;
+    return o;
+}
+
+static Out out_single(const evc_outputs *o) {
+    Out r;
+    memset(&r, 0, sizeof(r));
+    if (o) {
+        r.energy = o->energy;
+        r.coeffs = o->coeffs;
+        r.grad = o->grad;
+        r.d_pred = o->d_pred;
+        r.g_pred = o->g_pred;
+        r.hmat = o->hmat;
+    }
+    return r;
 }
 
 }  // namespace evc
@@ -328,6 +444,13 @@ extern "C" size_t evc_workspace_bytes(const evc_trdm_set *t, int natm) {
     return w.bytes;
 }
 
+extern "C" size_t evc_workspace_bytes_batch(const evc_trdm_set *t, int natm, int count) {
+    if (check_set(t) || count < 1) return 0;
+    Ws w;
+    carve(t, natm, nullptr, w);
+    return w.bytes * (size_t)count;
+}
+
 #define EVC_SETUP(need_grad)                                                                      \
     if (check_set(t)) return -1;                                                                  \
     if (check_geometry(g, need_grad)) return -1;                                                  \
@@ -335,12 +458,13 @@ extern "C" size_t evc_workspace_bytes(const evc_trdm_set *t, int natm) {
     Ws w;                                                                                         \
     carve(t, g->natm, static_cast<char *>(ws), w);                                                \
     EVC_REQUIRE(ws_bytes >= w.bytes, "workspace too small: %zu < %zu", ws_bytes, w.bytes);        \
-    hipStream_t st = as_stream(stream)
+    hipStream_t st = as_stream(stream);                                                           \
+    const Geo geo = geo_single(g)
 
 extern "C" int evc_phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, void *ws, size_t ws_bytes,
                                      double **h2rows_local, double **h1rows, void *stream) {
     EVC_SETUP(false);
-    int rc = phase_hamiltonian(t, g, w, true, st);
+    int rc = phase_hamiltonian(t, geo, w, true, st);
     if (rc) return rc;
     if (h2rows_local) *h2rows_local = w.h2rows + t->row_offset;
     if (h1rows) *h1rows = w.h1part;
@@ -351,14 +475,14 @@ extern "C" int evc_phase_solve(const evc_trdm_set *t, const evc_geometry *g, con
                                const evc_outputs *out, int nroots, void *ws, size_t ws_bytes, void *stream) {
     EVC_SETUP(false);
     EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
-    return phase_solve(t, g, h2rows_all ? h2rows_all : w.h2rows, out, nroots, w, st);
+    return phase_solve(t, geo, h2rows_all ? h2rows_all : w.h2rows, out_single(out), nroots, w, st);
 }
 
 extern "C" int evc_phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
                                   int flags, void *ws, size_t ws_bytes, void *stream) {
     EVC_SETUP(true);
     EVC_REQUIRE(out && out->grad, "outputs.grad is required");
-    return phase_gradient(t, g, out, flags, w, st);
+    return phase_gradient(t, geo, out_single(out), flags, w, st);
 }
 
 extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
@@ -370,11 +494,77 @@ extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g
     EVC_REQUIRE(t->rows2 == t->rows2_total && t->row_offset == 0,
                 "evc_energy_with_grad needs the complete t-RDM on this device (use the phase calls when sharded)");
     EVC_REQUIRE(energy_only || out->grad, "outputs.grad is required unless EVC_FLAG_ENERGY_ONLY");
+    const Out o = out_single(out);
+    int rc;
+    if ((rc = phase_hamiltonian(t, geo, w, false, st))) return rc;
+    if ((rc = phase_solve(t, geo, nullptr, o, nroots, w, st))) return rc;
+    if (energy_only) return 0;
+    return phase_gradient(t, geo, o, flags & ~EVC_FLAG_PARTIAL_RANK, w, st);
+}
+
+extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
+                                          const evc_outputs_batch *ob, int nroots, int flags, void *ws,
+                                          size_t ws_bytes, void *stream) {
+    const bool energy_only = (flags & EVC_FLAG_ENERGY_ONLY) != 0;
+    if (check_set(t)) return -1;
+    EVC_REQUIRE(gb && ob, "evc_energy_with_grad_batch: null batch descriptor");
+    EVC_REQUIRE(gb->count >= 1 && gb->count <= 4096, "batch count=%d out of range", gb->count);
+    EVC_REQUIRE(gb->S && gb->hcore && gb->eri && gb->enuc, "batch geometry: S/hcore/eri/enuc must be given");
+    if (!energy_only) {
+        EVC_REQUIRE(gb->natm >= 1 && gb->ipovlp && gb->dhcore && gb->eri_ip1 && gb->aoslices && gb->gnuc,
+                    "batch geometry: ipovlp/dhcore/eri_ip1/gnuc/aoslices are required for the gradient");
+        EVC_REQUIRE(ob->grad, "batch outputs.grad is required unless EVC_FLAG_ENERGY_ONLY");
+    }
+    EVC_REQUIRE(ob->energy && ob->coeffs, "batch outputs.energy/coeffs are required");
+    EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
+    EVC_REQUIRE(t->rows2 == t->rows2_total && t->row_offset == 0,
+                "evc_energy_with_grad_batch needs the complete t-RDM on this device");
+    EVC_REQUIRE(ws && aligned16(ws), "workspace NULL or misaligned");
+    Ws w;
+    carve(t, gb->natm, static_cast<char *>(ws), w);
+    EVC_REQUIRE(ws_bytes >= w.bytes * (size_t)gb->count, "workspace too small: %zu < %zu", ws_bytes,
+                w.bytes * (size_t)gb->count);
+    hipStream_t st = as_stream(stream);
+    const int64_t n = t->n, n2 = n * n, n4 = n2 * n2, T = t->ntrain, A = gb->natm;
+    Geo g;
+    memset(&g, 0, sizeof(g));
+    g.natm = gb->natm;
+    g.count = gb->count;
+    g.S = gb->S;
+    g.sS = n2;
+    g.hcore = gb->hcore;
+    g.sh = n2;
+    g.eri = gb->eri;
+    g.seri = n4;
+    g.ipovlp = gb->ipovlp;
+    g.sip = 3 * n2;
+    g.dhcore = gb->dhcore;
+    g.sdh = A * 3 * n2;
+    g.eri_ip1 = gb->eri_ip1;
+    g.sip1 = 3 * n4;
+    g.gnuc = gb->gnuc;
+    g.sgn = A * 3;
+    g.aoslices = gb->aoslices;
+    g.enuc_dev = gb->enuc;
+    Out o;
+    memset(&o, 0, sizeof(o));
+    o.energy = ob->energy;
+    o.se = T;
+    o.coeffs = ob->coeffs;
+    o.sc = T * T;
+    o.grad = ob->grad;
+    o.sg = A * 3;
+    o.d_pred = ob->d_pred;
+    o.sd = n2;
+    o.g_pred = ob->g_pred;
+    o.sG = n4;
+    o.hmat = ob->hmat;
+    o.sH = T * T;
     int rc;
     if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
-    if ((rc = phase_solve(t, g, nullptr, out, nroots, w, st))) return rc;
+    if ((rc = phase_solve(t, g, nullptr, o, nroots, w, st))) return rc;
     if (energy_only) return 0;
-    return phase_gradient(t, g, out, flags & ~EVC_FLAG_PARTIAL_RANK, w, st);
+    return phase_gradient(t, g, o, 0, w, st);
 }
 
 extern "C" int evc_subspace_solve(const double *h1rows, const double *h2rows, const double *S_train, int T,
@@ -404,21 +594,24 @@ extern "C" int evc_subspace_solve(const double *h1rows, const double *h2rows, co
     a.Hout = Hout;
     a.w2_offset = 0;
     a.w2_count = is_pairs(layout) ? (int64_t)T * (T + 1) / 2 : (int64_t)T * T;
-    return launch_subspace_solve(a, as_stream(stream));
+    return launch_subspace_solve(a, 1, as_stream(stream));
 }
 
-extern "C" size_t evc_grad_elec_ws_bytes(int n, int natm) {
-    evc_trdm_set t;
+static void fake_set(evc_trdm_set &t, int n) {
     memset(&t, 0, sizeof(t));
     t.n = n;
     t.ntrain = 1;
     t.layout = EVC_LAYOUT_FULL6;
-    t.rows2 = 0;
     t.rows2_total = 1;
     t.cols2 = (int64_t)n * n * n * n;
     t.ld2 = t.cols2 + (t.cols2 & 1);
     t.ld1 = (int64_t)n * n + ((n * n) & 1);
+}
+
+extern "C" size_t evc_grad_elec_ws_bytes(int n, int natm) {
     if (n < 1 || n > 64) return 0;
+    evc_trdm_set t;
+    fake_set(t, n);
     Ws w;
     carve(&t, natm, nullptr, w);
     return w.bytes;
@@ -430,20 +623,22 @@ extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *tra
     if (check_geometry(g, true)) return -1;
     EVC_REQUIRE(one_rdm && two_rdm && grad && ws && aligned16(ws), "evc_grad_elec_oao: null/misaligned pointer");
     evc_trdm_set t;
-    memset(&t, 0, sizeof(t));
-    t.n = n;
-    t.ntrain = 1;
-    t.layout = EVC_LAYOUT_FULL6;
-    t.rows2_total = 1;
-    t.cols2 = (int64_t)n * n * n * n;
-    t.ld2 = t.cols2 + (t.cols2 & 1);
-    t.ld1 = (int64_t)n * n + ((n * n) & 1);
+    fake_set(t, n);
     Ws w;
     carve(&t, g->natm, static_cast<char *>(ws), w);
     EVC_REQUIRE(ws_bytes >= w.bytes, "evc_grad_elec_oao: workspace too small: %zu < %zu", ws_bytes, w.bytes);
     hipStream_t st = as_stream(stream);
+    const Geo geo = geo_single(g);
     int rc;
-    if ((rc = launch_loewdin(g->S, g->hcore, n, w.X, w.U, w.s, w.h1, st))) return rc;
+    LoewdinArgs la{};
+    la.S = g->S;
+    la.h = g->hcore;
+    la.X = w.X;
+    la.U = w.U;
+    la.s = w.s;
+    la.h1 = w.h1;
+    la.n = n;
+    if ((rc = launch_loewdin(la, 1, st))) return rc;
     if (trafo) {
         // caller-supplied ao_mo_trafo (gradients_loewdin.py:271-272); its derivative is still the
         // Loewdin response of g->S, exactly as the reference computes it when none is passed (:274-277)
@@ -453,8 +648,8 @@ extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *tra
             return (int)e;
         }
     }
-    if ((rc = launch_quarter_transform(g->eri, w.X, 0, n, w.B1, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B1, w.X, 0, n, w.B2, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B2, w.X, 0, n, w.K3, st))) return rc;
-    return gradient_from_rdms(n, g, one_rdm, two_rdm, 1.0, false, grad, w, st);
+    if ((rc = launch_quarter_transform(g->eri, 0, w.X, 0, 0, n, w.B1, 0, 1, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B1, 0, w.X, 0, 0, n, w.B2, 0, 1, st))) return rc;
+    if ((rc = launch_quarter_transform(w.B2, 0, w.X, 0, 0, n, w.K3, 0, 1, st))) return rc;
+    return gradient_from_rdms(n, geo, one_rdm, 0, two_rdm, 0, 1.0, false, grad, 0, w, st);
 }

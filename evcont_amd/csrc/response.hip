@@ -180,7 +180,13 @@ extern "C" int evc_loewdin_trafo_grad(const double *S, int n, double *LG, double
     EVC_REQUIRE(n >= 1 && n <= 64, "evc_loewdin_trafo_grad: n=%d out of range 1..64", n);
     hipStream_t st = as_stream(stream);
     double *X = ws, *U = X + n * n, *s = U + n * n;  // ws: 2 n^2 + n doubles
-    int rc = launch_loewdin(S, nullptr, n, X, U, s, nullptr, st);
+    LoewdinArgs la{};
+    la.S = S;
+    la.X = X;
+    la.U = U;
+    la.s = s;
+    la.n = n;
+    int rc = launch_loewdin(la, 1, st);
     if (rc) return rc;
     static bool a = false;
     big_lds(loewdin_trafo_grad_kernel, a);
@@ -195,7 +201,13 @@ extern "C" int evc_derivative_ao_mo_trafo(const double *S, const double *ipovlp,
     EVC_REQUIRE(n >= 1 && n <= 64 && natm >= 1, "evc_derivative_ao_mo_trafo: n=%d natm=%d out of range", n, natm);
     hipStream_t st = as_stream(stream);
     double *X = ws, *U = X + n * n, *s = U + n * n;
-    int rc = launch_loewdin(S, nullptr, n, X, U, s, nullptr, st);
+    LoewdinArgs la{};
+    la.S = S;
+    la.X = X;
+    la.U = U;
+    la.s = s;
+    la.n = n;
+    int rc = launch_loewdin(la, 1, st);
     if (rc) return rc;
     static bool a = false;
     big_lds(dx_tensor_kernel, a);
@@ -244,16 +256,30 @@ extern "C" int evc_two_el_grad(const double *h2_ao, const double *two_rdm, const
     double *B1 = static_cast<double *>(ws), *B2 = B1 + n4, *K3 = B2 + n4;
     double *y2part = K3 + n4, *y2 = y2part + (size_t)y2_slabs(n) * n2, *t2part = y2 + n2;
     int rc;
-    if ((rc = launch_quarter_transform(h2_ao, X, 0, n, B1, st))) return rc;
-    if ((rc = launch_quarter_transform(B1, X, 0, n, B2, st))) return rc;
-    if ((rc = launch_quarter_transform(B2, X, 0, n, K3, st))) return rc;
-    if ((rc = launch_sym_oao_t(two_rdm, n, B2, st))) return rc;
-    if ((rc = launch_y2(B2, K3, n, y2part, st))) return rc;
-    if ((rc = launch_quarter_transform(two_rdm, X, 1, n, B1, st))) return rc;
-    if ((rc = launch_quarter_transform(B1, X, 1, n, B2, st))) return rc;
-    if ((rc = launch_quarter_transform(B2, X, 1, n, B1, st))) return rc;
-    if ((rc = launch_quarter_transform(B1, X, 1, n, B2, st))) return rc;
-    if ((rc = launch_ip1_dh(ip1, B2, n, t2part, nullptr, nullptr, 0, nullptr, y2part, y2_slabs(n), y2, st))) return rc;
+    auto qt = [&](const double *src, int ct, double *dst) {
+        return launch_quarter_transform(src, 0, X, 0, ct, n, dst, 0, 1, st);
+    };
+    if ((rc = qt(h2_ao, 0, B1))) return rc;
+    if ((rc = qt(B1, 0, B2))) return rc;
+    if ((rc = qt(B2, 0, K3))) return rc;
+    if ((rc = launch_sym_oao_t(two_rdm, 0, n, B2, 0, 1, st))) return rc;
+    if ((rc = launch_y2(B2, K3, n, y2part, 0, 1, st))) return rc;
+    if ((rc = qt(two_rdm, 1, B1))) return rc;
+    if ((rc = qt(B1, 1, B2))) return rc;
+    if ((rc = qt(B2, 1, B1))) return rc;
+    if ((rc = qt(B1, 1, B2))) return rc;
+    Ip1Args ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.ip1 = ip1;
+    ia.Gao = B2;
+    ia.t2part = t2part;
+    ia.y2part = y2part;
+    ia.y2 = y2;
+    ia.n = n;
+    ia.natm = 0;
+    ia.nslab = y2_slabs(n);
+    ia.nchunk = ip1_chunks(n);
+    if ((rc = launch_ip1_dh(ia, 1, st))) return rc;
     // out[A,x] = sum_ai dX[a,i,A,x] y2[i][a] - sum_{m in A} t2[x,m]
     hipLaunchKernelGGL(contract_kernel, dim3(natm * 3), dim3(kT), 0, st, dX, (const double *)y2, 1, 1.0, n, natm,
                        (const double *)t2part, ip1_chunks(n), 1.0, aoslices, out);

@@ -4,6 +4,7 @@
 //   a4/a5   pack / unpack of the electron-exchange symmetry     electron_integral_utils.py:38-88
 //   K13     Gs^T symmetrisation + Y2 = K3 . Gs contraction      gradients_loewdin.py:210-222
 //   K15     int2e_ip1 diagonal contraction                      gradients_loewdin.py:234-252
+// blockIdx.y = geometry of the batch (kernels.hpp).
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -23,13 +24,32 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
 // MFMA roles: M <-> q (rotated index, C from LDS), N <-> row (16 tensor rows per wave step),
 // K <-> d.  Rows of `in` are n contiguous doubles, so the 16 rows a wave consumes form one
 // contiguous 16*n*8-byte block; the output is written as 128-byte row segments.
+// The first tile's operand loads are issued before the LDS fill of C so both latencies overlap.
 template <int NPAD>
-__global__ __launch_bounds__(256) void qt_kernel(const double *__restrict__ in, const double *__restrict__ C,
-                                                 int ct, int n, int64_t rows, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void qt_kernel(const double *__restrict__ in, int64_t sin,
+                                                 const double *__restrict__ C, int64_t sC, int ct, int n,
+                                                 int64_t rows, double *__restrict__ out, int64_t sout) {
     constexpr int LDX = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;  // keeps the two 16-lane halves on disjoint banks
     constexpr int KSTEPS = NPAD / 4;
     constexpr int NT = NPAD / 16;
     __shared__ double Xs[NPAD * LDX];
+    in += (int64_t)blockIdx.y * sin;
+    C += (int64_t)blockIdx.y * sC;
+    out += (int64_t)blockIdx.y * sout;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t ntiles = (rows + 15) / 16;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    double b[KSTEPS];
+    {
+        const int64_t row = tile * 16 + l15;
+        const bool rok = tile < ntiles && row < rows;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int d = 4 * kk + l4;
+            b[kk] = (rok && d < n) ? in[row * n + d] : 0.0;
+        }
+    }
     for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += 256) {
         const int d = idx / NPAD, q = idx % NPAD;
         double v = 0.0;
@@ -37,17 +57,19 @@ __global__ __launch_bounds__(256) void qt_kernel(const double *__restrict__ in, 
         Xs[d * LDX + q] = v;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int64_t ntiles = (rows + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    while (tile < ntiles) {
         const int64_t row = tile * 16 + l15;
         const bool rok = row < rows;
-        double b[KSTEPS];
+        const int64_t next = tile + (int64_t)gridDim.x * 4;
+        double bn[KSTEPS];
+        {
+            const int64_t nrow = next * 16 + l15;
+            const bool nok = next < ntiles && nrow < rows;
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            const int d = 4 * kk + l4;
-            b[kk] = (rok && d < n) ? in[row * n + d] : 0.0;
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int d = 4 * kk + l4;
+                bn[kk] = (nok && d < n) ? in[nrow * n + d] : 0.0;
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -63,29 +85,35 @@ __global__ __launch_bounds__(256) void qt_kernel(const double *__restrict__ in, 
                 }
             }
         }
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) b[kk] = bn[kk];
+        tile = next;
     }
 }
 
 template <int NPAD>
-static int qt_launch(const double *in, const double *C, int ct, int n, double *out, hipStream_t st) {
+static int qt_launch(const double *in, int64_t sin, const double *C, int64_t sC, int ct, int n, double *out,
+                     int64_t sout, int count, hipStream_t st) {
     const int64_t rows = (int64_t)n * n * n;
     const int64_t ntiles = (rows + 15) / 16;
     int64_t blocks = (ntiles + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(qt_kernel<NPAD>, dim3((unsigned)blocks), dim3(256), 0, st, in, C, ct, n, rows, out);
+    hipLaunchKernelGGL(qt_kernel<NPAD>, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, in, sin, C, sC, ct,
+                       n, rows, out, sout);
     EVC_LAUNCH_CHECK("quarter_transform");
     return 0;
 }
 
-int launch_quarter_transform(const double *in, const double *C, int ct, int n, double *out, hipStream_t st) {
+int launch_quarter_transform(const double *in, int64_t sin, const double *C, int64_t sC, int ct, int n, double *out,
+                             int64_t sout, int count, hipStream_t st) {
     const int npad = (n + 15) / 16 * 16;
     switch (npad) {
-        case 16: return qt_launch<16>(in, C, ct, n, out, st);
-        case 32: return qt_launch<32>(in, C, ct, n, out, st);
-        case 48: return qt_launch<48>(in, C, ct, n, out, st);
-        case 64: return qt_launch<64>(in, C, ct, n, out, st);
-        case 80: return qt_launch<80>(in, C, ct, n, out, st);
-        case 96: return qt_launch<96>(in, C, ct, n, out, st);
+        case 16: return qt_launch<16>(in, sin, C, sC, ct, n, out, sout, count, st);
+        case 32: return qt_launch<32>(in, sin, C, sC, ct, n, out, sout, count, st);
+        case 48: return qt_launch<48>(in, sin, C, sC, ct, n, out, sout, count, st);
+        case 64: return qt_launch<64>(in, sin, C, sC, ct, n, out, sout, count, st);
+        case 80: return qt_launch<80>(in, sin, C, sC, ct, n, out, sout, count, st);
+        case 96: return qt_launch<96>(in, sin, C, sC, ct, n, out, sout, count, st);
         default: break;
     }
     set_error("quarter_transform: n=%d not supported (1..96)", n);
@@ -93,9 +121,11 @@ int launch_quarter_transform(const double *in, const double *C, int ct, int n, d
 }
 
 // ------------------------------------------------------------------ pack / unpack
-__global__ void pack_kernel(const double *__restrict__ h2, int n, double mult, double *__restrict__ out,
-                            int64_t M, int64_t out_len) {
+__global__ void pack_kernel(const double *__restrict__ h2, int64_t sh2, int n, double mult, double *__restrict__ out,
+                            int64_t sout, int64_t M, int64_t out_len) {
     const int64_t n2 = (int64_t)n * n;
+    h2 += (int64_t)blockIdx.y * sh2;
+    out += (int64_t)blockIdx.y * sout;
     for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < out_len;
          m += (int64_t)gridDim.x * blockDim.x) {
         double v = 0.0;
@@ -108,8 +138,11 @@ __global__ void pack_kernel(const double *__restrict__ h2, int n, double mult, d
     }
 }
 
-__global__ void unpack_kernel(const double *__restrict__ p, int n, double *__restrict__ out) {
+__global__ void unpack_kernel(const double *__restrict__ p, int64_t sp, int n, double *__restrict__ out,
+                              int64_t sout) {
     const int64_t n2 = (int64_t)n * n, n4 = n2 * n2;
+    p += (int64_t)blockIdx.y * sp;
+    out += (int64_t)blockIdx.y * sout;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t R = idx / n2, Cc = idx - R * n2;
@@ -124,24 +157,29 @@ static unsigned grid_for(int64_t work, int block) {
     return (unsigned)g;
 }
 
-int launch_pack(const double *h2, int n, double mult, double *out, int64_t out_len, hipStream_t st) {
+int launch_pack(const double *h2, int64_t sh2, int n, double mult, double *out, int64_t sout, int64_t out_len,
+                int count, hipStream_t st) {
     const int64_t n2 = (int64_t)n * n, M = n2 * (n2 + 1) / 2;
-    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(out_len, 256)), dim3(256), 0, st, h2, n, mult, out, M, out_len);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(out_len, 256), (unsigned)count), dim3(256), 0, st, h2, sh2, n, mult,
+                       out, sout, M, out_len);
     EVC_LAUNCH_CHECK("pack_pair_sym");
     return 0;
 }
 
-int launch_unpack(const double *p, int n, double *out, hipStream_t st) {
+int launch_unpack(const double *p, int64_t sp, int n, double *out, int64_t sout, int count, hipStream_t st) {
     const int64_t n4 = (int64_t)n * n * n * n;
-    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, st, p, n, out);
+    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(n4, 256), (unsigned)count), dim3(256), 0, st, p, sp, n, out, sout);
     EVC_LAUNCH_CHECK("unpack_pair_sym");
     return 0;
 }
 
 // ------------------------------------------------------------------ OAO symmetrisation (transposed)
 // GsT[(j,k,l)][i] = G[i,j,k,l] + G[j,i,k,l] + G[l,k,j,i] + G[k,l,i,j]
-__global__ void sym_oao_t_kernel(const double *__restrict__ G, int n, double *__restrict__ out) {
+__global__ void sym_oao_t_kernel(const double *__restrict__ G, int64_t sG, int n, double *__restrict__ out,
+                                 int64_t sout) {
     const int64_t n2 = (int64_t)n * n, n3 = n2 * n, n4 = n2 * n2;
+    G += (int64_t)blockIdx.y * sG;
+    out += (int64_t)blockIdx.y * sout;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n4;
          o += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(o % n);
@@ -155,9 +193,10 @@ __global__ void sym_oao_t_kernel(const double *__restrict__ G, int n, double *__
     }
 }
 
-int launch_sym_oao_t(const double *G, int n, double *out, hipStream_t st) {
+int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t sout, int count, hipStream_t st) {
     const int64_t n4 = (int64_t)n * n * n * n;
-    hipLaunchKernelGGL(sym_oao_t_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, st, G, n, out);
+    hipLaunchKernelGGL(sym_oao_t_kernel, dim3(grid_for(n4, 256), (unsigned)count), dim3(256), 0, st, G, sG, n, out,
+                       sout);
     EVC_LAUNCH_CHECK("sym_oao_t");
     return 0;
 }
@@ -170,8 +209,11 @@ int y2_slabs(int) { return kY2Slabs; }
 
 template <int NT>
 __global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT, const double *__restrict__ K3,
-                                                 int n, int64_t ktot, double *__restrict__ partial) {
+                                                 int n, int64_t ktot, double *__restrict__ partial, int64_t sws) {
     __shared__ double red[4][NT * 16][NT * 16 + 1];
+    GsT += (int64_t)blockIdx.y * sws;
+    K3 += (int64_t)blockIdx.y * sws;
+    partial += (int64_t)blockIdx.y * sws;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t ksteps = (ktot + 3) / 4;
@@ -214,40 +256,42 @@ __global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT,
     }
 }
 
-int launch_y2(const double *GsT, const double *K3, int n, double *partial, hipStream_t st) {
+int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
     const int64_t ktot = (int64_t)n * n * n;
     const int nt = (n + 15) / 16;
+    const dim3 grid(kY2Slabs, (unsigned)count);
     switch (nt) {
-        case 1: hipLaunchKernelGGL(y2_kernel<1>, dim3(kY2Slabs), dim3(256), 0, st, GsT, K3, n, ktot, partial); break;
-        case 2: hipLaunchKernelGGL(y2_kernel<2>, dim3(kY2Slabs), dim3(256), 0, st, GsT, K3, n, ktot, partial); break;
-        case 3: hipLaunchKernelGGL(y2_kernel<3>, dim3(kY2Slabs), dim3(256), 0, st, GsT, K3, n, ktot, partial); break;
-        case 4: hipLaunchKernelGGL(y2_kernel<4>, dim3(kY2Slabs), dim3(256), 0, st, GsT, K3, n, ktot, partial); break;
+        case 1: hipLaunchKernelGGL(y2_kernel<1>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
+        case 2: hipLaunchKernelGGL(y2_kernel<2>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
+        case 3: hipLaunchKernelGGL(y2_kernel<3>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
+        case 4: hipLaunchKernelGGL(y2_kernel<4>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
         default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
     }
     EVC_LAUNCH_CHECK("y2");
     return 0;
 }
 
-// ------------------------------------------------------------------ ip1 contraction + dhcore dots
+// ------------------------------------------------------------------ ip1 contraction + dhcore dots + slab sums
 // t2part[(m*3+x)*nchunk + ch] = sum_{e in chunk ch} ip1[x][m][e] * GsAO[m][e],  e = (b,c,d)
 // GsAO[m,b,c,d] = G[m,b,c,d] + G[b,m,d,c] + G[c,d,m,b] + G[d,c,b,m]   (G = 2-RDM in the AO basis)
-// Extra blocks (blockIdx.x >= n*nchunk): term3[A*3+x] = sum_ab dhcore[A,x,a,b] * Pao[a,b].
+// Blocks [nb1, nb1 + 3A): term3[A*3+x] = sum_ab dhcore[A,x,a,b] * Pao[a,b].
+// Remaining blocks: y2[e] = sum_slab y2part[slab][e].
 constexpr int kIp1PerThread = 4;
 int ip1_chunks(int n) {
     const int64_t n3 = (int64_t)n * n * n;
     return (int)ceil_div(n3, 256 * kIp1PerThread);
 }
 
-__global__ __launch_bounds__(256) void ip1_dh_kernel(const double *__restrict__ ip1, const double *__restrict__ G,
-                                                     int n, int nchunk, double *__restrict__ t2part,
-                                                     const double *__restrict__ dh, const double *__restrict__ Pao,
-                                                     int natm, double *__restrict__ term3,
-                                                     const double *__restrict__ y2part, int nslab,
-                                                     double *__restrict__ y2) {
+__global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
     __shared__ double scr[3][4];
+    __shared__ double part[4][64];
+    const int n = a.n, nchunk = a.nchunk;
     const int64_t n2 = (int64_t)n * n, n3 = n2 * n, n4 = n2 * n2;
+    const int64_t g = blockIdx.y;
     const int nb1 = n * nchunk;
     if ((int)blockIdx.x < nb1) {
+        const double *__restrict__ ip1 = a.ip1 + g * a.sip1;
+        const double *__restrict__ G = a.Gao + g * a.sws;
         const int m = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         const int64_t e0 = (int64_t)ch * 256 * kIp1PerThread;
@@ -278,43 +322,42 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(const double *__restrict__ 
         __syncthreads();
         if (threadIdx.x < 3) {
             const int x = threadIdx.x;
-            t2part[((int64_t)m * 3 + x) * nchunk + ch] = (scr[x][0] + scr[x][1]) + (scr[x][2] + scr[x][3]);
+            a.t2part[g * a.sws + ((int64_t)m * 3 + x) * nchunk + ch] =
+                (scr[x][0] + scr[x][1]) + (scr[x][2] + scr[x][3]);
         }
-    } else if ((int)blockIdx.x < nb1 + natm * 3) {
+    } else if ((int)blockIdx.x < nb1 + a.natm * 3) {
         const int ax = blockIdx.x - nb1;  // A*3 + x
-        const double *p = dh + (int64_t)ax * n2;
+        const double *p = a.dh + g * a.sdh + (int64_t)ax * n2;
+        const double *Pao = a.Pao + g * a.sws;
         double s = 0.0;
         for (int64_t e = threadIdx.x; e < n2; e += 256) s = fma(p[e], Pao[e], s);
         s = block_sum<4>(s, &scr[0][0]);
-        if (threadIdx.x == 0) term3[ax] = s;
+        if (threadIdx.x == 0) a.term3[g * a.sws + ax] = s;
     } else {
-        // y2[e] = sum_slab y2part[slab][e]: 64 elements per block, 4 slab groups per element
-        const int b = blockIdx.x - nb1 - natm * 3;
+        // 64 elements per block, 4 slab groups per element
+        const int b = blockIdx.x - nb1 - a.natm * 3;
         const int e = b * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-        __shared__ double part[4][64];
+        const double *y2part = a.y2part + g * a.sws;
         double s0 = 0.0, s1 = 0.0;
         if (e < n2) {
             int sl = grp;
-            for (; sl + 4 < nslab; sl += 8) {
+            for (; sl + 4 < a.nslab; sl += 8) {
                 s0 += y2part[(int64_t)sl * n2 + e];
                 s1 += y2part[(int64_t)(sl + 4) * n2 + e];
             }
-            if (sl < nslab) s0 += y2part[(int64_t)sl * n2 + e];
+            if (sl < a.nslab) s0 += y2part[(int64_t)sl * n2 + e];
         }
         part[grp][threadIdx.x & 63] = s0 + s1;
         __syncthreads();
-        if (grp == 0 && e < n2) y2[e] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
-                                        (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (grp == 0 && e < n2)
+            a.y2[g * a.sws + e] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                                  (part[2][threadIdx.x] + part[3][threadIdx.x]);
     }
 }
 
-int launch_ip1_dh(const double *ip1, const double *Gao, int n, double *t2part, const double *dhcore,
-                  const double *Pao, int natm, double *term3, const double *y2part, int nslab, double *y2,
-                  hipStream_t st) {
-    const int nchunk = ip1_chunks(n);
-    const int blocks = n * nchunk + natm * 3 + (n * n + 63) / 64;
-    hipLaunchKernelGGL(ip1_dh_kernel, dim3(blocks), dim3(256), 0, st, ip1, Gao, n, nchunk, t2part, dhcore, Pao,
-                       natm, term3, y2part, nslab, y2);
+int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st) {
+    const int blocks = a.n * a.nchunk + a.natm * 3 + (a.n * a.n + 63) / 64;
+    hipLaunchKernelGGL(ip1_dh_kernel, dim3(blocks, (unsigned)count), dim3(256), 0, st, a);
     EVC_LAUNCH_CHECK("ip1_dh");
     return 0;
 }
@@ -329,7 +372,7 @@ extern "C" int evc_quarter_transform(const double *in, const double *C, int c_tr
     EVC_REQUIRE(in && C && out, "evc_quarter_transform: null pointer");
     EVC_REQUIRE(n >= 1 && n <= 96, "evc_quarter_transform: n=%d out of range 1..96", n);
     EVC_REQUIRE(in != out, "evc_quarter_transform: in and out must not alias");
-    return launch_quarter_transform(in, C, c_transposed, n, out, as_stream(stream));
+    return launch_quarter_transform(in, 0, C, 0, c_transposed, n, out, 0, 1, as_stream(stream));
 }
 
 extern "C" int evc_four_index_transform(const double *in, const double *C, int c_transposed, int n, double *out,
@@ -340,15 +383,18 @@ extern "C" int evc_four_index_transform(const double *in, const double *C, int c
                     three_quarter != in,
                 "evc_four_index_transform: buffers must not alias");
     hipStream_t st = as_stream(stream);
+    auto qt = [&](const double *src, double *dst) {
+        return launch_quarter_transform(src, 0, C, 0, c_transposed, n, dst, 0, 1, st);
+    };
     // in -> out -> tmp -> (three_quarter | out) -> out ; the third result must survive in
     // `three_quarter` when requested, otherwise ping-pong between out and tmp.
     int rc;
-    if ((rc = launch_quarter_transform(in, C, c_transposed, n, out, st))) return rc;
-    if ((rc = launch_quarter_transform(out, C, c_transposed, n, tmp, st))) return rc;
+    if ((rc = qt(in, out))) return rc;
+    if ((rc = qt(out, tmp))) return rc;
     double *third = three_quarter ? three_quarter : out;
-    if ((rc = launch_quarter_transform(tmp, C, c_transposed, n, third, st))) return rc;
-    if (three_quarter) return launch_quarter_transform(third, C, c_transposed, n, out, st);
-    if ((rc = launch_quarter_transform(third, C, c_transposed, n, tmp, st))) return rc;
+    if ((rc = qt(tmp, third))) return rc;
+    if (three_quarter) return qt(third, out);
+    if ((rc = qt(third, tmp))) return rc;
     // result sits in tmp: copy back (device-to-device, same stream)
     hipError_t e = hipMemcpyAsync(out, tmp, sizeof(double) * (size_t)n * n * n * n, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) {
@@ -364,11 +410,11 @@ extern "C" int evc_pack_pair_sym(const double *h2, int n, double diag_mult, doub
     EVC_REQUIRE(n >= 1 && n <= 215, "evc_pack_pair_sym: n=%d out of range", n);
     const int64_t n2 = (int64_t)n * n, M = n2 * (n2 + 1) / 2;
     EVC_REQUIRE(out_len >= M, "evc_pack_pair_sym: out_len=%lld < M=%lld", (long long)out_len, (long long)M);
-    return launch_pack(h2, n, diag_mult, out, out_len, as_stream(stream));
+    return launch_pack(h2, 0, n, diag_mult, out, 0, out_len, 1, as_stream(stream));
 }
 
 extern "C" int evc_unpack_pair_sym(const double *packed, int n, double *out, void *stream) {
     EVC_REQUIRE(packed && out, "evc_unpack_pair_sym: null pointer");
     EVC_REQUIRE(n >= 1 && n <= 215, "evc_unpack_pair_sym: n=%d out of range", n);
-    return launch_unpack(packed, n, out, as_stream(stream));
+    return launch_unpack(packed, 0, n, out, 0, 1, as_stream(stream));
 }

@@ -195,6 +195,101 @@ class DeviceAO:
                         gnuc=p(self.gnuc), aoslices=p(self.aoslices))
 
 
+@dataclass
+class DeviceAOBatch:
+    """AO integrals of ``count`` geometries of one molecule, stacked along a leading batch axis
+    (include/evcont_hip.h ``evc_geometry_batch``)."""
+    S: torch.Tensor          # (G,N,N)
+    hcore: torch.Tensor      # (G,N,N)
+    eri: torch.Tensor        # (G,N,N,N,N)
+    enuc: torch.Tensor       # (G,)
+    natm: int
+    ipovlp: Optional[torch.Tensor] = None    # (G,3,N,N)
+    dhcore: Optional[torch.Tensor] = None    # (G,A,3,N,N)
+    eri_ip1: Optional[torch.Tensor] = None   # (G,3,N,N,N,N)
+    gnuc: Optional[torch.Tensor] = None      # (G,A,3)
+    aoslices: Optional[torch.Tensor] = None  # (A,2) int64, shared
+
+    @property
+    def count(self) -> int:
+        return int(self.S.shape[0])
+
+    @property
+    def nao(self) -> int:
+        return int(self.S.shape[1])
+
+    @staticmethod
+    def stack(aos) -> "DeviceAOBatch":
+        """Stack single-geometry ``DeviceAO`` objects (device-to-device copies)."""
+        aos = list(aos)
+        d = aos[0].S.device
+        st = lambda name: (torch.stack([getattr(a, name) for a in aos]).contiguous()
+                           if getattr(aos[0], name) is not None else None)
+        return DeviceAOBatch(S=st("S"), hcore=st("hcore"), eri=st("eri"),
+                             enuc=torch.tensor([a.enuc for a in aos], dtype=F64, device=d), natm=aos[0].natm,
+                             ipovlp=st("ipovlp"), dhcore=st("dhcore"), eri_ip1=st("eri_ip1"), gnuc=st("gnuc"),
+                             aoslices=aos[0].aoslices)
+
+    @staticmethod
+    def from_arrays(ao_list, device=None, energy_only: bool = False) -> "DeviceAOBatch":
+        return DeviceAOBatch.stack([DeviceAO.from_arrays(a, device, energy_only) for a in ao_list])
+
+    def cstruct(self) -> "_lib.GeometryBatch":
+        p = lambda t: (t.data_ptr() if t is not None else None)
+        return _lib.GeometryBatch(natm=self.natm, count=self.count, enuc=p(self.enuc), S=p(self.S),
+                                  hcore=p(self.hcore), eri=p(self.eri), ipovlp=p(self.ipovlp), dhcore=p(self.dhcore),
+                                  eri_ip1=p(self.eri_ip1), gnuc=p(self.gnuc), aoslices=p(self.aoslices))
+
+
+class BatchedEvaluator:
+    """``count`` independent geometries per call (``evc_energy_with_grad_batch``): every launch covers
+    the whole batch and the t-RDM is streamed once per 8 geometries.  Results stay on the device in
+    ``energy (G,T)``, ``coeffs (G,T,T)``, ``grad (G,A,3)``."""
+
+    def __init__(self, trdms: DeviceTRDMs, natm: int, count: int, stream: Optional["torch.cuda.Stream"] = None,
+                 keep_density_matrices: bool = False):
+        self.t, self.natm, self.count, self.stream = trdms, int(natm), int(count), stream
+        self.lib = _lib.load()
+        d, n, T = trdms.device, trdms.n, trdms.T
+        nbytes = self.lib.evc_workspace_bytes_batch(C.byref(trdms.cstruct), self.natm, self.count)
+        if nbytes == 0:
+            raise _lib.EvcontHipError("evc_workspace_bytes_batch: " + self.lib.evc_last_error().decode())
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+        self.ws_bytes = nbytes
+        G = self.count
+        self.energy = torch.zeros((G, T), dtype=F64, device=d)
+        self.coeffs = torch.zeros((G, T, T), dtype=F64, device=d)
+        self.grad = torch.zeros((G, max(self.natm, 1), 3), dtype=F64, device=d)
+        self.d_pred = torch.zeros((G, n, n), dtype=F64, device=d) if keep_density_matrices else None
+        self.g_pred = torch.zeros((G, n, n, n, n), dtype=F64, device=d) if keep_density_matrices else None
+        p = lambda t: (t.data_ptr() if t is not None else None)
+        self.out = _lib.OutputsBatch(energy=p(self.energy), coeffs=p(self.coeffs), grad=p(self.grad),
+                                     d_pred=p(self.d_pred), g_pred=p(self.g_pred), hmat=None)
+
+    def _sp(self) -> int:
+        return self.stream.cuda_stream if self.stream is not None else _stream_ptr(self.t.device)
+
+    def synchronize(self) -> None:
+        (self.stream if self.stream is not None else torch.cuda.current_stream(self.t.device)).synchronize()
+
+    def enqueue(self, aob: DeviceAOBatch, nroots: int = 1, energy_only: bool = False) -> None:
+        assert aob.count == self.count, "batch size is fixed at construction"
+        g = aob.cstruct()
+        flags = _lib.FLAG_ENERGY_ONLY if energy_only else 0
+        rc = self.lib.evc_energy_with_grad_batch(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out), int(nroots),
+                                                 flags, self.ws.data_ptr(), self.ws_bytes, self._sp())
+        check(rc, "evc_energy_with_grad_batch")
+
+    def energies_with_grads(self, aob: DeviceAOBatch):
+        """(E[G], grad[G,A,3]) as numpy arrays."""
+        self.enqueue(aob)
+        self.synchronize()
+        e = self.energy[:, 0].cpu().numpy().copy()
+        if not np.all(np.isfinite(e)):
+            raise np.linalg.LinAlgError("generalised eigenproblem failed for at least one geometry of the batch")
+        return e, self.grad[:, : self.natm].cpu().numpy().copy()
+
+
 class ContinuationEvaluator:
     """Energy / energy+force of the continuation at one geometry per call
     (``get_energy_with_grad``, ``ab_initio_gradients_loewdin.py:308-379``)."""

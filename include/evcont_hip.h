@@ -179,6 +179,42 @@ int evc_phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_o
 int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
                          int nroots, int flags, void *ws, size_t ws_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------
+ * Batched form: `count` independent geometries of the SAME molecule (same N, A, aoslices) per call.
+ * Every launch of the pipeline covers the whole batch, and the two streaming kernels read the
+ * t-RDM ONCE for up to 8 geometries (K5 becomes (rows,cols)x(cols,G), K8 (G,rows)x(rows,cols)),
+ * so the HBM cost of the t-RDM per evaluation drops by the batch size.  This is the throughput
+ * form for PES scans / batched re-evaluations; an MD run is count = 1.
+ * All arrays are stacked along a leading batch axis, C order.
+ * --------------------------------------------------------------------------------- */
+typedef struct evc_geometry_batch {
+    int32_t natm;
+    int32_t count;
+    const double *enuc;      /* (count)           mol.energy_nuc() per geometry, DEVICE array */
+    const double *S;         /* (count,N,N) */
+    const double *hcore;     /* (count,N,N) */
+    const double *eri;       /* (count,N,N,N,N) */
+    const double *ipovlp;    /* (count,3,N,N)       (NULL: energy only) */
+    const double *dhcore;    /* (count,A,3,N,N)     (NULL: energy only) */
+    const double *eri_ip1;   /* (count,3,N,N,N,N)   (NULL: energy only) */
+    const double *gnuc;      /* (count,A,3)         (NULL: energy only) */
+    const int64_t *aoslices; /* (A,2) shared by the batch */
+} evc_geometry_batch;
+
+typedef struct evc_outputs_batch {
+    double *energy;  /* (count,T)    first nroots entries of each row are written */
+    double *coeffs;  /* (count,T,T)  first nroots rows of each block are written */
+    double *grad;    /* (count,A,3) or NULL with EVC_FLAG_ENERGY_ONLY */
+    double *d_pred;  /* (count,N,N) or NULL (kept in the workspace) */
+    double *g_pred;  /* (count,N,N,N,N) or NULL (kept in the workspace) */
+    double *hmat;    /* (count,T,T) or NULL */
+} evc_outputs_batch;
+
+size_t evc_workspace_bytes_batch(const evc_trdm_set *t, int natm, int count);
+int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
+                               const evc_outputs_batch *ob, int nroots, int flags, void *ws,
+                               size_t ws_bytes, void *stream);
+
 /* Gradient of given (not predicted) RDMs: get_grad_elec_OAO (ab_initio_gradients_loewdin.py:255-305).
  * `trafo` = caller's ao_mo_trafo (N,N) or NULL for the Loewdin trafo of g->S; the trafo derivative is
  * the Loewdin response of g->S in both cases (:274-277).  Writes the ELECTRONIC gradient (no grad_nuc)
