@@ -21,21 +21,26 @@ __device__ __forceinline__ double2 ld_stream(const double *p) {
 // Wave reduction of N (power of two <= 64) per-lane values with N-1 shuffles instead of 6N: at each
 // butterfly step a lane sends the half of its values it does not keep.  On return every lane holds
 // the wave-wide sum of value index lane >> (6 - log2 N).
+template <int N, int M, int OFF>
+__device__ __forceinline__ void multi_reduce_step(double (&v)[N], int lane) {
+    if constexpr (M > 1) {
+        const bool up = (lane & OFF) != 0;
+#pragma unroll
+        for (int i = 0; i < M / 2; ++i) {
+            const double send = up ? v[i] : v[i + M / 2];
+            const double keep = up ? v[i + M / 2] : v[i];
+            v[i] = keep + __shfl_xor(send, OFF, kWave);
+        }
+        multi_reduce_step<N, M / 2, OFF / 2>(v, lane);
+    } else if constexpr (OFF >= 1) {
+        v[0] += __shfl_xor(v[0], OFF, kWave);
+        multi_reduce_step<N, 1, OFF / 2>(v, lane);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ double multi_reduce(double (&v)[N], int lane) {
-    int off = 32;
-#pragma unroll
-    for (int m = N; m > 1; m >>= 1) {
-        const bool up = (lane & off) != 0;
-#pragma unroll
-        for (int i = 0; i < m / 2; ++i) {
-            const double send = up ? v[i] : v[i + m / 2];
-            const double keep = up ? v[i + m / 2] : v[i];
-            v[i] = keep + __shfl_xor(send, off, kWave);
-        }
-        off >>= 1;
-    }
-    for (; off >= 1; off >>= 1) v[0] += __shfl_xor(v[0], off, kWave);
+    multi_reduce_step<N, N, 32>(v, lane);
     return v[0];
 }
 
@@ -105,6 +110,92 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvRowsLaunch L, int g0
     }
 }
 
+// Batched variant for G >= 4.  With G vectors the lane-private form above re-reads the v tile once per
+// row block (G/RB times the bytes of A through L2 and the texture path) and its RB*G accumulators cut
+// the occupancy, i.e. the bytes in flight.  Here the roles are turned: the four waves of a workgroup
+// take DIFFERENT rows (RBW each) of the SAME column tile (SUB sub-steps of 128 columns), the v tile
+// (G x SUB*128 doubles) is staged once per workgroup in LDS, and every lane issues all RBW*SUB = 16
+// independent 16-byte loads of A for the tile before the staging barrier, so a wave keeps 16 KB of the
+// stream in flight with only RBW*G accumulators.  Each wave reduces its own rows (no cross-wave sum).
+constexpr int kStep = 128;  // columns per sub-step (64 lanes x 16 B)
+
+template <int RBW, int G, int SUB>
+__global__ __launch_bounds__(256, 3) void gemv_rows_wr_kernel(GemvRowsLaunch L, int g0) {
+    constexpr int NV = RBW * G;
+    constexpr int TILE = SUB * kStep;        // columns per iteration
+    constexpr int VPT = G * TILE / 256;      // doubles of the v tile each thread stages
+    static_assert(VPT % 2 == 0 && (TILE % VPT) == 0, "tile shape");
+    __shared__ __align__(16) double vt[G][TILE];
+    int bid = blockIdx.x;
+    const int which = bid >= L.nblk0 ? 1 : 0;
+    if (which) bid -= L.nblk0;
+    const RowProblem &P = L.p[which];
+    const int span = bid % P.nspans;
+    const int rg = bid / P.nspans;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rows = P.rows, cols = P.cols, ld = P.ld;
+    const int64_t row0 = (int64_t)rg * (4 * RBW) + wave * RBW;
+    const int64_t cbeg = (int64_t)span * P.cps * kChunk;
+    const int64_t cend = min(cols, (int64_t)(span + 1) * P.cps * kChunk);
+    const double *__restrict__ v = P.v + (int64_t)g0 * P.vstride;
+    const double *__restrict__ Ar[RBW];
+#pragma unroll
+    for (int r = 0; r < RBW; ++r) {
+        int64_t rr = row0 + r;
+        if (rr >= rows) rr = rows - 1;  // re-read a valid row, result discarded
+        Ar[r] = P.A + rr * ld;
+    }
+    // staging role of this thread inside the v tile: VPT consecutive doubles of one vector
+    const int sg = (tid * VPT) / TILE, sc = (tid * VPT) % TILE;
+    const double *vsrc = v + (int64_t)sg * P.vstride;
+
+    double acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+
+    for (int64_t c0 = cbeg; c0 < cend; c0 += TILE) {
+        double2 a[SUB][RBW];
+        const bool full = c0 + TILE <= cols;
+        if (full) {
+#pragma unroll
+            for (int u = 0; u < SUB; ++u)
+#pragma unroll
+                for (int r = 0; r < RBW; ++r) a[u][r] = ld_stream(Ar[r] + c0 + u * kStep + lane * 2);
+#pragma unroll
+            for (int k = 0; k < VPT; k += 2)
+                *reinterpret_cast<double2 *>(&vt[sg][sc + k]) = ld_stream(vsrc + c0 + sc + k);
+        } else {
+#pragma unroll
+            for (int u = 0; u < SUB; ++u) {
+                const int64_t c = c0 + u * kStep + lane * 2;
+#pragma unroll
+                for (int r = 0; r < RBW; ++r)
+                    a[u][r] = (c + 1 < cols) ? ld_stream(Ar[r] + c) : make_double2(c < cols ? Ar[r][c] : 0.0, 0.0);
+            }
+#pragma unroll
+            for (int k = 0; k < VPT; ++k) vt[sg][sc + k] = (c0 + sc + k < cols) ? vsrc[c0 + sc + k] : 0.0;
+        }
+        __syncthreads();  // v tile staged
+#pragma unroll
+        for (int u = 0; u < SUB; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const double2 vv = *reinterpret_cast<const double2 *>(&vt[g][u * kStep + lane * 2]);
+#pragma unroll
+                for (int r = 0; r < RBW; ++r)
+                    acc[r * G + g] = fma(a[u][r].y, vv.y, fma(a[u][r].x, vv.x, acc[r * G + g]));
+            }
+        __syncthreads();  // everyone done with the tile before it is overwritten
+    }
+    const double s = multi_reduce<NV>(acc, lane);
+    constexpr int kShift = (NV >= 64) ? 0 : (NV == 32 ? 1 : NV == 16 ? 2 : 3);
+    if ((lane & ((1 << kShift) - 1)) == 0) {
+        const int idx = lane >> kShift, r = idx / G, g = idx - r * G;
+        if (idx < NV && row0 + r < rows)
+            P.partial[(int64_t)(g0 + g) * P.pstride + (int64_t)span * rows + row0 + r] = s;
+    }
+}
+
 // y[r] = alpha * sum_span partial[span][r]
 __global__ void gemv_rows_reduce_kernel(const double *partial, int64_t rows, int nspans, double alpha,
                                         double *y) {
@@ -154,25 +245,34 @@ static void rows_launch(GemvRowsLaunch L, int g0, hipStream_t st) {
     hipLaunchKernelGGL((gemv_rows_kernel<RB, G>), dim3(L.p[0].nblocks + L.p[1].nblocks), dim3(256), 0, st, L, g0);
 }
 
+template <int RBW, int G>
+static void rows_wr_launch(GemvRowsLaunch L, int g0, hipStream_t st) {
+    for (int k = 0; k < 2; ++k)
+        L.p[k].nblocks = L.p[k].nblocks ? (int)(ceil_div(L.p[k].rows, 4 * RBW) * L.p[k].nspans) : 0;
+    L.nblk0 = L.p[0].nblocks;
+    hipLaunchKernelGGL((gemv_rows_wr_kernel<RBW, G, 16 / RBW>), dim3(L.p[0].nblocks + L.p[1].nblocks), dim3(256), 0, st,
+                       L, g0);
+}
+
 int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     GemvRowsLaunch L;
     L.p[0] = p0;
     L.p[1] = p1;
     L.nblk0 = p0.nblocks;
     if (p0.nblocks + p1.nblocks == 0 || count <= 0) return 0;
-    static const int rb8 = env_int("EVC_ROWS_RB_G8", 4);
-    static const int rb4 = env_int("EVC_ROWS_RB_G4", 8);
+    static const int v8 = env_int("EVC_ROWS_G8", 0);   // 0: wave-rows kernel RBW=4; 1: lane-private RB=2
+    static const int v4 = env_int("EVC_ROWS_G4", 0);   // 0: wave-rows RBW=8; 1: wave-rows RBW=4; 2: lane-private RB=4
     int g0 = 0;
     while (g0 < count) {
         const int left = count - g0;
         if (left >= 8) {
-            if (rb8 == 8) rows_launch<8, 8>(L, g0, st);
-            else if (rb8 == 2) rows_launch<2, 8>(L, g0, st);
-            else rows_launch<4, 8>(L, g0, st);
+            if (v8 == 1) rows_launch<2, 8>(L, g0, st);
+            else rows_wr_launch<4, 8>(L, g0, st);
             g0 += 8;
         } else if (left >= 4) {
-            if (rb4 == 4) rows_launch<4, 4>(L, g0, st);
-            else rows_launch<8, 4>(L, g0, st);
+            if (v4 == 2) rows_launch<4, 4>(L, g0, st);
+            else if (v4 == 1) rows_wr_launch<4, 4>(L, g0, st);
+            else rows_wr_launch<8, 4>(L, g0, st);
             g0 += 4;
         } else if (left >= 2) {
             rows_launch<8, 2>(L, g0, st);
