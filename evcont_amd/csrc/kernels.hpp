@@ -47,6 +47,13 @@ int launch_pack(const double *h2, int64_t sh2, int n, double diag_mult, double *
 int launch_unpack(const double *packed, int64_t sp, int n, double *out, int64_t sout, int count, hipStream_t st);
 // Gs^T[jkl][i] = G[i,j,k,l] + G[j,i,k,l] + G[l,k,j,i] + G[k,l,i,j]   (gradients_loewdin.py:213-215)
 int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t sout, int count, hipStream_t st);
+// Packed fast path: from the packed predicted 2-RDM p (pair symmetric by construction) write in one pass
+//   GsT[jkl][i] = 2 p(ij,kl) + p(ji,kl) + p(ji,lk)        (= the OAO symmetrisation above, transposed)
+//   SB[i,j,k,l] = 2 (p(ij,kl) + p(ji,lk))                  (= AO-type symmetrisation, gradients_loewdin.py:238-240,
+//                                                             applied BEFORE the OAO->AO rotation, with which it commutes)
+//   G[i,j,k,l]  = p(ij,kl)                                 (optional: the unpacked 2-RDM, eiu:69-88)
+int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
+                      int64_t sG, int count, hipStream_t st);
 // partial[b][i][a] = sum_{k in slab b} GsT[k][i] * K3[k][a]   (k = jkl)
 int y2_slabs(int n);
 int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);
@@ -64,6 +71,7 @@ struct Ip1Args {
     double *y2;            // (n,n)        + g*sws
     int64_t sip1, sdh, sws;
     int n, natm, nslab, nchunk;
+    int presym;            // Gao already carries the 4-fold AO symmetrisation (packed fast path)
 };
 int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st);
 

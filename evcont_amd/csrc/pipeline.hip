@@ -243,18 +243,33 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
 
 // Gradient of the energy functional defined by (D, G) [G unpacked, N^4] given X,U,s,K3 in the
 // workspace.  scale1 = 0 drops everything that is not linear in G (multi-GPU partial ranks).
-static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, const double *G, int64_t sG,
-                              double scale1, bool add_gnuc, double *grad, int64_t sgrad, Ws &w, hipStream_t st) {
+// `packed` != NULL selects the fast path for pair-symmetric (packed) predicted 2-RDMs: both symmetrisations
+// are taken straight from the packed vector (G is then only written when the caller wants it, G may be NULL).
+static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, double *G, int64_t sG,
+                              const double *packed, int64_t spacked, double scale1, bool add_gnuc, double *grad,
+                              int64_t sgrad, Ws &w, hipStream_t st) {
     const int cnt = g.count;
     const int64_t sw = w.stride;
     int rc;
-    if ((rc = launch_sym_oao_t(G, sG, n, w.B2, sw, cnt, st))) return rc;
-    if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, sw, cnt, st))) return rc;
-    // G^AO = (X x X x X x X) G, contraction over the SECOND index of X (gradients_loewdin.py:224-232)
-    if ((rc = launch_quarter_transform(G, sG, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
+    double *gao;  // symmetrised or plain 2-RDM in the AO basis
+    if (packed) {
+        if ((rc = launch_unpack_sym(packed, spacked, n, w.B2, w.B1, sw, G, sG, cnt, st))) return rc;
+        if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
+        gao = w.B1;
+    } else {
+        if ((rc = launch_sym_oao_t(G, sG, n, w.B2, sw, cnt, st))) return rc;
+        if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, sw, cnt, st))) return rc;
+        // G^AO = (X x X x X x X) G, contraction over the SECOND index of X (gradients_loewdin.py:224-232)
+        if ((rc = launch_quarter_transform(G, sG, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
+        gao = w.B2;
+    }
     GradPrepArgs p;
     p.n = n;
     p.X = w.X;
@@ -269,7 +284,8 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
     if ((rc = launch_grad_prep(p, cnt, st))) return rc;
     Ip1Args ia;
     ia.ip1 = g.eri_ip1;
-    ia.Gao = w.B2;
+    ia.Gao = gao;
+    ia.presym = packed ? 1 : 0;
     ia.t2part = w.t2part;
     ia.dh = g.dhcore;
     ia.Pao = w.Pao;
@@ -340,10 +356,13 @@ static int phase_gradient(const evc_trdm_set *t, const Geo &g, const Out &out, i
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_cols + 2], st);
     if ((rc = launch_gemv_cols(c2, c1, cnt, st))) return rc;
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_cols++ + 3], st);
-    if (is_packed(t->layout))
-        if ((rc = launch_unpack(w.vec2, sw, n, G, sG, cnt, st))) return rc;
     const bool partial = (flags & EVC_FLAG_PARTIAL_RANK) != 0;
-    return gradient_from_rdms(n, g, D, sD, G, sG, partial ? 0.0 : 1.0, !partial, out.grad, out.sg, w, st);
+    if (is_packed(t->layout))
+        // the unpacked 2-RDM is only materialised when the caller asked for it
+        return gradient_from_rdms(n, g, D, sD, out.g_pred, out.sG, w.vec2, sw, partial ? 0.0 : 1.0, !partial,
+                                  out.grad, out.sg, w, st);
+    return gradient_from_rdms(n, g, D, sD, G, sG, nullptr, 0, partial ? 0.0 : 1.0, !partial, out.grad, out.sg, w,
+                              st);
 }
 
 static int check_geometry(const evc_geometry *g, bool need_grad) {
@@ -651,5 +670,6 @@ extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *tra
     if ((rc = launch_quarter_transform(g->eri, 0, w.X, 0, 0, n, w.B1, 0, 1, st))) return rc;
     if ((rc = launch_quarter_transform(w.B1, 0, w.X, 0, 0, n, w.B2, 0, 1, st))) return rc;
     if ((rc = launch_quarter_transform(w.B2, 0, w.X, 0, 0, n, w.K3, 0, 1, st))) return rc;
-    return gradient_from_rdms(n, geo, one_rdm, 0, two_rdm, 0, 1.0, false, grad, 0, w, st);
+    return gradient_from_rdms(n, geo, one_rdm, 0, const_cast<double *>(two_rdm), 0, nullptr, 0, 1.0, false, grad, 0,
+                              w, st);
 }

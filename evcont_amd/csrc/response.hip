@@ -277,6 +277,7 @@ extern "C" int evc_two_el_grad(const double *h2_ao, const double *two_rdm, const
     ia.y2 = y2;
     ia.n = n;
     ia.natm = 0;
+    ia.presym = 0;
     ia.nslab = y2_slabs(n);
     ia.nchunk = ip1_chunks(n);
     if ((rc = launch_ip1_dh(ia, 1, st))) return rc;

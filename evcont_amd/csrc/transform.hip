@@ -201,6 +201,46 @@ int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t so
     return 0;
 }
 
+// ------------------------------------------------------------------ packed fast path: unpack + both symmetrisations
+// One workgroup per (j,k); its n*n elements (i,l) are produced with l fastest (coalesced SB/G rows),
+// staged in LDS and written to GsT with i fastest ((j,k) fixes a contiguous n*n block of GsT).
+__global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restrict__ p, int64_t sp, int n,
+                                                         double *__restrict__ GsT, double *__restrict__ SB,
+                                                         int64_t sws, double *__restrict__ Gout, int64_t sG) {
+    extern __shared__ __align__(16) double tile[];  // [l][i], row length n+1
+    const int64_t n2 = (int64_t)n * n, n3 = n2 * n;
+    p += (int64_t)blockIdx.y * sp;
+    GsT += (int64_t)blockIdx.y * sws;
+    SB += (int64_t)blockIdx.y * sws;
+    if (Gout) Gout += (int64_t)blockIdx.y * sG;
+    const int j = blockIdx.x / n, k = blockIdx.x - j * n;
+    auto P = [&](int64_t a, int64_t b) { return a >= b ? p[tri_index(a, b)] : p[tri_index(b, a)]; };
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, l = idx - i * n;
+        const int64_t R = (int64_t)i * n + j, Rt = (int64_t)j * n + i, Cc = (int64_t)k * n + l, Ct = (int64_t)l * n + k;
+        const double p1 = P(R, Cc), p2 = P(Rt, Cc), p3 = P(Rt, Ct);
+        const int64_t o = i * n3 + j * n2 + k * n + l;
+        SB[o] = 2.0 * (p1 + p3);
+        if (Gout) Gout[o] = p1;
+        tile[l * (n + 1) + i] = 2.0 * p1 + p2 + p3;
+    }
+    __syncthreads();
+    double *dst = GsT + ((int64_t)j * n + k) * n2;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int l = idx / n, i = idx - l * n;
+        dst[idx] = tile[l * (n + 1) + i];
+    }
+}
+
+int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
+                      int64_t sG, int count, hipStream_t st) {
+    const size_t lds = sizeof(double) * (size_t)n * (n + 1);
+    hipLaunchKernelGGL(unpack_sym_kernel, dim3(n * n, (unsigned)count), dim3(256), lds, st, packed, sp, n, GsT, SB,
+                       sws, G, sG);
+    EVC_LAUNCH_CHECK("unpack_sym");
+    return 0;
+}
+
 // ------------------------------------------------------------------ Y2 contraction (split-K MFMA GEMM)
 // partial[slab][i][a] = sum_{k in slab} GsT[k][i] * K3[k][a],  k = (j,k,l) flattened, n^3 long.
 // Both operands are [k][n] row-major, so each MFMA fragment load is 16 contiguous doubles.
@@ -295,6 +335,23 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
         const int m = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         const int64_t e0 = (int64_t)ch * 256 * kIp1PerThread;
+        if (a.presym && (n3 & 1) == 0) {
+            // symmetrised operand: a plain streaming dot, 16-byte loads
+#pragma unroll
+            for (int u = 0; u < kIp1PerThread / 2; ++u) {
+                const int64_t e = e0 + ((int64_t)u * 256 + threadIdx.x) * 2;
+                if (e < n3) {
+                    const int64_t off = m * n3 + e;
+                    const double2 gs = *reinterpret_cast<const double2 *>(G + off);
+                    const double2 p0 = *reinterpret_cast<const double2 *>(ip1 + off);
+                    const double2 p1 = *reinterpret_cast<const double2 *>(ip1 + n4 + off);
+                    const double2 p2 = *reinterpret_cast<const double2 *>(ip1 + 2 * n4 + off);
+                    a0 = fma(p0.y, gs.y, fma(p0.x, gs.x, a0));
+                    a1 = fma(p1.y, gs.y, fma(p1.x, gs.x, a1));
+                    a2 = fma(p2.y, gs.y, fma(p2.x, gs.x, a2));
+                }
+            }
+        } else
 #pragma unroll
         for (int u = 0; u < kIp1PerThread; ++u) {
             const int64_t e = e0 + u * 256 + threadIdx.x;
@@ -302,8 +359,9 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
                 const int d = (int)(e % n);
                 const int c = (int)((e / n) % n);
                 const int b = (int)(e / n2);
-                const double gs = G[m * n3 + e] + G[b * n3 + m * n2 + d * n + c] +
-                                  G[c * n3 + d * n2 + m * n + b] + G[d * n3 + c * n2 + b * n + m];
+                const double gs = a.presym ? G[m * n3 + e]
+                                           : G[m * n3 + e] + G[b * n3 + m * n2 + d * n + c] +
+                                                 G[c * n3 + d * n2 + m * n + b] + G[d * n3 + c * n2 + b * n + m];
                 const int64_t off = m * n3 + e;
                 a0 = fma(ip1[off], gs, a0);
                 a1 = fma(ip1[n4 + off], gs, a1);

@@ -153,7 +153,8 @@ typedef struct evc_outputs {
     double *coeffs;  /* [nroots*T] */
     double *grad;    /* [A*3] or NULL */
     double *d_pred;  /* [N*N]  predicted 1-RDM (always written by the gradient phase) */
-    double *g_pred;  /* [N^4]  predicted 2-RDM, unpacked (always written by the gradient phase) */
+    double *g_pred;  /* [N^4]  predicted 2-RDM, unpacked; may be NULL (for the packed layouts the gradient
+                        phase then never materialises it) */
     double *hmat;    /* [T*T] or NULL: matrix handed to the eigensolver */
 } evc_outputs;
 
