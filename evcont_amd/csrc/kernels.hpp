@@ -42,6 +42,19 @@ int launch_gemv_cols(ColProblem p0, ColProblem p1, int count, hipStream_t st);
 // ---- transform.hip -----------------------------------------------------------------
 int launch_quarter_transform(const double *in, int64_t sin, const double *C, int64_t sC, int c_transposed, int n,
                              double *out, int64_t sout, int count, hipStream_t st);
+// Two quarter steps fused (n <= 32): out[r'][s'][p][q] = sum_rs in[p][q][r][s] C[r][r'] C[s][s'].
+struct PairTransformArgs {
+    const double *in;   // (n^4)   + g*sin
+    const double *C;    // (n,n)   + g*sC
+    double *out;        // (n^4) full result or NULL                          + g*sout
+    double *packed;     // packed lower triangle (diag * diag_mult) or NULL   + g*spacked
+    double *k3;         // half result K3[s'][p][q][r] = sum_s in[p][q][r][s] C[s][s'] or NULL  + g*sk3
+    int64_t sin, sC, sout, spacked, sk3, packed_len;
+    double diag_mult;
+    int ct, n;
+};
+constexpr int kPairTransformMaxN = 32;
+int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);
 int launch_pack(const double *h2, int64_t sh2, int n, double diag_mult, double *out, int64_t sout, int64_t out_len,
                 int count, hipStream_t st);
 int launch_unpack(const double *packed, int64_t sp, int n, double *out, int64_t sout, int count, hipStream_t st);

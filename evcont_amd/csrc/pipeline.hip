@@ -5,6 +5,7 @@
 //     blockIdx.y / blockIdx.x) and share ONE pass over the t-RDM in the two streaming kernels;
 //   * PHASES: split in three so a pair-sharded multi-GPU host can put its two small collectives
 //     (all-gather of the H rows, all-reduce of the gradient) between them.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.hpp"
@@ -60,6 +61,13 @@ struct Ws {
     int64_t stride;  // the same in doubles
     RowProblem rp2, rp1;
 };
+
+// n <= 32: the four-index rotations run as two fused pair steps (transform.hip pt_kernel); larger n
+// (or EVC_NO_PAIR_TRANSFORM=1, for A/B timing) as four quarter steps.
+static bool use_pair_transform(int n) {
+    static const bool off = getenv("EVC_NO_PAIR_TRANSFORM") != nullptr;
+    return !off && n <= kPairTransformMaxN;
+}
 
 static bool is_packed(int layout) { return layout == EVC_LAYOUT_ELEC3 || layout == EVC_LAYOUT_PACK2; }
 static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout == EVC_LAYOUT_PACK2; }
@@ -159,14 +167,46 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
     la.n = n;
     if ((rc = launch_loewdin(la, cnt, st))) return rc;
     // (ab|cd) -> K3[jkl][a] -> h2[ijkl]
-    if ((rc = launch_quarter_transform(g.eri, g.seri, w.X, sw, 0, n, w.B1, sw, cnt, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 0, n, w.B2, sw, cnt, st))) return rc;
-    if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 0, n, w.K3, sw, cnt, st))) return rc;
-    if ((rc = launch_quarter_transform(w.K3, sw, w.X, sw, 0, n, w.B1, sw, cnt, st))) return rc;
-    const double *v2 = w.B1;
-    if (is_packed(t->layout)) {
-        if ((rc = launch_pack(w.B1, sw, n, 0.5, w.vec2, sw, t->ld2, cnt, st))) return rc;
-        v2 = w.vec2;
+    const double *v2;
+    if (use_pair_transform(n)) {
+        // two fused pair steps; the second one emits K3 and writes h2 straight into the form the
+        // streaming kernel consumes (packed with diag x 1/2, or full)
+        PairTransformArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.in = g.eri;
+        pa.sin = g.seri;
+        pa.C = w.X;
+        pa.sC = sw;
+        pa.n = n;
+        pa.out = w.B1;
+        pa.sout = sw;
+        if ((rc = launch_pair_transform(pa, cnt, st))) return rc;
+        pa.in = w.B1;
+        pa.sin = sw;
+        pa.k3 = w.K3;
+        pa.sk3 = sw;
+        if (is_packed(t->layout)) {
+            pa.out = nullptr;
+            pa.packed = w.vec2;
+            pa.spacked = sw;
+            pa.packed_len = t->ld2;
+            pa.diag_mult = 0.5;
+            v2 = w.vec2;
+        } else {
+            pa.out = w.B2;
+            v2 = w.B2;
+        }
+        if ((rc = launch_pair_transform(pa, cnt, st))) return rc;
+    } else {
+        if ((rc = launch_quarter_transform(g.eri, g.seri, w.X, sw, 0, n, w.B1, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 0, n, w.B2, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 0, n, w.K3, sw, cnt, st))) return rc;
+        if ((rc = launch_quarter_transform(w.K3, sw, w.X, sw, 0, n, w.B1, sw, cnt, st))) return rc;
+        v2 = w.B1;
+        if (is_packed(t->layout)) {
+            if ((rc = launch_pack(w.B1, sw, n, 0.5, w.vec2, sw, t->ld2, cnt, st))) return rc;
+            v2 = w.vec2;
+        }
     }
     RowProblem p2 = w.rp2, p1 = w.rp1;
     p2.A = t->two_rdm;
@@ -252,23 +292,67 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
     const int64_t sw = w.stride;
     int rc;
     double *gao;  // symmetrised or plain 2-RDM in the AO basis
+    // G^AO = (X x X x X x X) G, contraction over the SECOND index of X (gradients_loewdin.py:224-232):
+    // src -> ... -> dst, through `other`, as two fused pair steps (n <= 32) or four quarter steps
+    auto rotate_to_ao = [&](const double *src, int64_t ssrc, double *other, double *dst) -> int {
+        int r;
+        if (use_pair_transform(n)) {
+            PairTransformArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.C = w.X;
+            pa.sC = sw;
+            pa.ct = 1;
+            pa.n = n;
+            pa.in = src;
+            pa.sin = ssrc;
+            pa.out = other;
+            pa.sout = sw;
+            if ((r = launch_pair_transform(pa, cnt, st))) return r;
+            pa.in = other;
+            pa.sin = sw;
+            pa.out = dst;
+            return launch_pair_transform(pa, cnt, st);
+        }
+        if ((r = launch_quarter_transform(src, ssrc, w.X, sw, 1, n, dst, sw, cnt, st))) return r;
+        if ((r = launch_quarter_transform(dst, sw, w.X, sw, 1, n, other, sw, cnt, st))) return r;
+        if ((r = launch_quarter_transform(other, sw, w.X, sw, 1, n, dst, sw, cnt, st))) return r;
+        if ((r = launch_quarter_transform(dst, sw, w.X, sw, 1, n, other, sw, cnt, st))) return r;
+        // result sits in `other`: one more hop would cost a launch, so report where it is
+        return 1 << 30;
+    };
     if (packed) {
         if ((rc = launch_unpack_sym(packed, spacked, n, w.B2, w.B1, sw, G, sG, cnt, st))) return rc;
         if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, sw, cnt, st))) return rc;
-        if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
-        if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
-        if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
-        if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
+        if (use_pair_transform(n)) {
+            // B1 (symmetrised, OAO) -> B2 -> B1
+            PairTransformArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.C = w.X;
+            pa.sC = sw;
+            pa.ct = 1;
+            pa.n = n;
+            pa.in = w.B1;
+            pa.sin = sw;
+            pa.out = w.B2;
+            pa.sout = sw;
+            if ((rc = launch_pair_transform(pa, cnt, st))) return rc;
+            pa.in = w.B2;
+            pa.out = w.B1;
+            if ((rc = launch_pair_transform(pa, cnt, st))) return rc;
+        } else {
+            if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
+            if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
+            if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
+            if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
+        }
         gao = w.B1;
     } else {
         if ((rc = launch_sym_oao_t(G, sG, n, w.B2, sw, cnt, st))) return rc;
         if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, sw, cnt, st))) return rc;
-        // G^AO = (X x X x X x X) G, contraction over the SECOND index of X (gradients_loewdin.py:224-232)
-        if ((rc = launch_quarter_transform(G, sG, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
-        if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
-        if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
-        if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
-        gao = w.B2;
+        rc = rotate_to_ao(G, sG, w.B1, w.B2);
+        if (rc == (1 << 30)) gao = w.B1;       // quarter-step route ends in `other`
+        else if (rc) return rc;
+        else gao = w.B2;
     }
     GradPrepArgs p;
     p.n = n;

@@ -120,6 +120,168 @@ int launch_quarter_transform(const double *in, int64_t sin, const double *C, int
     return -1;
 }
 
+// ------------------------------------------------------------------ fused pair transform (two quarter steps)
+// For every leading index pair (p,q) the n x n block M = in[p][q][:,:] is rotated on both sides,
+//     H = M X            (half result, optionally stored as K3[s'][p][q][r] = H[r][s'])
+//     N = X^T H          stored as out[r'][s'][p][q]  (= two quarter steps of the rotation scheme)
+// or, for the final step of the AO->OAO integral rotation, directly into the packed lower triangle
+// (row (r',s') >= column (p,q), diagonal x diag_mult; electron_integral_utils.py:38-66).
+// One wave per matrix: the D tiles of H = M X sit in exactly the lanes/registers the B operand of
+// X^T H needs (row 4*kk + (l>>4) of H lives in register kk%4 of row-tile kk/4), so the second product
+// consumes the accumulators of the first without any data movement; the X fragments serve as B
+// operand of the first and A operand of the second product.  A workgroup owns 8 consecutive q
+// (2 matrices per wave) and stages N in LDS so that the output leaves as 64-byte runs over q.
+template <int NPAD>
+__global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
+    constexpr int LDX = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;
+    constexpr int KS = NPAD / 4;
+    constexpr int NT = NPAD / 16;
+    constexpr int QT = 8, QP = QT + 1;
+    extern __shared__ __align__(16) double sm[];
+    double *Xs = sm;                  // NPAD * LDX
+    double *stage = Xs + NPAD * LDX;  // n*n*QP
+    const int n = a.n;
+    const int64_t n2 = (int64_t)n * n, n3 = n2 * n;
+    const int64_t g = blockIdx.y;
+    const double *__restrict__ in = a.in + g * a.sin;
+    const double *__restrict__ C = a.C + g * a.sC;
+    const int ntq = (n + QT - 1) / QT;
+    const int p = blockIdx.x / ntq, q0 = (blockIdx.x - p * ntq) * QT;
+    const int nq = min(QT, n - q0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // first matrix of this wave: operand loads issued before the LDS fill of X
+    double mf[NT][KS];
+    {
+        const bool ok = wave < nq;
+        const double *Mb = in + ((int64_t)p * n + q0 + wave) * n2;
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int r = rt * 16 + l15, s = 4 * kk + l4;
+                mf[rt][kk] = (ok && r < n && s < n) ? Mb[r * n + s] : 0.0;
+            }
+    }
+    for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += 256) {
+        const int d = idx / NPAD, q = idx % NPAD;
+        double v = 0.0;
+        if (d < n && q < n) v = a.ct ? C[q * n + d] : C[d * n + q];
+        Xs[d * LDX + q] = v;
+    }
+    __syncthreads();
+    double xf[KS][NT];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xf[kk][t] = Xs[(4 * kk + l4) * LDX + t * 16 + l15];
+
+    for (int ql = wave; ql < nq; ql += 4) {
+        const int q = q0 + ql;
+        // prefetch the wave's next matrix
+        double mn[NT][KS];
+        {
+            const bool ok = ql + 4 < nq;
+            const double *Mb = in + ((int64_t)p * n + q + 4) * n2;
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const int r = rt * 16 + l15, s = 4 * kk + l4;
+                    mn[rt][kk] = (ok && r < n && s < n) ? Mb[r * n + s] : 0.0;
+                }
+        }
+        // H = M X
+        d4 h[NT][NT];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int st = 0; st < NT; ++st) {
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) acc = mfma_f64(mf[rt][kk], xf[kk][st], acc);
+                h[rt][st] = acc;
+            }
+        if (a.k3) {
+            double *K3 = a.k3 + g * a.sk3;
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int st = 0; st < NT; ++st)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int r = rt * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
+                        if (r < n && s2 < n) K3[((int64_t)s2 * n + p) * n2 + (int64_t)q * n + r] = h[rt][st][reg];
+                    }
+        }
+        // N = X^T H : B operand of k-step kk is register kk%4 of H's row tile kk/4
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int st = 0; st < NT; ++st) {
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) acc = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], acc);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
+                    if (r2 < n && s2 < n) stage[(r2 * n + s2) * QP + ql] = acc[reg];
+                }
+            }
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = mn[rt][kk];
+    }
+    __syncthreads();
+    // write-out: 8 lanes cover the q run of one (r',s')
+    const int ql = threadIdx.x & 7;
+    if (a.out) {
+        double *out = a.out + g * a.sout;
+        for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32)
+            if (ql < nq) out[(int64_t)rs * n2 + (int64_t)p * n + q0 + ql] = stage[rs * QP + ql];
+    }
+    if (a.packed) {
+        double *pk = a.packed + g * a.spacked;
+        for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {
+            const int64_t R = rs, Cc = (int64_t)p * n + q0 + ql;
+            if (ql < nq && R >= Cc) pk[tri_index(R, Cc)] = stage[rs * QP + ql] * (R == Cc ? a.diag_mult : 1.0);
+        }
+        // zero the padding [M, packed_len) once per geometry
+        if (blockIdx.x == 0) {
+            const int64_t M = n2 * (n2 + 1) / 2;
+            for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
+        }
+    }
+    (void)n3;
+}
+
+int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st) {
+    const int n = a.n;
+    const int npad = (n + 15) / 16 * 16;
+    const int ntq = (n + 7) / 8;
+    const dim3 grid(n * ntq, (unsigned)count);
+    if (npad == 16) {
+        const size_t lds = sizeof(double) * ((size_t)16 * 16 + (size_t)n * n * 9);
+        hipLaunchKernelGGL(pt_kernel<16>, grid, dim3(256), lds, st, a);
+    } else if (npad == 32) {
+        const size_t lds = sizeof(double) * ((size_t)32 * 48 + (size_t)n * n * 9);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pt_kernel<32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(pt_kernel<32>, grid, dim3(256), lds, st, a);
+    } else {
+        set_error("pair_transform: n=%d not supported (1..32)", n);
+        return -1;
+    }
+    EVC_LAUNCH_CHECK("pair_transform");
+    return 0;
+}
+
 // ------------------------------------------------------------------ pack / unpack
 __global__ void pack_kernel(const double *__restrict__ h2, int64_t sh2, int n, double mult, double *__restrict__ out,
                             int64_t sout, int64_t M, int64_t out_len) {
