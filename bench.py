@@ -2,16 +2,24 @@
 """Throughput benchmark of the continuation energy+force hot path (BASELINE.json metric:
 continuation geometries/sec, energy+force, H30 STO-3G, 20 training states).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--layout pack2|full6|pair5|elec3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch G] [--streams S]
+                    [--layout pack2|full6|pair5|elec3] [--workload H30|H10|H2O|Zundel]
 
-One "step" = one energy+force evaluation of one synthetic geometry (N=30 orbitals, A=30
-atoms) against T=20 training states whose t-RDMs are resident in HBM.  64 distinct geometry
-bundles are resident on the device and cycled.  With --gpus N > 1 (launched by
-torch.distributed.run, one rank per GPU) the training PAIRS are sharded over the ranks and
-each evaluation uses two KB-sized RCCL collectives (evcont_amd/distributed.py): total work is
-fixed, so scaling is "strong".
+One "step" = one pass of the hot path over one batch of G synthetic geometries (N=30 orbitals,
+A=30 atoms) against T=20 training states whose t-RDMs are resident in HBM: G energy+force
+evaluations.  Every launch of the pipeline covers the whole batch and the two streaming kernels
+read the t-RDM once per 16 geometries (evc_energy_with_grad_batch).  S streams keep S batches in
+flight so the single-workgroup (latency-bound) kernels of one batch overlap the streaming kernels
+of another.  64 distinct geometry bundles are resident on the device and cycled.
 
-Rank 0 prints ONE JSON line (see DESIGN.md §Measurement for every field).
+`--batch 1 --streams 1` is the strictly sequential regime of an MD run (one geometry at a time);
+it is measured as well and reported under "md_regime".
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the training PAIRS are
+sharded over the ranks and each evaluation uses two KB-sized RCCL collectives
+(evcont_amd/distributed.py): total work is fixed, so scaling is "strong".
+
+Rank 0 prints ONE JSON line (see DESIGN.md §5 for every field).
 """
 import argparse
 import ctypes as C
@@ -36,26 +44,24 @@ WORKLOADS = {
     "Zundel": (28, 7, 30, (9, 2, 2, 2, 9, 2, 2)),  # configs[4]
 }
 LAYOUT_ND = {"full6": 6, "pair5": 5, "elec3": 3, "pack2": 2}
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (~6 TB/s achievable by a plain streaming read)
+MAX_G_PER_LAUNCH = 16   # geometries that share one pass over the t-RDM (csrc/gemv_mfma.hip)
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=60)
+    p.add_argument("--warmup", type=int, default=6)
     p.add_argument("--workload", default="H30", choices=list(WORKLOADS))
     p.add_argument("--layout", default="pack2", choices=list(LAYOUT_ND))
     p.add_argument("--geoms", type=int, default=64, help="distinct synthetic geometries resident on the device")
+    p.add_argument("--batch", type=int, default=16, help="geometries per step (1 = one geometry per step, MD regime)")
+    p.add_argument("--streams", type=int, default=2, help="batches in flight (one HIP stream + workspace each)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-md-regime", action="store_true", help="skip the extra sequential (batch 1, 1 stream) leg")
     p.add_argument("--cpu-samples", type=int, default=0, help="geometries timed on the host (0 = auto)")
     p.add_argument("--energy-only", action="store_true")
-    p.add_argument("--batch", type=int, default=1,
-                   help="geometries per step: every launch covers the batch and the t-RDM is streamed once per "
-                        "8 geometries (evc_energy_with_grad_batch); 1 = one geometry per step as in an MD run")
-    p.add_argument("--streams", type=int, default=1,
-                   help="independent geometries in flight (one HIP stream + workspace each); 1 = strictly "
-                        "sequential evaluations as in an MD run")
     return p.parse_args()
 
 
@@ -127,26 +133,7 @@ def main():
     trd = DeviceTRDMs.from_device_rows(one, two_rows, S_train, nd, r0, rows)
     del two_rows
     aos = [make_device_ao(n, A, seed * 1000 + k, dev, sizes) for k in range(a.geoms)]
-    nslots = max(1, a.streams) if world == 1 else 1
-    G = max(1, a.batch) if world == 1 else 1
-    mk_stream = lambda: (torch.cuda.Stream(dev) if nslots > 1 else None)
-    if G > 1:
-        nb = max(1, len(aos) // G)
-        batches = [DeviceAOBatch.stack(aos[i * G:(i + 1) * G]) for i in range(nb)]
-        evs = [BatchedEvaluator(trd, A, G, stream=mk_stream()) for _ in range(nslots)]
-    else:
-        evs = [ContinuationEvaluator(trd, A, stream=mk_stream()) for _ in range(nslots)]
-    ev = evs[0]
-    runner = PairShardedContinuation(ev, rows) if world > 1 else None
     lib = _lib.load()
-
-    def step(k):
-        if runner is not None:
-            runner.enqueue(aos[k % len(aos)], 1, a.energy_only)
-        elif G > 1:
-            evs[k % nslots].enqueue(batches[k % len(batches)], 1, a.energy_only)
-        else:
-            evs[k % nslots].enqueue(aos[k % len(aos)], 1, a.energy_only)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -154,57 +141,78 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for k in range(a.warmup):
-        step(k)
-    fence()
-    _lib.check(lib.evc_profile_begin(a.steps), "evc_profile_begin")
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        step(a.warmup + k)
-    fence()
-    dt = time.perf_counter() - t0
-    rows_ms, cols_ms = C.c_double(), C.c_double()
-    rows_n, cols_n = C.c_int(), C.c_int()
-    _lib.check(lib.evc_profile_end(C.byref(rows_ms), C.byref(rows_n), C.byref(cols_ms), C.byref(cols_n)),
-               "evc_profile_end")
-    e_last = float(ev.energy.reshape(-1)[0].item())
-    assert np.isfinite(e_last), "non-finite energy in the timed region"
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def measure(G, nslots, steps, warmup):
+        """Time `steps` passes over batches of G geometries with `nslots` batches in flight."""
+        mk_stream = lambda: (torch.cuda.Stream(dev) if nslots > 1 else None)
+        if world > 1:
+            evs = [ContinuationEvaluator(trd, A)]
+            runner = PairShardedContinuation(evs[0], rows)
+            step = lambda k: runner.enqueue(aos[k % len(aos)], 1, a.energy_only)
+        elif G > 1:
+            nb = max(1, len(aos) // G)
+            batches = [DeviceAOBatch.stack([aos[(i * G + j) % len(aos)] for j in range(G)]) for i in range(nb)]
+            evs = [BatchedEvaluator(trd, A, G, stream=mk_stream()) for _ in range(nslots)]
+            step = lambda k: evs[k % nslots].enqueue(batches[k % len(batches)], 1, a.energy_only)
+        else:
+            evs = [ContinuationEvaluator(trd, A, stream=mk_stream()) for _ in range(nslots)]
+            step = lambda k: evs[k % nslots].enqueue(aos[k % len(aos)], 1, a.energy_only)
+        for k in range(warmup):
+            step(k)
+        fence()
+        _lib.check(lib.evc_profile_begin(steps), "evc_profile_begin")
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(warmup + k)
+        fence()
+        dt = time.perf_counter() - t0
+        rows_ms, cols_ms = C.c_double(), C.c_double()
+        rows_n, cols_n = C.c_int(), C.c_int()
+        _lib.check(lib.evc_profile_end(C.byref(rows_ms), C.byref(rows_n), C.byref(cols_ms), C.byref(cols_n)),
+                   "evc_profile_end")
+        e_last = float(evs[0].energy.reshape(-1)[0].item())
+        assert np.isfinite(e_last), "non-finite energy in the timed region"
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        gl = min(G, MAX_G_PER_LAUNCH)                  # geometries per launch of the streaming kernels
+        lps = -(-G // MAX_G_PER_LAUNCH)                # launches per step
+        # ALGORITHMIC bytes of one K5 / K8 launch: the local two-body rows + the one-body t-RDM once,
+        # plus one h2 (K5) / predicted-RDM (K8) vector per geometry of the launch (DESIGN.md §4)
+        nbytes = trd.rows_local * cols * 8 + T * T * n * n * 8 + gl * (cols * 8 + n * n * 8)
+        k5 = rows_ms.value / max(rows_n.value, 1) / lps
+        k8 = cols_ms.value / max(cols_n.value, 1) / lps if cols_n.value else None
+        return {"value": steps * G / dt, "ms_per_step": 1e3 * dt / steps, "batch": G, "streams": nslots,
+                "k5_ms": k5, "k8_ms": k8, "bytes_per_launch": nbytes, "launches": rows_n.value * lps,
+                "geometries_per_launch": gl, "k5_GBs": nbytes / (k5 * 1e-3) / 1e9,
+                "k8_GBs": (nbytes / (k8 * 1e-3) / 1e9) if k8 else None, "last_energy": e_last}
+
+    G = max(1, a.batch) if world == 1 else 1
+    S = max(1, a.streams) if world == 1 else 1
+    m = measure(G, S, a.steps, a.warmup)
 
     if rank == 0:
-        # dominant kernel = K5, the 2-RDM x ERI contraction (rows GEMV); algorithmic bytes per
-        # launch = local two-body rows x cols x 8 B + one-body rows + the two vectors
-        # (+ per geometry of the batch: the h2 / predicted-RDM vector).  A batch of G > 8 is G/8 launches.
-        gl = min(G, 8)                      # geometries per launch
-        launches_per_step = -(-G // 8)
-        bytes_rows = trd.rows_local * cols * 8 + T * T * n * n * 8 + gl * (cols * 8 + n * n * 8)
-        bytes_cols = bytes_rows
-        k5_ms = rows_ms.value / max(rows_n.value, 1) / launches_per_step
-        k8_ms = cols_ms.value / max(cols_n.value, 1) / launches_per_step if cols_n.value else None
-        ach = bytes_rows / (k5_ms * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
                 rec = json.load(open(tj))
-                key = f"{a.workload}/{a.layout}/gemv_rows"
+                key = f"{a.workload}/{a.layout}/batch{G}/k5"
                 if key in rec:
                     traffic = rec[key]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
+        what = "energy" if a.energy_only else "energy+force"
         out = {
-            "metric": "continuation geometries/sec (energy+force), H30 STO-3G, 20 training states"
-            if a.workload == "H30" and not a.energy_only else
-            f"continuation geometries/sec ({'energy' if a.energy_only else 'energy+force'}), {a.workload}",
-            "value": a.steps * G / dt,
+            "metric": ("continuation geometries/sec (energy+force), H30 STO-3G, 20 training states"
+                       if a.workload == "H30" and not a.energy_only else
+                       f"continuation geometries/sec ({what}), {a.workload}"),
+            "value": m["value"],
             "unit": "geometries/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps,
+            "ms_per_step": m["ms_per_step"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -212,17 +220,27 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: N={n} orbitals, A={A} atoms, T={T} training states, "
                                    f"two-body t-RDM layout {a.layout} ({rows}x{cols} f64, "
-                                   f"{rows * cols * 8 / 1e9:.3f} GB resident in HBM), {a.geoms} resident geometries",
+                                   f"{rows * cols * 8 / 1e9:.3f} GB resident in HBM), {a.geoms} resident geometries; "
+                                   f"step = {G} {what} evaluations",
                        "parallelism": f"pairs{world}" if world > 1 else "single",
-                       "streams": nslots, "geometries_per_step": G},
-            "roofline": {"bound": "hbm", "kernel": "gemv_rows_kernel (K5: H_ab = Gamma.h2)",
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "bytes_per_launch": bytes_rows, "ms_per_launch": k5_ms,
-                         "launches": rows_n.value * launches_per_step, "geometries_per_launch": gl},
-            "kernels": {"gemv_rows_ms": k5_ms, "gemv_cols_ms": k8_ms,
-                        "gemv_cols_GBs": (bytes_cols / (k8_ms * 1e-3) / 1e9) if k8_ms else None},
-            "last_energy": e_last,
+                       "geometries_per_step": G, "streams": S},
+            "roofline": {"bound": "hbm",
+                         "kernel": "K5: H_ab = Gamma . h2 (gemv_rows_*_kernel, the 2-RDM x ERI contraction)",
+                         "achieved": m["k5_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": m["k5_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch": m["bytes_per_launch"], "ms_per_launch": m["k5_ms"],
+                         "launches": m["launches"], "geometries_per_launch": m["geometries_per_launch"]},
+            "kernels": {"k5_rows_ms": m["k5_ms"], "k8_cols_ms": m["k8_ms"], "k8_cols_GBs": m["k8_GBs"]},
+            "last_energy": m["last_energy"],
         }
+    if world == 1 and not a.no_md_regime and (G, S) != (1, 1):
+        md = measure(1, 1, max(20, min(a.steps * 2, 200)), 10)
+        if rank == 0:
+            out["md_regime"] = {"value": md["value"], "unit": "geometries/s", "ms_per_step": md["ms_per_step"],
+                                "note": "one geometry per step on one stream (no batching, no overlap)",
+                                "k5_rows_ms": md["k5_ms"], "k5_GBs": md["k5_GBs"], "k5_frac": md["k5_GBs"] / HBM_PEAK_GBS,
+                                "k8_cols_ms": md["k8_ms"], "k8_GBs": md["k8_GBs"]}
+    if rank == 0:
         if not a.no_cpu_baseline and world == 1 and not a.energy_only:
             samples = a.cpu_samples or (8 if a.workload in ("H30", "Zundel") else 50)
             out["cpu_baseline"] = cpu_baseline(a.workload, nd, trd, aos, samples)

@@ -216,11 +216,12 @@ constexpr int kRBPlan = 8;  // row-block height the workspace/partials are plann
 void plan_rows(RowProblem &P) {
     const int64_t nchunks = ceil_div(P.cols, kChunk);
     const int64_t nrb = ceil_div(P.rows, kRBPlan);
-    // aim at >= ~2048 workgroups (8 per CU) while keeping spans >= 4 chunks when possible
-    static const int target = env_int("EVC_ROWS_TARGET_WGS", 2048);
+    // aim at `target` 8-row blocks (span count = target / row blocks) while keeping spans >= 2 chunks
+    static const int target = env_int("EVC_ROWS_TARGET_WGS", 8192);
+    static const int min_cps = env_int("EVC_ROWS_MIN_CPS", 2);
     int64_t want_spans = ceil_div(target, nrb);
     int64_t cps = nchunks / want_spans;
-    if (cps < 4) cps = nchunks < 4 ? nchunks : 4;
+    if (cps < min_cps) cps = nchunks < min_cps ? nchunks : min_cps;
     if (cps < 1) cps = 1;
     P.cps = (int)cps;
     P.nspans = (int)ceil_div(nchunks, cps);
@@ -262,9 +263,18 @@ int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     if (p0.nblocks + p1.nblocks == 0 || count <= 0) return 0;
     static const int v8 = env_int("EVC_ROWS_G8", 0);   // 0: wave-rows kernel RBW=4; 1: lane-private RB=2
     static const int v4 = env_int("EVC_ROWS_G4", 0);   // 0: wave-rows RBW=8; 1: wave-rows RBW=4; 2: lane-private RB=4
+    static const int mfma_min = env_int("EVC_MFMA_MIN_G", 12);   // groups of >= this many geometries use the matrix cores
+    static const int mfma_tiles = env_int("EVC_MFMA_TILES", 4);
     int g0 = 0;
     while (g0 < count) {
         const int left = count - g0;
+        if (left >= mfma_min) {
+            const int G = left < 16 ? left : 16;
+            int rc = launch_gemv_rows_mfma(L, g0, G, mfma_tiles, st);
+            if (rc) return rc;
+            g0 += G;
+            continue;
+        }
         if (left >= 8) {
             if (v8 == 1) rows_launch<2, 8>(L, g0, st);
             else rows_wr_launch<4, 8>(L, g0, st);
@@ -398,9 +408,17 @@ int launch_gemv_cols(ColProblem p0, ColProblem p1, int count, hipStream_t st) {
     L.nblk0 = (int)ceil_div(p0.cols, kChunk);
     const int total = L.nblk0 + (int)ceil_div(p1.cols, kChunk);
     if (total == 0 || count <= 0) return 0;
+    static const int mfma_min = env_int("EVC_MFMA_MIN_G", 12);
     int g0 = 0;
     while (g0 < count) {
         const int left = count - g0;
+        if (left >= mfma_min) {
+            const int G = left < 16 ? left : 16;
+            int rc = launch_gemv_cols_mfma(L, g0, G, st);
+            if (rc) return rc;
+            g0 += G;
+            continue;
+        }
         if (left >= 8) { cols_launch<8>(L, total, g0, st); g0 += 8; }
         else if (left >= 4) { cols_launch<4>(L, total, g0, st); g0 += 4; }
         else if (left >= 2) { cols_launch<2>(L, total, g0, st); g0 += 2; }

@@ -33,6 +33,9 @@ struct GemvColsLaunch {
     ColProblem p[2];
     int nblk0;
 };
+// gemv_mfma.hip: matrix-core variants, G <= 16 geometries [g0, g0+G) per launch
+int launch_gemv_rows_mfma(const GemvRowsLaunch &L, int g0, int G, int tiles, hipStream_t st);
+int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st);
 void plan_rows(RowProblem &P);
 size_t rows_ws_doubles(int64_t rows, int64_t cols);
 // `count` geometries; launched in groups of up to kMaxBatchG that share one read of A.

@@ -69,6 +69,9 @@ static bool use_pair_transform(int n) {
     return !off && n <= kPairTransformMaxN;
 }
 
+// Many spans: sum the partials in a multi-workgroup launch instead of inside the eigensolver kernel.
+static bool reduce_in_own_launch(const Ws &w) { return w.rp2.nspans > 48; }
+
 static bool is_packed(int layout) { return layout == EVC_LAYOUT_ELEC3 || layout == EVC_LAYOUT_PACK2; }
 static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout == EVC_LAYOUT_PACK2; }
 
@@ -141,13 +144,28 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.stride = (int64_t)(off / sizeof(double));
 }
 
-// y[r] = alpha * sum_k partial[k][r]   (tiny; only used on the multi-GPU path)
-__global__ void rows_reduce_kernel(const double *partial, int64_t rows, int nspans, double alpha, double *y) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    double s = 0.0;
-    for (int k = 0; k < nspans; ++k) s += partial[(int64_t)k * rows + r];
-    y[r] = alpha * s;
+// y[g][r] = alpha * sum_k partial[g][k][r]: the fixed-order sum of the span partials, done here (many
+// workgroups) rather than inside the single-workgroup eigensolver when there are many spans.
+// Block = 64 rows x 4 span groups; blockIdx.y = geometry.
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const double *partial, int64_t spart, int64_t rows,
+                                                          int nspans, double alpha, double *y, int64_t sy) {
+    __shared__ double part[4][64];
+    partial += (int64_t)blockIdx.y * spart;
+    y += (int64_t)blockIdx.y * sy;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    double s0 = 0.0, s1 = 0.0;
+    if (r < rows) {
+        int k = grp;
+        for (; k + 4 < nspans; k += 8) {
+            s0 += partial[(int64_t)k * rows + r];
+            s1 += partial[(int64_t)(k + 4) * rows + r];
+        }
+        if (k < nspans) s0 += partial[(int64_t)k * rows + r];
+    }
+    part[grp][lane] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && r < rows) y[r] = alpha * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 
 static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool reduce_rows, hipStream_t st) {
@@ -222,10 +240,10 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_rows + 0], st);
     if ((rc = launch_gemv_rows(p2, p1, cnt, st))) return rc;
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_rows++ + 1], st);
-    if (reduce_rows && t->rows2 > 0) {
+    if ((reduce_rows || reduce_in_own_launch(w)) && t->rows2 > 0) {
         const double alpha2 = is_packed(t->layout) ? 1.0 : 0.5;
-        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)ceil_div(t->rows2, 256)), dim3(256), 0, st,
-                           w.h2part, t->rows2, w.rp2.nspans, alpha2, w.h2rows + t->row_offset);
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)ceil_div(t->rows2, 64), (unsigned)cnt), dim3(256), 0,
+                           st, w.h2part, sw, t->rows2, w.rp2.nspans, alpha2, w.h2rows + t->row_offset, sw);
         EVC_LAUNCH_CHECK("rows_reduce");
     }
     return 0;
@@ -245,6 +263,11 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
         a.nsp2 = 1;
         a.alpha2 = 1.0;
         a.sh2 = 0;
+    } else if (reduce_in_own_launch(w)) {
+        a.h2part = w.h2rows;  // written by rows_reduce_kernel in phase A (complete t-RDM on this device)
+        a.nsp2 = 1;
+        a.alpha2 = 1.0;
+        a.sh2 = sw;
     } else {
         a.h2part = w.h2part;
         a.nsp2 = w.rp2.nspans;

@@ -71,20 +71,23 @@ __global__ __launch_bounds__(256) void qt_kernel(const double *__restrict__ in, 
                 bn[kk] = (nok && d < n) ? in[nrow * n + d] : 0.0;
             }
         }
+        // the NT output tiles are independent accumulation chains: interleave them (a dependent
+        // f64 MFMA costs ~3x the issue interval)
+        d4 acc[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t * 16 < n) {
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk)
-                    acc = mfma_f64(Xs[(4 * kk + l4) * LDX + t * 16 + l15], b[kk], acc);
+        for (int kk = 0; kk < KSTEPS; ++kk)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = t * 16 + l4 + 4 * r;
-                    if (rok && q < n) out[(int64_t)q * rows + row] = acc[r];
-                }
+            for (int t = 0; t < NT; ++t)
+                acc[t] = mfma_f64(Xs[(4 * kk + l4) * LDX + t * 16 + l15], b[kk], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = t * 16 + l4 + 4 * r;
+                if (rok && q < n) out[(int64_t)q * rows + row] = acc[t][r];
             }
-        }
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) b[kk] = bn[kk];
         tile = next;
@@ -193,16 +196,18 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
                 }
         }
         // H = M X
+        // (a dependent f64 MFMA costs ~3x the issue interval: the NT*NT tile chains are interleaved)
         d4 h[NT][NT];
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-            for (int st = 0; st < NT; ++st) {
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int st = 0; st < NT; ++st) h[rt][st] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) acc = mfma_f64(mf[rt][kk], xf[kk][st], acc);
-                h[rt][st] = acc;
-            }
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
         if (a.k3) {
             double *K3 = a.k3 + g * a.sk3;
 #pragma unroll
@@ -216,19 +221,27 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
                     }
         }
         // N = X^T H : B operand of k-step kk is register kk%4 of H's row tile kk/4
+        d4 nn[NT][NT];
 #pragma unroll
         for (int it = 0; it < NT; ++it)
 #pragma unroll
-            for (int st = 0; st < NT; ++st) {
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int st = 0; st < NT; ++st) nn[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) acc = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], acc);
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int st = 0; st < NT; ++st)
+                    nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int st = 0; st < NT; ++st)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
-                    if (r2 < n && s2 < n) stage[(r2 * n + s2) * QP + ql] = acc[reg];
+                    if (r2 < n && s2 < n) stage[(r2 * n + s2) * QP + ql] = nn[it][st][reg];
                 }
-            }
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
