@@ -1,8 +1,9 @@
 // Streaming t-RDM contractions (HBM-bandwidth bound):
 //   K5/K4  rows GEMV   y[g][r]   = sum_c A[r,c] v[g][c]     (H_ab build,      evcont.py:38-68)
 //   K8/K7  cols GEMV   out[g][c] = sum_r w[g][r] A[r,c]     (predicted RDMs,  gradients_loewdin.py:343-356)
-// A (the t-RDM) is shared by a batch of G <= 8 geometries, so one pass over the 0.68-2.6 GB matrix
-// serves G evaluations; at G = 8 the kernels are still HBM bound (16 flop per 8 bytes, ~20 % VALU).
+// A (the t-RDM) is shared by a batch of geometries, so one pass over the 0.68-2.6 GB matrix serves
+// G evaluations: G <= 8 per pass with the VALU kernels of this file, 12..16 with the matrix-core
+// variants of gemv_mfma.hip (the dispatch at the bottom of this file picks per group).
 // Each launch carries TWO problems (the two-body and the one-body t-RDM) so the small one rides
 // along with the big one instead of costing a kernel boundary.
 #include <stdlib.h>
@@ -213,12 +214,18 @@ static int env_int(const char *name, int dflt) {
 
 constexpr int kRBPlan = 8;  // row-block height the workspace/partials are planned for (all variants use it)
 
-void plan_rows(RowProblem &P) {
+// Span plan.  `batched` selects the finer decomposition the batched (G > 1) kernels want (they own whole
+// row groups, so they need more spans for the same number of workgroups); the partial buffers are sized
+// for the finer plan and the single-geometry kernels simply use fewer spans of the same layout.
+void plan_rows(RowProblem &P, bool batched) {
     const int64_t nchunks = ceil_div(P.cols, kChunk);
     const int64_t nrb = ceil_div(P.rows, kRBPlan);
-    // aim at `target` 8-row blocks (span count = target / row blocks) while keeping spans >= 2 chunks
-    static const int target = env_int("EVC_ROWS_TARGET_WGS", 8192);
-    static const int min_cps = env_int("EVC_ROWS_MIN_CPS", 2);
+    // aim at `target` 8-row blocks (span count = target / row blocks) while keeping spans >= min_cps chunks
+    static const int target_b = env_int("EVC_ROWS_TARGET_WGS", 8192);
+    static const int target_1 = env_int("EVC_ROWS_TARGET_WGS_G1", 2048);
+    static const int min_cps_b = env_int("EVC_ROWS_MIN_CPS", 2);
+    const int target = batched ? target_b : target_1;
+    const int min_cps = batched ? min_cps_b : 4;
     int64_t want_spans = ceil_div(target, nrb);
     int64_t cps = nchunks / want_spans;
     if (cps < min_cps) cps = nchunks < min_cps ? nchunks : min_cps;
@@ -232,7 +239,7 @@ size_t rows_ws_doubles(int64_t rows, int64_t cols) {
     RowProblem P{};
     P.rows = rows;
     P.cols = cols;
-    plan_rows(P);
+    plan_rows(P, true);
     return (size_t)rows * P.nspans;
 }
 
@@ -454,7 +461,7 @@ extern "C" int evc_gemv_rows(const double *A, int64_t rows, int64_t cols, int64_
     P.rows = rows;
     P.cols = cols;
     P.ld = ld;
-    plan_rows(P);
+    plan_rows(P, false);
     RowProblem none{};
     int rc = launch_gemv_rows(P, none, 1, as_stream(stream));
     if (rc) return rc;

@@ -9,7 +9,7 @@
 
 namespace evc {
 
-constexpr int kMaxBatchG = 8;  // geometries contracted per pass of the streaming kernels
+constexpr int kMaxBatchG = 16;  // geometries contracted per pass of the streaming kernels (MFMA variants)
 
 // ---- gemv_stream.hip ---------------------------------------------------------------
 struct RowProblem {
@@ -36,7 +36,7 @@ struct GemvColsLaunch {
 // gemv_mfma.hip: matrix-core variants, G <= 16 geometries [g0, g0+G) per launch
 int launch_gemv_rows_mfma(const GemvRowsLaunch &L, int g0, int G, int tiles, hipStream_t st);
 int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st);
-void plan_rows(RowProblem &P);
+void plan_rows(RowProblem &P, bool batched);
 size_t rows_ws_doubles(int64_t rows, int64_t cols);
 // `count` geometries; launched in groups of up to kMaxBatchG that share one read of A.
 int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st);

@@ -124,11 +124,12 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.rp2.rows = t->rows2;
     w.rp2.cols = t->cols2;
     w.rp2.ld = t->ld2;
-    if (t->rows2 > 0) plan_rows(w.rp2);
+    // buffers are sized for the finer (batched) span plan; replan() picks the plan of the actual call
+    if (t->rows2 > 0) plan_rows(w.rp2, true);
     w.rp1.rows = (int64_t)T * T;
     w.rp1.cols = (int64_t)n2;
     w.rp1.ld = t->ld1;
-    plan_rows(w.rp1);
+    plan_rows(w.rp1, true);
     w.h2part = take((size_t)t->rows2 * (w.rp2.nspans > 0 ? w.rp2.nspans : 1) + 1);
     w.h1part = take((size_t)T * T * w.rp1.nspans);
     w.h2rows = take((size_t)t->rows2_total);
@@ -149,29 +150,42 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
 // Block = 64 rows x 4 span groups; blockIdx.y = geometry.
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const double *partial, int64_t spart, int64_t rows,
                                                           int nspans, double alpha, double *y, int64_t sy) {
-    __shared__ double part[4][64];
+    __shared__ double part[16][17];
     partial += (int64_t)blockIdx.y * spart;
     y += (int64_t)blockIdx.y * sy;
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    const int rl = threadIdx.x & 15, grp = threadIdx.x >> 4;   // 16 rows x 16 span lanes
+    const int64_t r = (int64_t)blockIdx.x * 16 + rl;
     double s0 = 0.0, s1 = 0.0;
     if (r < rows) {
         int k = grp;
-        for (; k + 4 < nspans; k += 8) {
+        for (; k + 16 < nspans; k += 32) {
             s0 += partial[(int64_t)k * rows + r];
-            s1 += partial[(int64_t)(k + 4) * rows + r];
+            s1 += partial[(int64_t)(k + 16) * rows + r];
         }
         if (k < nspans) s0 += partial[(int64_t)k * rows + r];
     }
-    part[grp][lane] = s0 + s1;
+    part[grp][rl] = s0 + s1;
     __syncthreads();
-    if (grp == 0 && r < rows) y[r] = alpha * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    if (grp == 0 && r < rows) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[k][rl];   // fixed order
+        y[r] = alpha * s;
+    }
+}
+
+// Span plan of this call (never more spans than the buffers were carved for).
+static void replan(const evc_trdm_set *t, Ws &w, int count) {
+    const bool batched = count > 1;
+    if (t->rows2 > 0) plan_rows(w.rp2, batched);
+    plan_rows(w.rp1, batched);
 }
 
 static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool reduce_rows, hipStream_t st) {
     const int n = t->n, cnt = g.count;
     const int64_t sw = w.stride;
     int rc;
+    replan(t, w, cnt);
     LoewdinArgs la{};
     la.S = g.S;
     la.h = g.hcore;
@@ -242,7 +256,7 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
     if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_rows++ + 1], st);
     if ((reduce_rows || reduce_in_own_launch(w)) && t->rows2 > 0) {
         const double alpha2 = is_packed(t->layout) ? 1.0 : 0.5;
-        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)ceil_div(t->rows2, 64), (unsigned)cnt), dim3(256), 0,
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)ceil_div(t->rows2, 16), (unsigned)cnt), dim3(256), 0,
                            st, w.h2part, sw, t->rows2, w.rp2.nspans, alpha2, w.h2rows + t->row_offset, sw);
         EVC_LAUNCH_CHECK("rows_reduce");
     }
@@ -584,6 +598,7 @@ extern "C" size_t evc_workspace_bytes_batch(const evc_trdm_set *t, int natm, int
     Ws w;                                                                                         \
     carve(t, g->natm, static_cast<char *>(ws), w);                                                \
     EVC_REQUIRE(ws_bytes >= w.bytes, "workspace too small: %zu < %zu", ws_bytes, w.bytes);        \
+    replan(t, w, 1);                                                                              \
     hipStream_t st = as_stream(stream);                                                           \
     const Geo geo = geo_single(g)
 
