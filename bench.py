@@ -15,9 +15,14 @@ of another.  64 distinct geometry bundles are resident on the device and cycled.
 `--batch 1 --streams 1` is the strictly sequential regime of an MD run (one geometry at a time);
 it is measured as well and reported under "md_regime".
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the training PAIRS are
-sharded over the ranks and each evaluation uses two KB-sized RCCL collectives
-(evcont_amd/distributed.py): total work is fixed, so scaling is "strong".
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) two ways of using the
+node are measured in the same run:
+  --shard geometries (default, `value`): every rank holds a replica of the t-RDMs (0.68 GB) and
+      evaluates its own batches of geometries; no data-path collective; per-GPU work is fixed, so
+      scaling is "weak" and `value` = geometries of ALL ranks / max-over-ranks time.
+  --shard pairs (reported under "pair_sharded"; `value` when selected): the training PAIRS are
+      sharded over the ranks, every rank sees the same batch, two KB-sized RCCL collectives per
+      step (evcont_amd/distributed.py); total work is fixed: "strong".
 
 Rank 0 prints ONE JSON line (see DESIGN.md §5 for every field).
 """
@@ -62,6 +67,9 @@ def parse():
     p.add_argument("--no-md-regime", action="store_true", help="skip the extra sequential (batch 1, 1 stream) leg")
     p.add_argument("--cpu-samples", type=int, default=0, help="geometries timed on the host (0 = auto)")
     p.add_argument("--energy-only", action="store_true")
+    p.add_argument("--shard", default="geometries", choices=["geometries", "pairs"],
+                   help="what is distributed over the ranks when --gpus N > 1")
+    p.add_argument("--no-second-mode", action="store_true", help="N > 1: skip the leg for the other --shard mode")
     return p.parse_args()
 
 
@@ -112,11 +120,18 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # EVC_BENCH_BACKEND=gloo lets several ranks share one card (rehearsal on a one-GPU box); RCCL needs a card per rank
+    backend = os.environ.get("EVC_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    assert backend != "nccl" or world <= ndev, f"{world} ranks but {ndev} visible devices"
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from evcont_amd import _lib
     from evcont_amd.evaluator import (DeviceTRDMs, ContinuationEvaluator, BatchedEvaluator, DeviceAOBatch,
@@ -128,12 +143,14 @@ def main():
     nd = LAYOUT_ND[a.layout]
     rows, cols = layout_shape(nd, T, n)
     seed = 1234 + list(WORKLOADS).index(a.workload)
-    r0, r1 = shard_rows(rows, world, rank)
-    S_train, one, two_rows = make_device_trdm_rows(n, T, nd, seed, dev, (r0, r1))
-    trd = DeviceTRDMs.from_device_rows(one, two_rows, S_train, nd, r0, rows)
-    del two_rows
-    aos = [make_device_ao(n, A, seed * 1000 + k, dev, sizes) for k in range(a.geoms)]
     lib = _lib.load()
+
+    def trdms(row_range):
+        S_train, one, two_rows = make_device_trdm_rows(n, T, nd, seed, dev, row_range)
+        return DeviceTRDMs.from_device_rows(one, two_rows, S_train, nd, row_range[0], rows)
+
+    def geometries(first_seed):
+        return [make_device_ao(n, A, first_seed + k, dev, sizes) for k in range(a.geoms)]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -141,21 +158,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def measure(G, nslots, steps, warmup):
-        """Time `steps` passes over batches of G geometries with `nslots` batches in flight."""
+    def measure(trd, aos, G, nslots, steps, warmup, sharded_pairs):
+        """Time `steps` passes over batches of G geometries with `nslots` batches in flight on this rank."""
         mk_stream = lambda: (torch.cuda.Stream(dev) if nslots > 1 else None)
-        if world > 1:
-            evs = [ContinuationEvaluator(trd, A)]
-            runner = PairShardedContinuation(evs[0], rows)
-            step = lambda k: runner.enqueue(aos[k % len(aos)], 1, a.energy_only)
-        elif G > 1:
+        if G > 1:
             nb = max(1, len(aos) // G)
-            batches = [DeviceAOBatch.stack([aos[(i * G + j) % len(aos)] for j in range(G)]) for i in range(nb)]
+            inputs = [DeviceAOBatch.stack([aos[(i * G + j) % len(aos)] for j in range(G)]) for i in range(nb)]
             evs = [BatchedEvaluator(trd, A, G, stream=mk_stream()) for _ in range(nslots)]
-            step = lambda k: evs[k % nslots].enqueue(batches[k % len(batches)], 1, a.energy_only)
         else:
+            inputs = aos
             evs = [ContinuationEvaluator(trd, A, stream=mk_stream()) for _ in range(nslots)]
-            step = lambda k: evs[k % nslots].enqueue(aos[k % len(aos)], 1, a.energy_only)
+        if sharded_pairs:
+            runners = [PairShardedContinuation(ev, rows) for ev in evs]
+        else:
+            runners = evs
+        step = lambda k: runners[k % nslots].enqueue(inputs[k % len(inputs)], 1, a.energy_only)
         for k in range(warmup):
             step(k)
         fence()
@@ -182,15 +199,23 @@ def main():
         nbytes = trd.rows_local * cols * 8 + T * T * n * n * 8 + gl * (cols * 8 + n * n * 8)
         k5 = rows_ms.value / max(rows_n.value, 1) / lps
         k8 = cols_ms.value / max(cols_n.value, 1) / lps if cols_n.value else None
-        return {"value": steps * G / dt, "ms_per_step": 1e3 * dt / steps, "batch": G, "streams": nslots,
+        # geometries evaluated by the whole job per step: G on every rank (distinct ones unless pair-sharded)
+        job_g = G if (sharded_pairs or world == 1) else G * world
+        return {"value": steps * job_g / dt, "ms_per_step": 1e3 * dt / steps, "batch": G, "streams": nslots,
                 "k5_ms": k5, "k8_ms": k8, "bytes_per_launch": nbytes, "launches": rows_n.value * lps,
                 "geometries_per_launch": gl, "k5_GBs": nbytes / (k5 * 1e-3) / 1e9,
-                "k8_GBs": (nbytes / (k8 * 1e-3) / 1e9) if k8 else None, "last_energy": e_last}
+                "k8_GBs": (nbytes / (k8 * 1e-3) / 1e9) if k8 else None, "last_energy": e_last,
+                "geometries_per_step": job_g}
 
-    G = max(1, a.batch) if world == 1 else 1
-    S = max(1, a.streams) if world == 1 else 1
-    m = measure(G, S, a.steps, a.warmup)
+    G, S = max(1, a.batch), max(1, a.streams)
+    pairs_first = world > 1 and a.shard == "pairs"
+    full_range, my_range = (0, rows), shard_rows(rows, world, rank)
+    # geometry sharding: every rank draws its own geometries; pair sharding: all ranks see the same ones
+    trd = trdms(my_range if pairs_first else full_range)
+    aos = geometries(seed * 1000 + (0 if pairs_first else rank * a.geoms))
+    m = measure(trd, aos, G, 1 if pairs_first else S, a.steps, a.warmup, pairs_first)
 
+    out = None
     if rank == 0:
         traffic = None
         tj = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -198,11 +223,17 @@ def main():
             try:
                 rec = json.load(open(tj))
                 key = f"{a.workload}/{a.layout}/batch{G}/k5"
-                if key in rec:
+                if key in rec and not pairs_first:
                     traffic = rec[key]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         what = "energy" if a.energy_only else "energy+force"
+        if world == 1:
+            par = "single"
+        elif pairs_first:
+            par = f"pairs{world}: training pairs sharded, all-gather of H rows + all-reduce of the gradient per step"
+        else:
+            par = f"geometries{world}: replicated t-RDMs, independent batches per GPU, no data-path collective"
         out = {
             "metric": ("continuation geometries/sec (energy+force), H30 STO-3G, 20 training states"
                        if a.workload == "H30" and not a.energy_only else
@@ -214,18 +245,18 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": m["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if (pairs_first or world == 1) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: N={n} orbitals, A={A} atoms, T={T} training states, "
                                    f"two-body t-RDM layout {a.layout} ({rows}x{cols} f64, "
-                                   f"{rows * cols * 8 / 1e9:.3f} GB resident in HBM), {a.geoms} resident geometries; "
-                                   f"step = {G} {what} evaluations",
-                       "parallelism": f"pairs{world}" if world > 1 else "single",
-                       "geometries_per_step": G, "streams": S},
+                                   f"{rows * cols * 8 / 1e9:.3f} GB resident in HBM), {a.geoms} resident geometries "
+                                   f"per GPU; step = {m['geometries_per_step']} {what} evaluations",
+                       "parallelism": par,
+                       "geometries_per_step": m["geometries_per_step"], "batch_per_gpu": G, "streams": m["streams"]},
             "roofline": {"bound": "hbm",
-                         "kernel": "K5: H_ab = Gamma . h2 (gemv_rows_*_kernel, the 2-RDM x ERI contraction)",
+                         "kernel": "K5: H_ab = Gamma . h2 (gemv_rows_*_kernel, the 2-RDM x ERI contraction), rank 0",
                          "achieved": m["k5_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": m["k5_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": m["bytes_per_launch"], "ms_per_launch": m["k5_ms"],
@@ -233,8 +264,27 @@ def main():
             "kernels": {"k5_rows_ms": m["k5_ms"], "k8_cols_ms": m["k8_ms"], "k8_cols_GBs": m["k8_GBs"]},
             "last_energy": m["last_energy"],
         }
+    if world > 1 and not a.no_second_mode:
+        # the other way of using the node, same batch size, reported next to the headline
+        del trd
+        torch.cuda.empty_cache()
+        second_pairs = not pairs_first
+        trd2 = trdms(my_range if second_pairs else full_range)
+        del aos
+        # pair sharding needs identical geometries on all ranks, geometry sharding distinct ones
+        aos2 = geometries(seed * 1000 + (0 if second_pairs else rank * a.geoms))
+        m2 = measure(trd2, aos2, G, 1 if second_pairs else S, a.steps, a.warmup, second_pairs)
+        if rank == 0:
+            out["pair_sharded" if second_pairs else "geometry_sharded"] = {
+                "value": m2["value"], "unit": "geometries/s", "ms_per_step": m2["ms_per_step"],
+                "scaling": "strong" if second_pairs else "weak", "geometries_per_step": m2["geometries_per_step"],
+                "batch_per_gpu": G, "streams": m2["streams"], "k5_rows_ms": m2["k5_ms"], "k5_GBs": m2["k5_GBs"],
+                "k5_frac": m2["k5_GBs"] / HBM_PEAK_GBS, "k8_cols_ms": m2["k8_ms"],
+                "rows_per_rank": (my_range[1] - my_range[0]) if second_pairs else rows,
+                "last_energy": m2["last_energy"]}
+        trd = trd2
     if world == 1 and not a.no_md_regime and (G, S) != (1, 1):
-        md = measure(1, 1, max(20, min(a.steps * 2, 200)), 10)
+        md = measure(trd, aos, 1, 1, max(20, min(a.steps * 2, 200)), 10, False)
         if rank == 0:
             out["md_regime"] = {"value": md["value"], "unit": "geometries/s", "ms_per_step": md["ms_per_step"],
                                 "note": "one geometry per step on one stream (no batching, no overlap)",

@@ -81,6 +81,12 @@ SIGNATURES = {
     "evc_workspace_bytes_batch": (C.c_size_t, [C.POINTER(TrdmSet), C.c_int, C.c_int]),
     "evc_energy_with_grad_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.POINTER(OutputsBatch),
                                              C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "evc_phase_hamiltonian_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.c_void_p, C.c_int64,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "evc_phase_solve_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.c_void_p, C.c_int64,
+                                        C.POINTER(OutputsBatch), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "evc_phase_gradient_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.POINTER(OutputsBatch),
+                                           C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_grad_elec_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "evc_grad_elec_oao": (C.c_int, [C.c_int, C.POINTER(Geometry), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -181,7 +181,9 @@ static void replan(const evc_trdm_set *t, Ws &w, int count) {
     plan_rows(w.rp1, batched);
 }
 
-static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool reduce_rows, hipStream_t st) {
+// rows_out != NULL: the scaled two-body rows go to rows_out[g*srows_out + r] (r local) instead of the workspace.
+static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool reduce_rows, hipStream_t st,
+                             double *rows_out = nullptr, int64_t srows_out = 0) {
     const int n = t->n, cnt = g.count;
     const int64_t sw = w.stride;
     int rc;
@@ -257,14 +259,15 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
     if ((reduce_rows || reduce_in_own_launch(w)) && t->rows2 > 0) {
         const double alpha2 = is_packed(t->layout) ? 1.0 : 0.5;
         hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)ceil_div(t->rows2, 16), (unsigned)cnt), dim3(256), 0,
-                           st, w.h2part, sw, t->rows2, w.rp2.nspans, alpha2, w.h2rows + t->row_offset, sw);
+                           st, w.h2part, sw, t->rows2, w.rp2.nspans, alpha2,
+                           rows_out ? rows_out : w.h2rows + t->row_offset, rows_out ? srows_out : sw);
         EVC_LAUNCH_CHECK("rows_reduce");
     }
     return 0;
 }
 
-static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows_all, const Out &out, int nroots,
-                       Ws &w, hipStream_t st) {
+static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows_all, int64_t sh2_all, const Out &out,
+                       int nroots, Ws &w, hipStream_t st) {
     SolveArgs a;
     memset(&a, 0, sizeof(a));
     const int64_t sw = w.stride;
@@ -276,7 +279,7 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
         a.h2part = h2rows_all;
         a.nsp2 = 1;
         a.alpha2 = 1.0;
-        a.sh2 = 0;
+        a.sh2 = sh2_all;
     } else if (reduce_in_own_launch(w)) {
         a.h2part = w.h2rows;  // written by rows_reduce_kernel in phase A (complete t-RDM on this device)
         a.nsp2 = 1;
@@ -616,7 +619,7 @@ extern "C" int evc_phase_solve(const evc_trdm_set *t, const evc_geometry *g, con
                                const evc_outputs *out, int nroots, void *ws, size_t ws_bytes, void *stream) {
     EVC_SETUP(false);
     EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
-    return phase_solve(t, geo, h2rows_all ? h2rows_all : w.h2rows, out_single(out), nroots, w, st);
+    return phase_solve(t, geo, h2rows_all ? h2rows_all : w.h2rows, 0, out_single(out), nroots, w, st);
 }
 
 extern "C" int evc_phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
@@ -638,36 +641,28 @@ extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g
     const Out o = out_single(out);
     int rc;
     if ((rc = phase_hamiltonian(t, geo, w, false, st))) return rc;
-    if ((rc = phase_solve(t, geo, nullptr, o, nroots, w, st))) return rc;
+    if ((rc = phase_solve(t, geo, nullptr, 0, o, nroots, w, st))) return rc;
     if (energy_only) return 0;
     return phase_gradient(t, geo, o, flags & ~EVC_FLAG_PARTIAL_RANK, w, st);
 }
 
-extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
-                                          const evc_outputs_batch *ob, int nroots, int flags, void *ws,
-                                          size_t ws_bytes, void *stream) {
-    const bool energy_only = (flags & EVC_FLAG_ENERGY_ONLY) != 0;
+// Shared argument checking / descriptor set-up of the batch entry points.
+static int setup_batch(const char *who, const evc_trdm_set *t, const evc_geometry_batch *gb,
+                       const evc_outputs_batch *ob, bool need_grad, void *ws, size_t ws_bytes, Ws &w, Geo &g, Out &o) {
     if (check_set(t)) return -1;
-    EVC_REQUIRE(gb && ob, "evc_energy_with_grad_batch: null batch descriptor");
-    EVC_REQUIRE(gb->count >= 1 && gb->count <= 4096, "batch count=%d out of range", gb->count);
-    EVC_REQUIRE(gb->S && gb->hcore && gb->eri && gb->enuc, "batch geometry: S/hcore/eri/enuc must be given");
-    if (!energy_only) {
+    EVC_REQUIRE(gb, "%s: null batch descriptor", who);
+    EVC_REQUIRE(gb->count >= 1 && gb->count <= 4096, "%s: batch count=%d out of range", who, gb->count);
+    EVC_REQUIRE(gb->S && gb->hcore && gb->eri && gb->enuc, "%s: batch geometry: S/hcore/eri/enuc must be given", who);
+    if (need_grad) {
         EVC_REQUIRE(gb->natm >= 1 && gb->ipovlp && gb->dhcore && gb->eri_ip1 && gb->aoslices && gb->gnuc,
-                    "batch geometry: ipovlp/dhcore/eri_ip1/gnuc/aoslices are required for the gradient");
-        EVC_REQUIRE(ob->grad, "batch outputs.grad is required unless EVC_FLAG_ENERGY_ONLY");
+                    "%s: batch geometry: ipovlp/dhcore/eri_ip1/gnuc/aoslices are required for the gradient", who);
+        EVC_REQUIRE(ob && ob->grad, "%s: batch outputs.grad is required", who);
     }
-    EVC_REQUIRE(ob->energy && ob->coeffs, "batch outputs.energy/coeffs are required");
-    EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
-    EVC_REQUIRE(t->rows2 == t->rows2_total && t->row_offset == 0,
-                "evc_energy_with_grad_batch needs the complete t-RDM on this device");
-    EVC_REQUIRE(ws && aligned16(ws), "workspace NULL or misaligned");
-    Ws w;
+    EVC_REQUIRE(ws && aligned16(ws), "%s: workspace NULL or misaligned", who);
     carve(t, gb->natm, static_cast<char *>(ws), w);
-    EVC_REQUIRE(ws_bytes >= w.bytes * (size_t)gb->count, "workspace too small: %zu < %zu", ws_bytes,
+    EVC_REQUIRE(ws_bytes >= w.bytes * (size_t)gb->count, "%s: workspace too small: %zu < %zu", who, ws_bytes,
                 w.bytes * (size_t)gb->count);
-    hipStream_t st = as_stream(stream);
     const int64_t n = t->n, n2 = n * n, n4 = n2 * n2, T = t->ntrain, A = gb->natm;
-    Geo g;
     memset(&g, 0, sizeof(g));
     g.natm = gb->natm;
     g.count = gb->count;
@@ -687,25 +682,81 @@ extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geome
     g.sgn = A * 3;
     g.aoslices = gb->aoslices;
     g.enuc_dev = gb->enuc;
-    Out o;
     memset(&o, 0, sizeof(o));
-    o.energy = ob->energy;
-    o.se = T;
-    o.coeffs = ob->coeffs;
-    o.sc = T * T;
-    o.grad = ob->grad;
-    o.sg = A * 3;
-    o.d_pred = ob->d_pred;
-    o.sd = n2;
-    o.g_pred = ob->g_pred;
-    o.sG = n4;
-    o.hmat = ob->hmat;
-    o.sH = T * T;
+    if (ob) {
+        o.energy = ob->energy;
+        o.se = T;
+        o.coeffs = ob->coeffs;
+        o.sc = T * T;
+        o.grad = ob->grad;
+        o.sg = A * 3;
+        o.d_pred = ob->d_pred;
+        o.sd = n2;
+        o.g_pred = ob->g_pred;
+        o.sG = n4;
+        o.hmat = ob->hmat;
+        o.sH = T * T;
+    }
+    return 0;
+}
+
+extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
+                                          const evc_outputs_batch *ob, int nroots, int flags, void *ws,
+                                          size_t ws_bytes, void *stream) {
+    const bool energy_only = (flags & EVC_FLAG_ENERGY_ONLY) != 0;
+    Ws w;
+    Geo g;
+    Out o;
+    if (setup_batch("evc_energy_with_grad_batch", t, gb, ob, !energy_only, ws, ws_bytes, w, g, o)) return -1;
+    EVC_REQUIRE(ob && ob->energy && ob->coeffs, "batch outputs.energy/coeffs are required");
+    EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
+    EVC_REQUIRE(t->rows2 == t->rows2_total && t->row_offset == 0,
+                "evc_energy_with_grad_batch needs the complete t-RDM on this device (use the phase calls when sharded)");
+    hipStream_t st = as_stream(stream);
     int rc;
     if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
-    if ((rc = phase_solve(t, g, nullptr, o, nroots, w, st))) return rc;
+    if ((rc = phase_solve(t, g, nullptr, 0, o, nroots, w, st))) return rc;
     if (energy_only) return 0;
     return phase_gradient(t, g, o, 0, w, st);
+}
+
+extern "C" int evc_phase_hamiltonian_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, double *rows_out,
+                                           int64_t ld_rows_out, void *ws, size_t ws_bytes, void *stream) {
+    Ws w;
+    Geo g;
+    Out o;
+    if (setup_batch("evc_phase_hamiltonian_batch", t, gb, nullptr, false, ws, ws_bytes, w, g, o)) return -1;
+    EVC_REQUIRE(t->rows2 == 0 || (rows_out && ld_rows_out >= t->rows2),
+                "evc_phase_hamiltonian_batch: rows_out NULL or ld_rows_out=%lld < rows2=%lld", (long long)ld_rows_out,
+                (long long)t->rows2);
+    return phase_hamiltonian(t, g, w, true, as_stream(stream), rows_out, ld_rows_out);
+}
+
+extern "C" int evc_phase_solve_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, const double *h2rows_all,
+                                     int64_t ld_rows_all, const evc_outputs_batch *ob, int nroots, void *ws,
+                                     size_t ws_bytes, void *stream) {
+    Ws w;
+    Geo g;
+    Out o;
+    if (setup_batch("evc_phase_solve_batch", t, gb, ob, false, ws, ws_bytes, w, g, o)) return -1;
+    EVC_REQUIRE(ob && ob->energy && ob->coeffs, "batch outputs.energy/coeffs are required");
+    EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
+    EVC_REQUIRE(h2rows_all && ld_rows_all >= t->rows2_total,
+                "evc_phase_solve_batch: h2rows_all NULL or ld_rows_all=%lld < rows2_total=%lld",
+                (long long)ld_rows_all, (long long)t->rows2_total);
+    replan(t, w, g.count);
+    return phase_solve(t, g, h2rows_all, ld_rows_all, o, nroots, w, as_stream(stream));
+}
+
+extern "C" int evc_phase_gradient_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
+                                        const evc_outputs_batch *ob, int flags, void *ws, size_t ws_bytes,
+                                        void *stream) {
+    Ws w;
+    Geo g;
+    Out o;
+    if (setup_batch("evc_phase_gradient_batch", t, gb, ob, true, ws, ws_bytes, w, g, o)) return -1;
+    replan(t, w, g.count);
+    return phase_gradient(t, g, o, flags, w, as_stream(stream));
 }
 
 extern "C" int evc_subspace_solve(const double *h1rows, const double *h2rows, const double *S_train, int T,

@@ -1,16 +1,21 @@
 """Pair-sharded multi-GPU evaluation: one process per GPU, each rank holds a
-contiguous slice of the two-body t-RDM rows (training pairs).  Per geometry:
+contiguous slice of the two-body t-RDM rows (training pairs).  Per geometry (or per batch of G
+geometries, replicated on every rank):
 
     phase A (local)   Loewdin + integrals (replicated, cheap) + H rows of the local pairs
-    all_gather        the scaled H rows           -- P doubles in total (KB-sized)
+    all_gather        the scaled H rows           -- G*P doubles in total (KB-sized)
     phase B (local)   identical T x T eigensolve on every rank (no broadcast of c needed)
     phase C (local)   partial predicted 2-RDM of the local pairs pushed through the gradient,
                       which is LINEAR in it (``ab_initio_gradients_loewdin.py:210-252,300-303``);
                       rank 0 alone adds the one-body and nuclear terms
-    all_reduce(SUM)   the (A,3) gradient          -- 720 B at A=30
+    all_reduce(SUM)   the (G,A,3) gradient        -- 720 B per geometry at A=30
 
 ``torch.distributed`` with backend "nccl" is RCCL over xGMI on ROCm; the same code runs on
 "gloo" for the CPU tests, where the three phases are supplied by a test double.
+
+The other way to use N GPUs — independent geometries on independent GPUs against replicated
+t-RDMs — needs no collective at all and no code here: every rank runs its own
+``evaluator.BatchedEvaluator`` (bench.py ``--shard geometries``).
 """
 from __future__ import annotations
 
@@ -29,8 +34,11 @@ def shard_rows(rows_total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 class PairShardedContinuation:
-    """Drives a per-rank evaluator (``evaluator.ContinuationEvaluator`` on its row slice, or any
-    object with the same three phase methods and ``grad``/``energy`` tensors) and the two collectives."""
+    """Drives a per-rank evaluator on its row slice and the two collectives.
+
+    ``evaluator`` is an ``evaluator.ContinuationEvaluator`` (one geometry per call) or an
+    ``evaluator.BatchedEvaluator`` (``count`` geometries per call; recognised by its ``count``
+    attribute), or any object with the same three phase methods and ``grad``/``energy`` tensors."""
 
     def __init__(self, evaluator, rows_total: int, group: Optional[dist.ProcessGroup] = None):
         self.ev = evaluator
@@ -40,25 +48,53 @@ class PairShardedContinuation:
         self.rows_total = int(rows_total)
         self.chunk = -(-self.rows_total // self.world)
         self.r0, self.r1 = shard_rows(self.rows_total, self.world, self.rank)
+        self.count = getattr(evaluator, "count", None)      # None: single-geometry evaluator
         dev = evaluator.grad.device
-        self._send = torch.zeros(self.chunk, dtype=torch.float64, device=dev)
-        self._recv = torch.zeros(self.chunk * self.world, dtype=torch.float64, device=dev)
+        G = self.count or 1
+        self._send = torch.zeros((G, self.chunk), dtype=torch.float64, device=dev)
+        self._recv = torch.zeros((self.world, G, self.chunk), dtype=torch.float64, device=dev)
+        self._rows_all = torch.zeros((G, self.world * self.chunk), dtype=torch.float64, device=dev)
 
     def enqueue(self, ao, nroots: int = 1, energy_only: bool = False) -> None:
-        rows_local = self.ev.phase_hamiltonian(ao)
+        """Enqueue one (batched) evaluation.  The collectives are ordered against torch's CURRENT stream,
+        so an evaluator bound to a private stream is driven with that stream made current."""
+        st = getattr(self.ev, "stream", None)
+        if st is not None:
+            with torch.cuda.stream(st):
+                self._enqueue(ao, nroots, energy_only)
+        else:
+            self._enqueue(ao, nroots, energy_only)
+
+    def _enqueue(self, ao, nroots: int, energy_only: bool) -> None:
         n_local = self.r1 - self.r0
-        if n_local:
-            self._send[:n_local].copy_(rows_local[:n_local])
-        dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
-        rows_all = self._recv[: self.rows_total]      # chunks are contiguous and only the tail is padding
-        self.ev.phase_solve(ao, rows_all.contiguous(), nroots)
+        if self.count is None:
+            rows_local = self.ev.phase_hamiltonian(ao)
+            if n_local:
+                self._send[0, :n_local].copy_(rows_local[:n_local])
+        else:
+            self.ev.phase_hamiltonian(ao, self._send)
+        dist.all_gather_into_tensor(self._recv.view(-1), self._send.view(-1), group=self.group)
+        # (rank, g, r) -> (g, rank*chunk + r): the chunks of one geometry are then contiguous in pair
+        # order and only the tail of the last chunk is padding
+        self._rows_all.view(-1, self.world, self.chunk).copy_(self._recv.permute(1, 0, 2))
+        if self.count is None:
+            self.ev.phase_solve(ao, self._rows_all[0, : self.rows_total], nroots)
+        else:
+            self.ev.phase_solve(ao, self._rows_all, nroots)
         if energy_only:
             return
         self.ev.phase_gradient(ao, partial_rank=(self.rank != 0))
         dist.all_reduce(self.ev.grad, op=dist.ReduceOp.SUM, group=self.group)
 
-    def energy_with_grad(self, ao):
-        self.enqueue(ao)
+    def _sync(self):
         if self.ev.grad.is_cuda:
-            torch.cuda.current_stream(self.ev.grad.device).synchronize()
-        return float(self.ev.energy[0].item()), self.ev.grad.cpu().numpy().copy()
+            st = getattr(self.ev, "stream", None)
+            (st if st is not None else torch.cuda.current_stream(self.ev.grad.device)).synchronize()
+
+    def energy_with_grad(self, ao):
+        """Single-geometry evaluators: (E, grad (A,3)).  Batched: (E (G,), grad (G,A,3))."""
+        self.enqueue(ao)
+        self._sync()
+        if self.count is None:
+            return float(self.ev.energy[0].item()), self.ev.grad.cpu().numpy().copy()
+        return self.ev.energy[:, 0].cpu().numpy().copy(), self.ev.grad.cpu().numpy().copy()

@@ -243,7 +243,7 @@ class DeviceAOBatch:
 
 class BatchedEvaluator:
     """``count`` independent geometries per call (``evc_energy_with_grad_batch``): every launch covers
-    the whole batch and the t-RDM is streamed once per 8 geometries.  Results stay on the device in
+    the whole batch and the t-RDM is streamed once per up to 16 geometries.  Results stay on the device in
     ``energy (G,T)``, ``coeffs (G,T,T)``, ``grad (G,A,3)``."""
 
     def __init__(self, trdms: DeviceTRDMs, natm: int, count: int, stream: Optional["torch.cuda.Stream"] = None,
@@ -288,6 +288,32 @@ class BatchedEvaluator:
         if not np.all(np.isfinite(e)):
             raise np.linalg.LinAlgError("generalised eigenproblem failed for at least one geometry of the batch")
         return e, self.grad[:, : self.natm].cpu().numpy().copy()
+
+    # -- phase API for the pair-sharded multi-GPU host (evcont_amd/distributed.py) -----------------
+    def phase_hamiltonian(self, aob: DeviceAOBatch, rows_out: torch.Tensor) -> None:
+        """Scaled two-body rows of this rank's pairs -> ``rows_out[g, :rows_local]`` (row stride = rows_out.stride(0))."""
+        assert rows_out.dtype == F64 and rows_out.dim() == 2 and rows_out.shape[0] == self.count
+        assert rows_out.stride(1) == 1 and rows_out.shape[1] >= self.t.rows_local
+        g = aob.cstruct()
+        rc = self.lib.evc_phase_hamiltonian_batch(C.byref(self.t.cstruct), C.byref(g), rows_out.data_ptr(),
+                                                  int(rows_out.stride(0)), self.ws.data_ptr(), self.ws_bytes, self._sp())
+        check(rc, "evc_phase_hamiltonian_batch")
+
+    def phase_solve(self, aob: DeviceAOBatch, rows_all: torch.Tensor, nroots: int = 1) -> None:
+        assert rows_all.dtype == F64 and rows_all.dim() == 2 and rows_all.shape[0] == self.count
+        assert rows_all.stride(1) == 1 and rows_all.shape[1] >= self.t.rows_total
+        g = aob.cstruct()
+        rc = self.lib.evc_phase_solve_batch(C.byref(self.t.cstruct), C.byref(g), rows_all.data_ptr(),
+                                            int(rows_all.stride(0)), C.byref(self.out), int(nroots),
+                                            self.ws.data_ptr(), self.ws_bytes, self._sp())
+        check(rc, "evc_phase_solve_batch")
+
+    def phase_gradient(self, aob: DeviceAOBatch, partial_rank: bool) -> None:
+        g = aob.cstruct()
+        rc = self.lib.evc_phase_gradient_batch(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out),
+                                               _lib.FLAG_PARTIAL_RANK if partial_rank else 0, self.ws.data_ptr(),
+                                               self.ws_bytes, self._sp())
+        check(rc, "evc_phase_gradient_batch")
 
 
 class ContinuationEvaluator:

@@ -183,7 +183,7 @@ int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g, const evc
 /* ---------------------------------------------------------------------------------
  * Batched form: `count` independent geometries of the SAME molecule (same N, A, aoslices) per call.
  * Every launch of the pipeline covers the whole batch, and the two streaming kernels read the
- * t-RDM ONCE for up to 8 geometries (K5 becomes (rows,cols)x(cols,G), K8 (G,rows)x(rows,cols)),
+ * t-RDM ONCE for up to 16 geometries (K5 becomes (rows,cols)x(cols,G), K8 (G,rows)x(rows,cols)),
  * so the HBM cost of the t-RDM per evaluation drops by the batch size.  This is the throughput
  * form for PES scans / batched re-evaluations; an MD run is count = 1.
  * All arrays are stacked along a leading batch axis, C order.
@@ -215,6 +215,20 @@ size_t evc_workspace_bytes_batch(const evc_trdm_set *t, int natm, int count);
 int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
                                const evc_outputs_batch *ob, int nroots, int flags, void *ws,
                                size_t ws_bytes, void *stream);
+
+/* The three phases of the pair-sharded evaluation for a batch (t may hold a row slice).
+ * A: writes the scaled two-body rows of this rank to rows_out[g*ld_rows_out + r], r < t->rows2
+ *    (caller's buffer: the send buffer of the all-gather).
+ * B: h2rows_all[g*ld_rows_all + p], p < t->rows2_total, is the gathered row vector of geometry g.
+ * C: as evc_phase_gradient; with EVC_FLAG_PARTIAL_RANK ob->grad receives only the two-body share. */
+int evc_phase_hamiltonian_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, double *rows_out,
+                                int64_t ld_rows_out, void *ws, size_t ws_bytes, void *stream);
+int evc_phase_solve_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, const double *h2rows_all,
+                          int64_t ld_rows_all, const evc_outputs_batch *ob, int nroots, void *ws,
+                          size_t ws_bytes, void *stream);
+int evc_phase_gradient_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
+                             const evc_outputs_batch *ob, int flags, void *ws, size_t ws_bytes,
+                             void *stream);
 
 /* Gradient of given (not predicted) RDMs: get_grad_elec_OAO (ab_initio_gradients_loewdin.py:255-305).
  * `trafo` = caller's ao_mo_trafo (N,N) or NULL for the Loewdin trafo of g->S; the trafo derivative is

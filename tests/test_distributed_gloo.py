@@ -107,3 +107,73 @@ def test_pair_sharded_matches_single(world, T):
         for r in res:
             assert abs(r[ie] - Eref) < 1e-11              # every rank holds the same energy
             np.testing.assert_allclose(r[ig], gref, rtol=0, atol=1e-10)   # ... and the reduced gradient
+
+
+class OraclePhasesBatch:
+    """Batched counterpart (evaluator.BatchedEvaluator phase API): `count` geometries per call, the rows go
+    into the caller's (count, chunk) buffer."""
+
+    def __init__(self, one, two_packed_rows, S, r0, rows_total, natm, count):
+        self.count = count
+        self.one_ev = [OraclePhases(one, two_packed_rows, S, r0, rows_total, natm) for _ in range(count)]
+        self.grad = torch.zeros((count, natm, 3), dtype=torch.float64)
+        self.energy = torch.zeros((count, S.shape[0]), dtype=torch.float64)
+
+    def phase_hamiltonian(self, aos, rows_out):
+        assert rows_out.shape[0] == self.count
+        for g, (ev, ao) in enumerate(zip(self.one_ev, aos)):
+            rows = ev.phase_hamiltonian(ao)
+            rows_out[g, : rows.numel()].copy_(rows)
+
+    def phase_solve(self, aos, rows_all, nroots=1):
+        P = self.one_ev[0].rows_total
+        for g, (ev, ao) in enumerate(zip(self.one_ev, aos)):
+            ev.phase_solve(ao, rows_all[g, :P], nroots)
+            self.energy[g] = ev.energy
+
+    def phase_gradient(self, aos, partial_rank):
+        for g, (ev, ao) in enumerate(zip(self.one_ev, aos)):
+            ev.phase_gradient(ao, partial_rank)
+            self.grad[g] = ev.grad
+
+
+def _worker_batch(rank, world, port, n, T, A, seeds, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, one, two = make_trdms(n, T, 6)
+        packed = pack_rows(two, True, True)
+        rows = packed.shape[0]
+        r0, r1 = shard_rows(rows, world, rank)
+        ev = OraclePhasesBatch(one, packed[r0:r1], S, r0, rows, A, len(seeds))
+        drv = PairShardedContinuation(ev, rows)
+        E, g = drv.energy_with_grad([make_ao_arrays(n, A, s) for s in seeds])
+        q.put((rank, E, g))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(2, 3), (3, 2)])
+def test_pair_sharded_batch_matches_single(world, T):
+    """Batched driver: (G, chunk) send buffer, (world, G, chunk) gather and its re-ordering to pair order."""
+    n, A, seeds = 4, 2, (5, 7, 9)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_batch, args=(r, world, port, n, T, A, seeds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    S, one, two = make_trdms(n, T, 6)
+    packed = pack_rows(two, True, True)
+    for k, seed in enumerate(seeds):
+        ao = make_ao_arrays(n, A, seed)
+        b = orc.AOBundle(ao.S, ao.hcore, ao.eri, ao.ipovlp, ao.dhcore, ao.eri_ip1, ao.aoslices, ao.enuc, ao.gnuc)
+        Eref, gref = orc.energy_with_grad(b, one, packed, S)
+        for r in res:
+            assert abs(r[1][k] - Eref) < 1e-11
+            np.testing.assert_allclose(r[2][k], gref, rtol=0, atol=1e-10)

@@ -56,3 +56,40 @@ def test_batch_golden(load_golden):
         assert abs(E[k] - float(g["ewg_E_pack2"])) < 1e-10
         np.testing.assert_allclose(grad[k], g["ewg_grad_pack2"], rtol=0, atol=1e-9)
     assert abs(E[1] - E[3]) < 1e-13 and abs(E[0] - E[1]) > 1e-6
+
+
+@pytest.mark.parametrize("lname", ["pack2", "full6"])
+@pytest.mark.parametrize("world,G", [(2, 3), (3, 16)])
+def test_batched_phase_api_emulated_pair_sharding(lname, world, G):
+    """Batched three-phase entry points on row slices (one BatchedEvaluator per emulated rank); the two
+    collectives are emulated on one device exactly as distributed.PairShardedContinuation lays them out:
+    (G, chunk) send buffers -> (world, G, chunk) -> (G, world*chunk); partial gradients summed."""
+    from evcont_amd.evaluator import (DeviceTRDMs, DeviceAO, DeviceAOBatch, BatchedEvaluator, layout_shape)
+    from evcont_amd.distributed import shard_rows
+    dev = torch.device("cuda:0")
+    n, T, A = 6, 4, 3
+    S, one, two = make_trdms(n, T, 77)
+    two_l = layout(two, lname)
+    rows, _ = layout_shape(two_l.ndim, T, n)
+    aob = DeviceAOBatch.stack([DeviceAO.from_arrays(make_ao_arrays(n, A, 900 + k), dev) for k in range(G)])
+    full = BatchedEvaluator(DeviceTRDMs(one, two_l, S, dev), A, G)
+    Eref, gref = full.energies_with_grads(aob)
+    chunk = -(-rows // world)
+    evs, send = [], []
+    for r in range(world):
+        r0, r1 = shard_rows(rows, world, r)
+        evs.append(BatchedEvaluator(DeviceTRDMs(one, two_l, S, dev, row_range=(r0, r1)), A, G))
+        buf = torch.zeros((G, chunk), dtype=torch.float64, device=dev)
+        evs[-1].phase_hamiltonian(aob, buf)
+        send.append(buf)
+    recv = torch.stack(send)                                   # (world, G, chunk) = all_gather_into_tensor
+    rows_all = recv.permute(1, 0, 2).reshape(G, world * chunk).contiguous()
+    total = torch.zeros_like(evs[0].grad)
+    for r, ev in enumerate(evs):
+        ev.phase_solve(aob, rows_all, 1)
+        ev.phase_gradient(aob, partial_rank=(r != 0))
+        total += ev.grad
+    torch.cuda.synchronize()
+    for ev in evs:
+        np.testing.assert_allclose(ev.energy[:, 0].cpu().numpy(), Eref, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(total.cpu().numpy(), gref, rtol=0, atol=1e-10)
