@@ -124,6 +124,180 @@ __global__ __launch_bounds__(256) void gemv_rows_mfma_kernel(GemvRowsLaunch L, i
     }
 }
 
+// Software-pipelined variant (the default).  Block = (column span, row group of <= kRG 16-row tiles);
+// the tiles of the matrix are dealt to BALANCED row groups (a group with one or two tiles costs a
+// block almost as much as a full one: its chunk steps are latency bound either way).  The four waves
+// interleave the 32-column chunks of the span; a wave keeps the V fragments of a chunk in registers
+// for all tiles of the group and issues the loads of its NEXT chunk before the MFMAs of the current
+// one (two register buffers).  The steady-state loop body is branch-free so that the compiler's vmcnt
+// bookkeeping really leaves the younger loads in flight across the MFMAs (a conditional prefetch
+// makes it wait for vmcnt(0)).  The MFMAs of a pass add up to ~60 us of pipe time per SIMD at
+// H30/T=20, G=16.  Block -> (span, row group) is XCD-aware: workgroups are dealt round-robin to the
+// 8 XCDs, each with its own L2, so the row groups of one span (which re-read the same V tile) get
+// block ids that are congruent mod 8.
+// Measured (tools/micro/rows_insitu.hip, 210 x 405450, G=16): 146 us with groups of <= 3 tiles,
+// 165 us with <= 4, 160 us with <= 2; wider groups (5..7 tiles, alternating half-chunk buffers) ran
+// out of registers at two waves per SIMD and were slower (200 us).
+#define EVC_LD_B(B_, C_)                                                                             \
+    {                                                                                                \
+        const int64_t cc_ = (C_) + 2 * l4;                                                           \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) B_[u] = ld2(vr + cc_ + 8 * u);                 \
+    }
+#define EVC_LD_A(A_, T0_, N_, C_)                                                                    \
+    {                                                                                                \
+        const int64_t cc_ = (C_) + 2 * l4;                                                           \
+        _Pragma("unroll") for (int tt = 0; tt < (N_); ++tt)                                          \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) A_[tt][u] = ld2(ar[(T0_) + tt] + cc_ + 8 * u); \
+    }
+#define EVC_LD_A_GUARD(A_, T0_, N_, C_)                                                              \
+    {                                                                                                \
+        const int64_t cc_ = (C_) + 2 * l4;                                                           \
+        _Pragma("unroll") for (int tt = 0; tt < (N_); ++tt)                                          \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                            \
+                A_[tt][u] = ld2_guard(ar[(T0_) + tt], cc_ + 8 * u, cols);                            \
+    }
+#define EVC_MMA(A_, T0_, N_, B_)                                                                     \
+    {                                                                                                \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+            _Pragma("unroll") for (int tt = 0; tt < (N_); ++tt)                                      \
+                acc[(T0_) + tt] = mfma_f64(A_[tt][u].x, B_[u].x, acc[(T0_) + tt]);                   \
+            _Pragma("unroll") for (int tt = 0; tt < (N_); ++tt)                                      \
+                acc[(T0_) + tt] = mfma_f64(A_[tt][u].y, B_[u].y, acc[(T0_) + tt]);                   \
+        }                                                                                            \
+    }
+
+constexpr int kRG = 4;  // most 16-row tiles per row group (register budget of two waves per SIMD)
+
+// One wave's share of a (span, row group) block with NT live 16-row tiles.  Lanes whose geometry slot
+// l15 is >= G read geometry g0's vector (a valid address) and their output columns are discarded.
+template <int NT, int MAXT>
+__device__ __forceinline__ void rows_pipe_body(const RowProblem &P, int64_t row_base, int64_t cbeg, int64_t cend,
+                                               const double *__restrict__ vr, int l15, int l4, int wave,
+                                               d4 (&acc)[MAXT]) {
+    const int64_t rows = P.rows, cols = P.cols, ld = P.ld;
+    const int64_t cfull = min(cend, cols & ~(int64_t)31);  // chunks starting below this are complete
+    constexpr int64_t kStep = 4 * kMC;
+    const double *__restrict__ ar[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) ar[tt] = P.A + min(row_base + 16 * tt + l15, rows - 1) * ld;
+    int64_t c = cbeg + wave * kMC;
+    const int64_t nfull = c < cfull ? (cfull - c + kStep - 1) / kStep : 0;  // complete chunks of this wave
+    double2 b0[4], b1[4];
+    {
+        double2 a0[NT][4], a1[NT][4];
+        if (nfull > 0) {
+            EVC_LD_B(b0, c);
+            EVC_LD_A(a0, 0, NT, c);
+            int64_t i = 1;
+            for (; i + 1 < nfull; i += 2) {
+                EVC_LD_B(b1, c + i * kStep);
+                EVC_LD_A(a1, 0, NT, c + i * kStep);
+                EVC_MMA(a0, 0, NT, b0);
+                EVC_LD_B(b0, c + (i + 1) * kStep);
+                EVC_LD_A(a0, 0, NT, c + (i + 1) * kStep);
+                EVC_MMA(a1, 0, NT, b1);
+            }
+            if (i < nfull) {
+                EVC_LD_B(b1, c + i * kStep);
+                EVC_LD_A(a1, 0, NT, c + i * kStep);
+                EVC_MMA(a0, 0, NT, b0);
+                EVC_MMA(a1, 0, NT, b1);
+            } else {
+                EVC_MMA(a0, 0, NT, b0);
+            }
+            c += nfull * kStep;
+        }
+        if (c < cend) {  // the ragged last chunk of the matrix (at most one wave of one span per row group)
+            const int64_t cc = c + 2 * l4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b0[u] = ld2_guard(vr, cc + 8 * u, cols);
+            EVC_LD_A_GUARD(a0, 0, NT, c);
+            EVC_MMA(a0, 0, NT, b0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemv_rows_mfma_pipe_kernel(GemvRowsLaunch L, int g0, int G) {
+    constexpr int MAXT = kRG;
+    __shared__ double red[4][4][4][64];  // [wave][tile][reg][lane]
+    int b = blockIdx.x;
+    int which, span, rg;
+    if (b < L.nblk1) {  // the few blocks of the small second problem are dispatched first
+        which = 1;
+        const int nrg1 = L.nrg[1];
+        span = b / nrg1;
+        rg = b - span * nrg1;
+        if (span >= L.p[1].nspans) return;
+    } else {
+        which = 0;
+        b -= L.nblk1;  // nblk1 is a multiple of 8: b & 7 is still the XCD this block was dealt to
+        const int nrg0 = L.nrg[0];
+        const int xcd = b & 7, idx = b >> 3;
+        const int j = idx / nrg0;
+        rg = idx - j * nrg0;
+        span = j * 8 + xcd;
+        if (span >= L.p[0].nspans) return;
+    }
+    const RowProblem &P = L.p[which];
+    const int64_t rows = P.rows;
+    const int tpg = L.tpg[which], trem = L.trem[which];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t row_base = (int64_t)(rg * tpg + min(rg, trem)) * 16;
+    const int ntile = tpg + (rg < trem ? 1 : 0);  // tiles of this row group (the last one may be ragged)
+    const int64_t cbeg = (int64_t)span * P.cps * 512;
+    const int64_t cend = min(P.cols, (int64_t)(span + 1) * P.cps * 512);
+    const double *__restrict__ vr = P.v + (int64_t)(g0 + (l15 < G ? l15 : 0)) * P.vstride;
+    d4 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (ntile == 4) rows_pipe_body<4, MAXT>(P, row_base, cbeg, cend, vr, l15, l4, wave, acc);  // wave-uniform
+    else if (ntile == 3) rows_pipe_body<3, MAXT>(P, row_base, cbeg, cend, vr, l15, l4, wave, acc);
+    else if (ntile == 2) rows_pipe_body<2, MAXT>(P, row_base, cbeg, cend, vr, l15, l4, wave, acc);
+    else if (ntile == 1) rows_pipe_body<1, MAXT>(P, row_base, cbeg, cend, vr, l15, l4, wave, acc);
+    // cross-wave sum, four tiles per pass
+#pragma unroll
+    for (int h = 0; h < (MAXT + 3) / 4; ++h) {
+        if (h * 4 < ntile) {
+            if (h) __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                if (h * 4 + tt < MAXT)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave][tt][r][lane] = acc[h * 4 + tt][r];
+            __syncthreads();
+            for (int idx = tid; idx < 4 * 4 * 64; idx += 256) {
+                const int ln = idx & 63, r = (idx >> 6) & 3, tt = idx >> 8;
+                const int t = h * 4 + tt;
+                const int64_t row = row_base + t * 16 + (ln >> 4) + 4 * r;
+                const int g = ln & 15;
+                if (t < ntile && row < rows && g < G) {
+                    const double s =
+                        (red[0][tt][r][ln] + red[1][tt][r][ln]) + (red[2][tt][r][ln] + red[3][tt][r][ln]);
+                    P.partial[(int64_t)(g0 + g) * P.pstride + (int64_t)span * rows + row] = s;
+                }
+            }
+        }
+    }
+}
+
+static void rows_mfma_pipe_launch(GemvRowsLaunch L, int g0, int G, int max_tiles, hipStream_t st) {
+    int *nrg = L.nrg;
+    for (int k = 0; k < 2; ++k) {
+        // balanced row groups of at most max_tiles tiles
+        const int nt = (int)ceil_div(L.p[k].rows > 0 ? L.p[k].rows : 1, 16);
+        nrg[k] = (int)ceil_div(nt, max_tiles);
+        L.tpg[k] = nt / nrg[k];
+        L.trem[k] = nt % nrg[k];
+        if (!L.p[k].nblocks) L.p[k].nspans = 0;
+    }
+    const int nb0 = L.p[0].nblocks ? 8 * nrg[0] * (int)ceil_div(L.p[0].nspans, 8) : 0;
+    const int nb1 = L.p[1].nblocks ? (int)ceil_div((int64_t)nrg[1] * L.p[1].nspans, 8) * 8 : 0;
+    L.nblk0 = nb0;
+    L.nblk1 = nb1;
+    hipLaunchKernelGGL(gemv_rows_mfma_pipe_kernel, dim3(nb0 + nb1), dim3(256), 0, st, L, g0, G);
+}
+
 template <int RT>
 static void rows_mfma_launch(GemvRowsLaunch L, int g0, int G, hipStream_t st) {
     for (int k = 0; k < 2; ++k)
@@ -133,7 +307,8 @@ static void rows_mfma_launch(GemvRowsLaunch L, int g0, int G, hipStream_t st) {
 }
 
 int launch_gemv_rows_mfma(const GemvRowsLaunch &L, int g0, int G, int tiles, hipStream_t st) {
-    if (tiles == 4) rows_mfma_launch<4>(L, g0, G, st);
+    if (tiles <= 0) rows_mfma_pipe_launch(L, g0, G, tiles == 0 ? 3 : (-tiles > kRG ? kRG : -tiles), st);
+    else if (tiles == 4) rows_mfma_launch<4>(L, g0, G, st);
     else if (tiles == 8) rows_mfma_launch<8>(L, g0, G, st);
     else rows_mfma_launch<16>(L, g0, G, st);
     EVC_LAUNCH_CHECK("gemv_rows_mfma");

@@ -271,7 +271,7 @@ int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     static const int v8 = env_int("EVC_ROWS_G8", 0);   // 0: wave-rows kernel RBW=4; 1: lane-private RB=2
     static const int v4 = env_int("EVC_ROWS_G4", 0);   // 0: wave-rows RBW=8; 1: wave-rows RBW=4; 2: lane-private RB=4
     static const int mfma_min = env_int("EVC_MFMA_MIN_G", 12);   // groups of >= this many geometries use the matrix cores
-    static const int mfma_tiles = env_int("EVC_MFMA_TILES", 4);
+    static const int mfma_tiles = env_int("EVC_MFMA_TILES", 0);   // 0: pipelined 4-tile kernel; 4/8/16: un-pipelined variants
     int g0 = 0;
     while (g0 < count) {
         const int left = count - g0;

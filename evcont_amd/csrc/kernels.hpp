@@ -22,6 +22,10 @@ struct RowProblem {
 struct GemvRowsLaunch {
     RowProblem p[2];
     int nblk0;
+    int nblk1;  // matrix-core variant: blocks of p[1] (padded to a multiple of 8), dispatched first
+    // matrix-core variant: the 16-row tiles of p[k] are dealt to nrg[k] balanced row groups, the first
+    // trem[k] of which have tpg[k] + 1 tiles and the others tpg[k]
+    int tpg[2], trem[2], nrg[2];
 };
 struct ColProblem {
     const double *A;  // (rows, ld)                        shared by the batch
