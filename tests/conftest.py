@@ -33,6 +33,13 @@ def load_golden():
     return _load
 
 
+@pytest.fixture(scope="session")
+def h10_fci():
+    """H10 / STO-3G / 5 FCI training states with physical integrals (tests/golden/make_h10_fci.py)."""
+    with np.load(os.path.join(GOLDEN_DIR, "h10_fci_t5.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
 def bundle_from_golden(g):
     """oracle.AOBundle from a golden dict (tests only)."""
     from oracle.evcont_oracle import AOBundle

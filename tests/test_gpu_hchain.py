@@ -1,0 +1,83 @@
+"""GPU tests on PHYSICAL inputs (hydrogen chains, STO-3G; BASELINE configs 0-1): the HIP path through
+the reference-shaped API against the oracle, against independently computed FCI energies at the
+training geometries, and against finite differences of its own energies; plus the FCI training-data
+container (growth / prune / device-resident copy)."""
+import numpy as np
+import pytest
+import torch
+
+from evcont_amd.hchain import s_gaussian_mol, hydrogen_chain
+from evcont_amd.fci_small import SmallFCI
+from oracle import evcont_oracle as orc
+from test_hchain_physics import bundle, bent_chain, chain, fd, train
+
+pytestmark = pytest.mark.gpu
+
+
+def test_h10_fci_training_states_energy_and_force(h10_fci):
+    """configs[1]: H10 chain, 5 FCI training states, energy+force on the GPU vs the CPU path."""
+    from evcont_amd.ab_initio_gradients_loewdin import get_energy_with_grad
+    h10 = h10_fci
+    S, one, two = h10["overlap"], h10["one_rdm"], h10["two_rdm_pack2"]
+    for d, e_fci in zip(h10["spacings"], h10["ens"]):
+        m = hydrogen_chain(10, float(d))
+        E, g = get_energy_with_grad(m, one, two, S)
+        Eo, go = orc.energy_with_grad(bundle(m), one, two, S)
+        assert abs(E - Eo) < 1e-10 and np.abs(g - go).max() < 1e-9
+        assert abs(E - e_fci) < 1e-8                      # training point: the continuation is exact
+    m = s_gaussian_mol(h10["R_test"])
+    E, g = get_energy_with_grad(m, one, two, S)
+    Eo, go = orc.energy_with_grad(bundle(m), one, two, S)
+    assert abs(E - Eo) < 1e-10 and np.abs(g - go).max() < 1e-9
+    assert float(h10["e_fci_test"]) - 1e-9 <= E < float(h10["e_fci_test"]) + 0.15      # variational
+    assert np.abs(g.sum(axis=0)).max() < 1e-8             # no net force
+
+
+def test_h6_gpu_gradient_against_finite_differences_of_gpu_energies():
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
+    dev = torch.device("cuda:0")
+    S, one, two, _ = train([chain(6, d) for d in (1.5, 2.0, 2.8)])
+    ev = ContinuationEvaluator(DeviceTRDMs(one, two, S, dev), 6)
+    R = bent_chain(6, d=1.9, seed=11, amp=0.15)
+    E, g = ev.energy_with_grad(DeviceAO.from_arrays(s_gaussian_mol(R), dev))
+    energy = lambda r: np.float64(ev.energies(DeviceAO.from_arrays(s_gaussian_mol(r, need_grad=False), dev,
+                                                                    energy_only=True))[0][0])
+    g_fd = fd(energy, R, h=2e-4)
+    assert np.abs(g - g_fd).max() < 2e-7
+
+
+def test_fci_container_growth_prune_and_device_copy():
+    from evcont_amd.FCI_EVCont import FCI_EVCont_obj
+    from evcont_amd.ab_initio_gradients_loewdin import get_energy_with_grad
+    spacings = (1.5, 2.0, 2.8)
+    cont = FCI_EVCont_obj(cisolver=SmallFCI(), cibasis="OAO")
+    assert cont.overlap is None and cont.one_rdm is None and cont.two_rdm is None
+    for d in spacings:
+        cont.append_to_rdms(hydrogen_chain(6, d, need_grad=False))
+    S, one, two, ens = train([chain(6, d) for d in spacings])
+    assert cont.overlap.shape == (3, 3) and cont.two_rdm.shape == (3, 3, 6, 6, 6, 6)
+    assert cont.mol_index == [0, 1, 2] and len(cont.fcivecs) == 3
+    np.testing.assert_allclose(cont.ens, ens, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(cont.overlap, S, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(cont.one_rdm, one, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(cont.two_rdm, two, rtol=0, atol=1e-8)
+    # the reference API on the container's arrays: exact at a training geometry
+    E, _ = get_energy_with_grad(hydrogen_chain(6, 2.0), cont.one_rdm, cont.two_rdm, cont.overlap)
+    assert abs(E - ens[1]) < 1e-8
+    # device-resident packed copy: built once, rebuilt when the training set changes
+    t1 = cont.device_trdms()
+    assert t1 is cont.device_trdms() and t1.layout == 2 and t1.T == 3
+    from evcont_amd.evaluator import ContinuationEvaluator, DeviceAO
+    ev = ContinuationEvaluator(t1, 6)
+    E2, _ = ev.energy_with_grad(DeviceAO.from_arrays(hydrogen_chain(6, 2.0), t1.device))
+    assert abs(E2 - E) < 1e-10
+    full = (cont.overlap.copy(), cont.one_rdm.copy(), cont.two_rdm.copy())
+    cont.prune_datapoints([0, 2])
+    ix = np.ix_([0, 2], [0, 2])
+    assert np.array_equal(cont.overlap, full[0][ix]) and np.array_equal(cont.two_rdm, full[2][ix])
+    assert len(cont.fcivecs) == 2 and len(cont.ens) == 2
+    t2 = cont.device_trdms()
+    assert t2 is not t1 and t2.T == 2
+    # pruning a training point away: the continuation is no longer exact there, but still variational
+    E3, _ = ContinuationEvaluator(t2, 6).energy_with_grad(DeviceAO.from_arrays(hydrogen_chain(6, 2.0), t2.device))
+    assert E3 > ens[1] + 1e-7
