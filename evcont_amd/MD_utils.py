@@ -57,14 +57,62 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True):
 def get_trajectory(init_mol, overlap, one_rdm, two_rdm, dt=10.0, steps=10, init_veloc=None, hermitian=True,
                    trajectory_output=None, energy_output=None):
     """NVE trajectory from the continuation (reference :60-125).  Single process: the reference's
-    rank-0-computes / Bcast split exists only to coexist with MPI-parallel training code."""
-    from pyscf import md  # needs PySCF's integrator
+    rank-0-computes / Bcast split exists only to coexist with MPI-parallel training code.
+
+    PySCF molecules are propagated by ``pyscf.md.NVE`` exactly as in the reference; array-level molecules
+    that can be rebuilt at new coordinates (``with_coords``, e.g. ``evcont_amd.hchain.HChainMol``) by the
+    velocity-Verlet integrator below, with the same conventions (Bohr, atomic time units, frame 0 = the
+    initial geometry, ``steps`` frames)."""
     scanner_fun = get_scanner(init_mol, one_rdm, two_rdm, overlap, hermitian=hermitian)
+    if hasattr(init_mol, "with_coords"):
+        frames = nve_velocity_verlet(scanner_fun, init_mol, dt=dt, steps=steps, veloc=init_veloc,
+                                     trajectory_output=trajectory_output, energy_output=energy_output)
+        return np.array([f["coord"] for f in frames])
+    from pyscf import md  # needs PySCF's integrator
     frames = []
     integ = md.NVE(scanner_fun, dt=dt, steps=steps, veloc=init_veloc, incore_anyway=True, frames=frames,
                    trajectory_output=trajectory_output, energy_output=energy_output, verbose=0)
     integ.run()
     return np.array([frame.coord for frame in frames])
+
+
+AMU2AU = 1822.888486209      # atomic mass unit in electron masses (CODATA 2018)
+
+
+def nve_velocity_verlet(scanner, init_mol, dt=10.0, steps=10, veloc=None, trajectory_output=None,
+                        energy_output=None):
+    """Velocity-Verlet NVE propagation of an array-level molecule with ``scanner(mol) -> (E, grad)``.
+    Returns one frame per step: ``{"coord", "veloc", "epot", "ekin", "time"}`` (frame 0 = initial geometry);
+    the force of a step's end point is reused as the next step's start, so there is exactly one
+    energy+force evaluation per step."""
+    R = np.array(init_mol.atom_coords(), dtype=np.float64)
+    m = (np.asarray(init_mol.atom_mass_list(), dtype=np.float64) * AMU2AU)[:, None]
+    v = np.zeros_like(R) if veloc is None else np.array(veloc, dtype=np.float64)
+    mol = init_mol
+    e, g = scanner(mol)
+    frames = []
+    fe = open(energy_output, "w") if isinstance(energy_output, str) else energy_output
+    ft = open(trajectory_output, "w") if isinstance(trajectory_output, str) else trajectory_output
+    for k in range(steps):
+        ekin = 0.5 * float(np.sum(m * v * v))
+        frames.append({"coord": R.copy(), "veloc": v.copy(), "epot": float(e), "ekin": ekin, "time": k * dt})
+        if fe is not None:
+            fe.write(f"{k * dt:14.6f} {e:18.10f} {ekin:18.10f} {e + ekin:18.10f}\n")
+        if ft is not None:
+            ft.write(f"{R.shape[0]}\nMD time {k * dt:.6f} a.u., coordinates in Bohr\n")
+            for xyz in R:
+                ft.write("H %18.10f %18.10f %18.10f\n" % tuple(xyz))
+        if k == steps - 1:
+            break
+        a = -np.asarray(g) / m
+        R = R + dt * v + 0.5 * dt * dt * a
+        mol = init_mol.with_coords(R)
+        e, g = scanner(mol)
+        v = v + 0.5 * dt * (a - np.asarray(g) / m)
+    for f, given in ((fe, energy_output), (ft, trajectory_output)):
+        if f is not None and isinstance(given, str):
+            f.close()
+    return frames
 
 
 def converge_EVCont_MD(*args, **kwargs):

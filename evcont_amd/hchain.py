@@ -34,6 +34,9 @@ from .synthetic import AOArrays
 # STO-3G hydrogen 1s (zeta = 1.24): exponents and contraction coefficients of normalised primitives
 STO3G_H_EXPONENTS = (3.42525091, 0.62391373, 0.16885540)
 STO3G_H_COEFFICIENTS = (0.15432897, 0.53532814, 0.44463454)
+# STO-6G hydrogen 1s (the basis of scripts/PES_H_chain)
+STO6G_H_EXPONENTS = (35.52322122, 6.513143725, 1.822142904, 0.6259552659, 0.2430767471, 0.1001124280)
+STO6G_H_COEFFICIENTS = (0.009163596281, 0.04936149294, 0.1685383049, 0.3705627997, 0.4164915298, 0.1303340841)
 
 
 def boys01(t: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
@@ -61,12 +64,23 @@ class HChainMol(AOArrays):
     """``AOArrays`` of a geometry plus what the training-state generators ask a ``mol`` for."""
     coords: Optional[np.ndarray] = None   # (A,3) Bohr
     nelec: Tuple[int, int] = (0, 0)
+    charges: Optional[np.ndarray] = None
+    exponents: Tuple[float, ...] = STO3G_H_EXPONENTS
+    coefficients: Tuple[float, ...] = STO3G_H_COEFFICIENTS
 
     def energy_nuc(self) -> float:
         return float(self.enuc)
 
     def atom_coords(self) -> np.ndarray:
         return np.array(self.coords, copy=True)
+
+    def atom_mass_list(self) -> np.ndarray:
+        """Atomic masses in amu (hydrogen-like centres: 1.008 per unit charge is only right for H)."""
+        return np.full(self.natm, 1.008)
+
+    def with_coords(self, coords, need_grad: bool = True) -> "HChainMol":
+        """The same molecule (basis, charges, electrons) at new nuclear positions (Bohr)."""
+        return s_gaussian_mol(coords, self.charges, self.exponents, self.coefficients, need_grad, self.nelec)
 
 
 def s_gaussian_mol(coords, charges: Optional[Sequence[float]] = None,
@@ -180,7 +194,8 @@ def s_gaussian_mol(coords, charges: Optional[Sequence[float]] = None,
     if nelec is None:
         nelec = ((ne + 1) // 2, ne // 2)
     return HChainMol(S=S, hcore=hcore, eri=eri, ipovlp=ipovlp, dhcore=dhcore, eri_ip1=eri_ip1,
-                     aoslices=aoslices, enuc=float(enuc), gnuc=gnuc, coords=R, nelec=tuple(nelec))
+                     aoslices=aoslices, enuc=float(enuc), gnuc=gnuc, coords=R, nelec=tuple(nelec), charges=Z,
+                     exponents=tuple(float(x) for x in ex), coefficients=tuple(float(x) for x in co))
 
 
 def hydrogen_chain(natm: int, spacing: float, need_grad: bool = True) -> HChainMol:

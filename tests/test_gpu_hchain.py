@@ -81,3 +81,27 @@ def test_fci_container_growth_prune_and_device_copy():
     # pruning a training point away: the continuation is no longer exact there, but still variational
     E3, _ = ContinuationEvaluator(t2, 6).energy_with_grad(DeviceAO.from_arrays(hydrogen_chain(6, 2.0), t2.device))
     assert E3 > ens[1] + 1e-7
+
+
+def test_md_trajectory_conserves_energy(tmp_path):
+    """configs[3]-style MD inner loop: NVE trajectory of H6 driven by the continuation forces on the GPU
+    through get_trajectory / get_scanner.  The total energy is conserved up to the O(dt^2) error of
+    velocity Verlet — halving dt quarters the drift, which only happens when the forces are the exact
+    gradient of the energies."""
+    from evcont_amd.MD_utils import get_scanner, get_trajectory, nve_velocity_verlet
+    S, one, two, _ = train([chain(6, d) for d in (1.5, 2.0, 2.8)])
+    m0 = s_gaussian_mol(bent_chain(6, d=1.9, seed=5, amp=0.05))
+    drift = {}
+    for dt, steps in ((4.0, 16), (2.0, 31)):
+        traj = get_trajectory(m0, S, one, two, dt=dt, steps=steps, energy_output=str(tmp_path / "en.txt"))
+        assert traj.shape == (steps, 6, 3) and np.array_equal(traj[0], m0.coords)
+        en = np.loadtxt(tmp_path / "en.txt")
+        assert en[0, 2] == 0.0 and en[-1, 2] > 5e-3                    # kinetic energy was gained
+        drift[dt] = np.abs(en[:, 3] - en[0, 3]).max()
+    assert np.abs(traj[-1] - traj[0]).max() > 5e-2                     # the atoms did move
+    assert drift[2.0] < 5e-5 and 3.0 < drift[4.0] / drift[2.0] < 5.0
+    sc = get_scanner(m0, one, two, S)
+    frames = nve_velocity_verlet(sc, m0, dt=2.0, steps=3)
+    assert np.allclose(frames[2]["coord"], traj[2], atol=1e-12)
+    assert sc.base.predicted_one_rdm.shape == (6, 6) and sc.base.predicted_two_rdm.shape == (6, 6, 6, 6)
+    assert sc.base.converged and sc.mol is not m0
