@@ -1,10 +1,9 @@
 """Device-backed mirror of the evaluator-facing part of ``evcont/MD_utils.py``.
 
 ``get_scanner`` (reference :20-57) is the harness PySCF's MD integrators call once per step;
-``get_trajectory`` (:60-125) is a thin wrapper around ``pyscf.md.NVE``.  The active-learning
-driver ``converge_EVCont_MD`` (:128-502) is host-side orchestration with file checkpoints and
-MPI broadcasts and is outside this build's scope; scripts that use it keep
-importing it from the reference and get the accelerated evaluator through the functions here.
+``get_trajectory`` (:60-125) is a thin wrapper around ``pyscf.md.NVE`` (or the velocity-Verlet
+driver below for array-level molecules).  The active-learning driver ``converge_EVCont_MD``
+(:128-502) lives in ``evcont_amd/active_learning.py``.
 """
 from __future__ import annotations
 
@@ -115,7 +114,11 @@ def nve_velocity_verlet(scanner, init_mol, dt=10.0, steps=10, veloc=None, trajec
     return frames
 
 
-def converge_EVCont_MD(*args, **kwargs):
-    raise NotImplementedError(
-        "converge_EVCont_MD (reference MD_utils.py:128-502) is host orchestration outside this build's scope; "
-        "use the reference's driver with evcont_amd's evaluator functions")
+def converge_EVCont_MD(EVCont_obj, init_mol, steps=100, dt=1, convergence_thresh=1.0e-3,
+                       prune_irrelevant_data=False, trn_times=[], data_addition="farthest_point_ham", **kwargs):
+    """Active-learning driver (reference :128-502): see ``evcont_amd.active_learning.converge_EVCont_MD``,
+    which evaluates the loop's re-evaluation and selection steps as batched device calls."""
+    from .active_learning import converge_EVCont_MD as _impl
+    return _impl(EVCont_obj, init_mol, steps=steps, dt=dt, convergence_thresh=convergence_thresh,
+                 prune_irrelevant_data=prune_irrelevant_data, trn_times=list(trn_times),
+                 data_addition=data_addition, **kwargs)

@@ -69,6 +69,11 @@ SIGNATURES = {
     "evc_subspace_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
+    "evc_subspace_solve_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "evc_integrals_oao_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "evc_integrals_oao_batch": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_workspace_bytes": (C.c_size_t, [C.POINTER(TrdmSet), C.c_int]),
     "evc_phase_hamiltonian": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(Geometry), C.c_void_p, C.c_size_t,
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),

@@ -86,7 +86,8 @@ class TRDMContainer:
         from .synthetic import pack_rows
         if self.two_rdm is None:
             raise ValueError("the container holds no training data yet")
-        key = (id(self.overlap), id(self.one_rdm), id(self.two_rdm), self.ntrain, layout, str(device))
+        from .cache import key_of
+        key = key_of(self.one_rdm, self.two_rdm, self.overlap, (layout, str(device)))   # address + content sample
         if self._device is None or self._device_key != key:
             pairs, elec = {"full6": (False, False), "pair5": (True, False), "elec3": (False, True),
                            "pack2": (True, True)}[layout]

@@ -243,7 +243,8 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     {
         const int64_t g = blockIdx.x;
         a.h1part += g * a.sh1;
-        a.h2part += g * a.sh2;
+        if (a.h2part) a.h2part += g * a.sh2;
+        a.S += g * a.sS;
         a.evals += g * a.sev;
         a.evecs += g * a.svec;
         if (a.Hout) a.Hout += g * a.sH;

@@ -110,7 +110,8 @@ struct SolveArgs {
     const double *h2part;  // (nsp2, rows2_total) partial sums of two-body rows  + g*sh2
     int nsp2;
     double alpha2;
-    const double *S;  // (T,T) shared
+    const double *S;  // (T,T) + g*sS  (sS = 0: one overlap matrix shared by the batch)
+    int64_t sS;
     int T, layout, nroots;
     double e_shift;             // used when e_shift_dev == NULL
     const double *e_shift_dev;  // [count] or NULL

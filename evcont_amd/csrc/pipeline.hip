@@ -789,6 +789,108 @@ extern "C" int evc_subspace_solve(const double *h1rows, const double *h2rows, co
     return launch_subspace_solve(a, 1, as_stream(stream));
 }
 
+extern "C" int evc_subspace_solve_batch(const double *H, const double *S, int64_t s_stride, int T, int count,
+                                        int nroots, const double *e_shift, double *evals, double *evecs,
+                                        void *stream) {
+    EVC_REQUIRE(H && S && evals && evecs, "evc_subspace_solve_batch: null pointer");
+    EVC_REQUIRE(T >= 1 && T <= 64, "evc_subspace_solve_batch: T=%d out of range 1..64", T);
+    EVC_REQUIRE(count >= 1 && count <= (1 << 24), "evc_subspace_solve_batch: count=%d out of range", count);
+    EVC_REQUIRE(nroots >= 1 && nroots <= T, "evc_subspace_solve_batch: nroots=%d out of range", nroots);
+    EVC_REQUIRE(s_stride == 0 || s_stride >= (int64_t)T * T, "evc_subspace_solve_batch: s_stride=%lld",
+                (long long)s_stride);
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.h1part = H;  // the assembled matrix plays the role of the (single) one-body partial
+    a.nsp1 = 1;
+    a.alpha1 = 1.0;
+    a.sh1 = (int64_t)T * T;
+    a.h2part = nullptr;
+    a.nsp2 = 0;
+    a.S = S;
+    a.sS = s_stride;
+    a.T = T;
+    a.layout = EVC_LAYOUT_FULL6;
+    a.nroots = nroots;
+    a.e_shift_dev = e_shift;
+    a.evals = evals;
+    a.sev = T;
+    a.evecs = evecs;
+    a.svec = (int64_t)T * T;
+    return launch_subspace_solve(a, count, as_stream(stream));
+}
+
+// Workspace of evc_integrals_oao_batch per geometry: X, U, s, h1 (Loewdin outputs) + one N^4 buffer.
+// Layout inside one stride (every piece starts on a 16-byte boundary): [X | U | s | h1 | B1 (n^4)].
+static int64_t even_up(int64_t x) { return (x + 1) & ~(int64_t)1; }
+static int64_t integrals_ws_stride(int n) {
+    const int64_t n2 = (int64_t)n * n;
+    return 3 * even_up(n2) + even_up(n) + even_up(n2 * n2);
+}
+
+extern "C" size_t evc_integrals_oao_ws_bytes(int n, int count) {
+    if (n < 1 || n > 96 || count < 1) return 0;
+    return sizeof(double) * (size_t)integrals_ws_stride(n) * (size_t)count;
+}
+
+extern "C" int evc_integrals_oao_batch(int n, int count, const double *S, const double *hcore, const double *eri,
+                                       double *h1, double *h2, double *trafo, void *ws, size_t ws_bytes,
+                                       void *stream) {
+    EVC_REQUIRE(S && hcore && eri && h1 && h2 && ws, "evc_integrals_oao_batch: null pointer");
+    EVC_REQUIRE(n >= 1 && n <= 80, "evc_integrals_oao_batch: n=%d out of range 1..80", n);
+    EVC_REQUIRE(count >= 1 && count <= 65535, "evc_integrals_oao_batch: count=%d out of range", count);
+    EVC_REQUIRE(aligned16(ws) && ws_bytes >= evc_integrals_oao_ws_bytes(n, count),
+                "evc_integrals_oao_batch: workspace misaligned or too small");
+    hipStream_t st = as_stream(stream);
+    const int64_t n2 = (int64_t)n * n, n4 = n2 * n2, sw = integrals_ws_stride(n);
+    double *base = static_cast<double *>(ws);
+    double *X = base, *U = X + even_up(n2), *s = U + even_up(n2), *h1w = s + even_up(n), *B1 = h1w + even_up(n2);
+    int rc;
+    LoewdinArgs la{};
+    la.S = S;
+    la.h = hcore;
+    la.X = X;
+    la.U = U;
+    la.s = s;
+    la.h1 = h1w;
+    la.sS = n2;
+    la.sh = n2;
+    la.sws = sw;
+    la.n = n;
+    if ((rc = launch_loewdin(la, count, st))) return rc;
+    if (use_pair_transform(n)) {
+        PairTransformArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.in = eri;
+        pa.sin = n4;
+        pa.C = X;
+        pa.sC = sw;
+        pa.n = n;
+        pa.out = B1;
+        pa.sout = sw;
+        if ((rc = launch_pair_transform(pa, count, st))) return rc;
+        pa.in = B1;
+        pa.sin = sw;
+        pa.out = h2;
+        pa.sout = n4;
+        if ((rc = launch_pair_transform(pa, count, st))) return rc;
+    } else {
+        if ((rc = launch_quarter_transform(eri, n4, X, sw, 0, n, B1, sw, count, st))) return rc;
+        if ((rc = launch_quarter_transform(B1, sw, X, sw, 0, n, h2, n4, count, st))) return rc;
+        if ((rc = launch_quarter_transform(h2, n4, X, sw, 0, n, B1, sw, count, st))) return rc;
+        if ((rc = launch_quarter_transform(B1, sw, X, sw, 0, n, h2, n4, count, st))) return rc;
+    }
+    hipError_t e = hipMemcpy2DAsync(h1, sizeof(double) * n2, h1w, sizeof(double) * sw, sizeof(double) * n2, count,
+                                    hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && trafo)
+        e = hipMemcpy2DAsync(trafo, sizeof(double) * n2, X, sizeof(double) * sw, sizeof(double) * n2, count,
+                             hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        set_error("evc_integrals_oao_batch: copy failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
 static void fake_set(evc_trdm_set &t, int n) {
     memset(&t, 0, sizeof(t));
     t.n = n;

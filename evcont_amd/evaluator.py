@@ -247,7 +247,7 @@ class BatchedEvaluator:
     ``energy (G,T)``, ``coeffs (G,T,T)``, ``grad (G,A,3)``."""
 
     def __init__(self, trdms: DeviceTRDMs, natm: int, count: int, stream: Optional["torch.cuda.Stream"] = None,
-                 keep_density_matrices: bool = False):
+                 keep_density_matrices: bool = False, keep_hmat: bool = False):
         self.t, self.natm, self.count, self.stream = trdms, int(natm), int(count), stream
         self.lib = _lib.load()
         d, n, T = trdms.device, trdms.n, trdms.T
@@ -262,9 +262,11 @@ class BatchedEvaluator:
         self.grad = torch.zeros((G, max(self.natm, 1), 3), dtype=F64, device=d)
         self.d_pred = torch.zeros((G, n, n), dtype=F64, device=d) if keep_density_matrices else None
         self.g_pred = torch.zeros((G, n, n, n, n), dtype=F64, device=d) if keep_density_matrices else None
+        # the subspace Hamiltonians H(R) (lower triangles as handed to the eigensolver), for subset re-solves
+        self.hmat = torch.zeros((G, T, T), dtype=F64, device=d) if keep_hmat else None
         p = lambda t: (t.data_ptr() if t is not None else None)
         self.out = _lib.OutputsBatch(energy=p(self.energy), coeffs=p(self.coeffs), grad=p(self.grad),
-                                     d_pred=p(self.d_pred), g_pred=p(self.g_pred), hmat=None)
+                                     d_pred=p(self.d_pred), g_pred=p(self.g_pred), hmat=p(self.hmat))
 
     def _sp(self) -> int:
         return self.stream.cuda_stream if self.stream is not None else _stream_ptr(self.t.device)

@@ -113,6 +113,24 @@ int evc_loewdin(const double *S, const double *hcore, int n, double *X, double *
 int evc_subspace_solve(const double *h1rows, const double *h2rows, const double *S_train, int T,
                        int layout, int nroots, double e_shift, double *evals, double *evecs,
                        double *w2, double *w1, double *Hout, void *stream);
+/* `count` independent problems H[g] c = E S[g] c of one size (one workgroup each): H (count,T,T) and
+ * S (T,T) shared (s_stride = 0) or (count,T,T) (s_stride = T*T), lower triangles read.  Writes
+ * evals (count,T) (first nroots of each row, + e_shift[g] if e_shift != NULL) and evecs (count,T,T).
+ * This is what the active-learning loop needs: the continuation energies of a trajectory for SUBSETS
+ * of the training set (MD_utils.py:264-299,448-483) are eigenproblems of sub-matrices of the one
+ * H(R) of the full set, so the t-RDM is contracted once per geometry, not once per subset. */
+int evc_subspace_solve_batch(const double *H, const double *S, int64_t s_stride, int T, int count,
+                             int nroots, const double *e_shift, double *evals, double *evecs,
+                             void *stream);
+
+/* OAO integrals of `count` geometries (get_basis + get_integrals, electron_integral_utils.py:91-138):
+ * X = S^-1/2, h1 = X^T hcore X (count,N,N), h2 = four-index rotation of eri (count,N,N,N,N); `trafo`
+ * (count,N,N) receives X if non-NULL.  Inputs stacked along the leading axis.  Used by the
+ * "farthest_point_ham" selection metric (MD_utils.py:363-405).  n <= 80. */
+size_t evc_integrals_oao_ws_bytes(int n, int count);
+int evc_integrals_oao_batch(int n, int count, const double *S, const double *hcore, const double *eri,
+                            double *h1, double *h2, double *trafo, void *ws, size_t ws_bytes,
+                            void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Fused per-geometry pipeline (ab_initio_gradients_loewdin.py:308-379 get_energy_with_grad,
