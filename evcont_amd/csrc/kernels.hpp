@@ -59,6 +59,7 @@ struct PairTransformArgs {
     int64_t sin, sC, sout, spacked, sk3, packed_len;
     double diag_mult;
     int ct, n;
+    int tiles_per_wg;   // set by launch_pair_transform: consecutive 8-wide q tiles per workgroup
 };
 constexpr int kPairTransformMaxN = 32;
 int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);

@@ -148,17 +148,22 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     const int64_t g = blockIdx.y;
     const double *__restrict__ in = a.in + g * a.sin;
     const double *__restrict__ C = a.C + g * a.sC;
+    // a workgroup owns `tpw` consecutive q tiles of one p: the stores of a tile drain while the next
+    // one is loaded and multiplied, and X is staged once
     const int ntq = (n + QT - 1) / QT;
-    const int p = blockIdx.x / ntq, q0 = (blockIdx.x - p * ntq) * QT;
-    const int nq = min(QT, n - q0);
+    const int tpw = a.tiles_per_wg;
+    const int ntg = (ntq + tpw - 1) / tpw;
+    const int p = blockIdx.x / ntg;
+    const int tq_begin = (blockIdx.x - p * ntg) * tpw, tq_end = min(ntq, tq_begin + tpw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
 
     // first matrix of this wave: operand loads issued before the LDS fill of X
     double mf[NT][KS];
     {
-        const bool ok = wave < nq;
-        const double *Mb = in + ((int64_t)p * n + q0 + wave) * n2;
+        const int q = tq_begin * QT + wave;
+        const bool ok = q < n;
+        const double *Mb = in + ((int64_t)p * n + q) * n2;
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
@@ -180,13 +185,17 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) xf[kk][t] = Xs[(4 * kk + l4) * LDX + t * 16 + l15];
 
+    for (int tq = tq_begin; tq < tq_end; ++tq) {
+    const int q0 = tq * QT;
+    const int nq = min(QT, n - q0);
     for (int ql = wave; ql < nq; ql += 4) {
         const int q = q0 + ql;
-        // prefetch the wave's next matrix
+        // prefetch the wave's next matrix: q + 4 of this tile, else its first one of the next tile
         double mn[NT][KS];
         {
-            const bool ok = ql + 4 < nq;
-            const double *Mb = in + ((int64_t)p * n + q + 4) * n2;
+            const int qn = (ql + 4 < nq) ? q + 4 : q0 + QT + wave;
+            const bool ok = (ql + 4 < nq) || (tq + 1 < tq_end && qn < n);
+            const double *Mb = in + ((int64_t)p * n + qn) * n2;
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
@@ -262,19 +271,24 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             if (ql < nq && R >= Cc) pk[tri_index(R, Cc)] = stage[rs * QP + ql] * (R == Cc ? a.diag_mult : 1.0);
         }
         // zero the padding [M, packed_len) once per geometry
-        if (blockIdx.x == 0) {
+        if (blockIdx.x == 0 && tq == tq_begin) {
             const int64_t M = n2 * (n2 + 1) / 2;
             for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
         }
     }
+    __syncthreads();  // the stage is free again; the stores above drain while the next tile is computed
+    }
     (void)n3;
 }
 
-int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st) {
+int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t st) {
+    PairTransformArgs a = a_in;
     const int n = a.n;
     const int npad = (n + 15) / 16 * 16;
     const int ntq = (n + 7) / 8;
-    const dim3 grid(n * ntq, (unsigned)count);
+    static const int tpw_env = getenv("EVC_PT_TILES") ? atoi(getenv("EVC_PT_TILES")) : 2;
+    a.tiles_per_wg = tpw_env < 1 ? 1 : (tpw_env > ntq ? ntq : tpw_env);
+    const dim3 grid(n * ((ntq + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
     if (npad == 16) {
         const size_t lds = sizeof(double) * ((size_t)16 * 16 + (size_t)n * n * 9);
         hipLaunchKernelGGL(pt_kernel<16>, grid, dim3(256), lds, st, a);
