@@ -319,10 +319,11 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &L, int g0, int G, int tiles, hip
 // Wave = 32*CT columns (CT even/odd tile pairs); block = 4 waves = 128*CT columns; the wave walks
 // down the rows 4 at a time (one K step), 4 K steps per iteration so that 4*CT 16-byte loads are in
 // flight per lane.  The weights of a row tile (<= 512 rows) are staged in LDS as wl[row][16].
-constexpr int kCT = 4;
-constexpr int kRowTile = 512;
+constexpr int kRowTile = 256;
 
-__global__ __launch_bounds__(256, 3) void gemv_cols_mfma_kernel(GemvColsLaunch L, int g0, int G) {
+// CT: 32-column tile pairs per wave; KSN: K steps (4 rows each) per iteration.
+template <int CT, int KSN, int MINB>
+__global__ __launch_bounds__(256, MINB) void gemv_cols_mfma_kernel(GemvColsLaunch L, int g0, int G) {
     extern __shared__ __align__(16) double wl[];  // min(rows, kRowTile) (rounded up to 4) x 16
     int bid = gridDim.x - 1 - blockIdx.x;  // the few blocks of the small second problem are dispatched first
     const int which = bid >= L.nblk0 ? 1 : 0;
@@ -331,12 +332,12 @@ __global__ __launch_bounds__(256, 3) void gemv_cols_mfma_kernel(GemvColsLaunch L
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t rows = P.rows, cols = P.cols, ld = P.ld;
-    const int64_t c0 = ((int64_t)bid * 4 + wave) * (32 * kCT);   // first column of this wave
+    const int64_t c0 = ((int64_t)bid * 4 + wave) * (32 * CT);   // first column of this wave
     const double *__restrict__ w = P.w + (int64_t)g0 * P.wstride;
 
-    d4 ae[kCT], ao[kCT];
+    d4 ae[CT], ao[CT];
 #pragma unroll
-    for (int t = 0; t < kCT; ++t) {
+    for (int t = 0; t < CT; ++t) {
         ae[t] = (d4){0.0, 0.0, 0.0, 0.0};
         ao[t] = (d4){0.0, 0.0, 0.0, 0.0};
     }
@@ -353,11 +354,11 @@ __global__ __launch_bounds__(256, 3) void gemv_cols_mfma_kernel(GemvColsLaunch L
         }
         __syncthreads();
         if (c0 < cols) {
-            for (int rb = 0; rb < nr4; rb += 16) {
-                double2 x[4][kCT];
-                double wf[4];
+            for (int rb = 0; rb < nr4; rb += 4 * KSN) {
+                double2 x[KSN][CT];
+                double wf[KSN];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = 0; ks < KSN; ++ks) {
                     const int r = rb + 4 * ks + l4;
                     // rows beyond the tile carry zero weights; clamp the address to a valid row
                     const int64_t rr = r0 + (r < nr ? r : nr - 1);
@@ -365,16 +366,16 @@ __global__ __launch_bounds__(256, 3) void gemv_cols_mfma_kernel(GemvColsLaunch L
                     const bool live = rb + 4 * ks < nr4;
                     wf[ks] = live ? wl[(rb + 4 * ks + l4) * 16 + l15] : 0.0;
 #pragma unroll
-                    for (int t = 0; t < kCT; ++t) {
+                    for (int t = 0; t < CT; ++t) {
                         const int64_t c = cl + 32 * t;
                         x[ks][t] = live ? ((c + 1 < cols) ? ld2(row + c) : make_double2(c < cols ? row[c] : 0.0, 0.0))
                                         : make_double2(0.0, 0.0);
                     }
                 }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < KSN; ++ks)
 #pragma unroll
-                    for (int t = 0; t < kCT; ++t) {
+                    for (int t = 0; t < CT; ++t) {
                         ae[t] = mfma_f64(wf[ks], x[ks][t].x, ae[t]);
                         ao[t] = mfma_f64(wf[ks], x[ks][t].y, ao[t]);
                     }
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256, 3) void gemv_cols_mfma_kernel(GemvColsLaunch L
     }
     if (c0 < cols) {
 #pragma unroll
-        for (int t = 0; t < kCT; ++t) {
+        for (int t = 0; t < CT; ++t) {
             const int64_t c = cl + 32 * t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -398,21 +399,30 @@ __global__ __launch_bounds__(256, 3) void gemv_cols_mfma_kernel(GemvColsLaunch L
     }
 }
 
-int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
-    const int64_t per = 4 * 32 * kCT;
+template <int CT, int KSN, int MINB>
+static void cols_mfma_launch(GemvColsLaunch L, int g0, int G, size_t lds, hipStream_t st) {
+    const int64_t per = 4 * 32 * CT;
     L.nblk0 = (int)ceil_div(L.p[0].cols, per);
     const int total = L.nblk0 + (int)ceil_div(L.p[1].cols, per);
-    if (total == 0) return 0;
-    int64_t rmax = L.p[0].rows > L.p[1].rows ? L.p[0].rows : L.p[1].rows;
-    if (rmax > kRowTile) rmax = kRowTile;
-    const size_t lds = sizeof(double) * 16 * (size_t)((rmax + 3) & ~3);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemv_cols_mfma_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemv_cols_mfma_kernel<CT, KSN, MINB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kRowTile * 16 * (int)sizeof(double));
         attr = true;
     }
-    hipLaunchKernelGGL(gemv_cols_mfma_kernel, dim3(total), dim3(256), lds, st, L, g0, G);
+    hipLaunchKernelGGL((gemv_cols_mfma_kernel<CT, KSN, MINB>), dim3(total), dim3(256), lds, st, L, g0, G);
+}
+
+int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
+    if (L.p[0].cols + L.p[1].cols == 0) return 0;
+    int64_t rmax = L.p[0].rows > L.p[1].rows ? L.p[0].rows : L.p[1].rows;
+    if (rmax > kRowTile) rmax = kRowTile;
+    const size_t lds = sizeof(double) * 16 * (size_t)((rmax + 3) & ~3);
+    // measured at H30/T=20, G=16 (in situ): 96-column waves 196 us, 128-column 205 us, 160-column 222 us,
+    // 64-column 202 us; fitting all blocks into one resident round did not help
+    static const int ct = getenv("EVC_COLS_CT") ? atoi(getenv("EVC_COLS_CT")) : 3;
+    if (ct == 4) cols_mfma_launch<4, 4, 3>(L, g0, G, lds, st);
+    else cols_mfma_launch<3, 4, 3>(L, g0, G, lds, st);
     EVC_LAUNCH_CHECK("gemv_cols_mfma");
     return 0;
 }
