@@ -395,14 +395,21 @@ int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t so
 // staged in LDS and written to GsT with i fastest ((j,k) fixes a contiguous n*n block of GsT).
 __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restrict__ p, int64_t sp, int n,
                                                          double *__restrict__ GsT, double *__restrict__ SB,
-                                                         int64_t sws, double *__restrict__ Gout, int64_t sG) {
+                                                         int64_t sws, double *__restrict__ Gout, int64_t sG,
+                                                         int count) {
     extern __shared__ __align__(16) double tile[];  // [l][i], row length n+1
     const int64_t n2 = (int64_t)n * n, n3 = n2 * n;
-    p += (int64_t)blockIdx.y * sp;
-    GsT += (int64_t)blockIdx.y * sws;
-    SB += (int64_t)blockIdx.y * sws;
-    if (Gout) Gout += (int64_t)blockIdx.y * sG;
-    const int j = blockIdx.x / n, k = blockIdx.x - j * n;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; the blocks an XCD receives work
+    // through ONE geometry at a time, so that geometry's packed vector (3.2 MB at N=30) stays in the
+    // XCD's 4 MB L2 for the three gathers per element.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int geom = (slot / (n * n)) * 8 + xcd, jk = slot % (n * n);
+    if (geom >= count) return;
+    p += (int64_t)geom * sp;
+    GsT += (int64_t)geom * sws;
+    SB += (int64_t)geom * sws;
+    if (Gout) Gout += (int64_t)geom * sG;
+    const int j = jk / n, k = jk - j * n;
     auto P = [&](int64_t a, int64_t b) { return a >= b ? p[tri_index(a, b)] : p[tri_index(b, a)]; };
     for (int idx = threadIdx.x; idx < n * n; idx += 256) {
         const int i = idx / n, l = idx - i * n;
@@ -424,8 +431,9 @@ __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restric
 int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
                       int64_t sG, int count, hipStream_t st) {
     const size_t lds = sizeof(double) * (size_t)n * (n + 1);
-    hipLaunchKernelGGL(unpack_sym_kernel, dim3(n * n, (unsigned)count), dim3(256), lds, st, packed, sp, n, GsT, SB,
-                       sws, G, sG);
+    const unsigned groups = (unsigned)((count + 7) / 8);   // geometries in groups of 8, one per XCD
+    hipLaunchKernelGGL(unpack_sym_kernel, dim3(8u * n * n * groups), dim3(256), lds, st, packed, sp, n, GsT, SB, sws,
+                       G, sG, count);
     EVC_LAUNCH_CHECK("unpack_sym");
     return 0;
 }
