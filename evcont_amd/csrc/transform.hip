@@ -287,7 +287,8 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     const int npad = (n + 15) / 16 * 16;
     const int ntq = (n + 7) / 8;
     static const int tpw_env = getenv("EVC_PT_TILES") ? atoi(getenv("EVC_PT_TILES")) : 2;
-    a.tiles_per_wg = tpw_env < 1 ? 1 : (tpw_env > ntq ? ntq : tpw_env);
+    // few geometries: keep one tile per workgroup so that there are enough workgroups for the chip
+    a.tiles_per_wg = (count < 4 || tpw_env < 1) ? 1 : (tpw_env > ntq ? ntq : tpw_env);
     const dim3 grid(n * ((ntq + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
     if (npad == 16) {
         const size_t lds = sizeof(double) * ((size_t)16 * 16 + (size_t)n * n * 9);
@@ -402,9 +403,20 @@ __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restric
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; the blocks an XCD receives work
     // through ONE geometry at a time, so that geometry's packed vector (3.2 MB at N=30) stays in the
     // XCD's 4 MB L2 for the three gathers per element.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int geom = (slot / (n * n)) * 8 + xcd, jk = slot % (n * n);
-    if (geom >= count) return;
+    // The first count - count%8 geometries are laid out that way; the remainder (and any batch of fewer
+    // than 8) is spread over all XCDs in plain (geometry, jk) order.
+    const int nx = count & ~7;
+    const int64_t nxblocks = (int64_t)nx * n * n;
+    int geom, jk;
+    if ((int64_t)blockIdx.x < nxblocks) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        geom = (slot / (n * n)) * 8 + xcd;
+        jk = slot % (n * n);
+    } else {
+        const int64_t b = (int64_t)blockIdx.x - nxblocks;
+        geom = nx + (int)(b / (n * n));
+        jk = (int)(b % (n * n));
+    }
     p += (int64_t)geom * sp;
     GsT += (int64_t)geom * sws;
     SB += (int64_t)geom * sws;
@@ -431,9 +443,8 @@ __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restric
 int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
                       int64_t sG, int count, hipStream_t st) {
     const size_t lds = sizeof(double) * (size_t)n * (n + 1);
-    const unsigned groups = (unsigned)((count + 7) / 8);   // geometries in groups of 8, one per XCD
-    hipLaunchKernelGGL(unpack_sym_kernel, dim3(8u * n * n * groups), dim3(256), lds, st, packed, sp, n, GsT, SB, sws,
-                       G, sG, count);
+    hipLaunchKernelGGL(unpack_sym_kernel, dim3((unsigned)(n * n * count)), dim3(256), lds, st, packed, sp, n, GsT, SB,
+                       sws, G, sG, count);
     EVC_LAUNCH_CHECK("unpack_sym");
     return 0;
 }
