@@ -16,8 +16,32 @@ from .integrals import ao_arrays, energy_nuc, is_array_mol
 
 def _nonhermitian_unsupported():
     raise NotImplementedError(
-        "hermitian=False (scipy.linalg.eig branch, reference :76-78) is not implemented on the device; "
-        "every script of the reference uses hermitian=True")
+        "hermitian=False is not supported for the energy+gradient path: the reference's eig branch (:76-78) "
+        "returns 2-norm-normalised vectors, which mis-scale its own predicted RDMs; every script uses hermitian=True")
+
+
+def _eig_nonhermitian(H: np.ndarray, S: np.ndarray, layout: int):
+    """The reference's non-Hermitian branch (:50-51,67-68,76-81) on the subspace matrix assembled by the
+    device: pair layouts carry the two-body part in the lower triangle only, so the upper one is filled
+    from it first; then ``scipy.linalg.eig(H, S)`` (a T x T problem, solved on the host exactly as the
+    reference does) and the |Im| < 1e-5 filter."""
+    import scipy.linalg
+    H = np.array(H, dtype=np.float64)
+    if layout in (5, 2):
+        iu = np.triu_indices(H.shape[0])
+        H[iu] = H.T[iu]
+    vals, vecs = scipy.linalg.eig(H, np.asarray(S, dtype=np.float64))
+    keep = np.abs(vals.imag) < 1.0e-5
+    return vals[keep], vecs[:, keep]
+
+
+def _select(vals, vecs, nroots, ground_state):
+    if ground_state:
+        k = int(np.argmin(vals.real))
+        return float(vals[k].real), np.array(vecs[:, k].real)
+    assert vals.shape[0] >= nroots                   # reference :166
+    order = np.argsort(vals.real)[:nroots]
+    return np.array(vals[order].real), np.array(vecs[:, order].real.T)
 
 
 def _trdms(one_RDM, two_RDM, S) -> DeviceTRDMs:
@@ -36,7 +60,7 @@ def _evaluator(one_RDM, two_RDM, S, natm: int) -> ContinuationEvaluator:
     return ev
 
 
-def _solve_from_integrals(h1, h2, one_RDM, two_RDM, S, nroots):
+def _solve_from_integrals(h1, h2, one_RDM, two_RDM, S, nroots, hermitian=True, ground_state=False):
     """H_ab from given OAO integrals (reference :38-68) + eigh(H, S) (:73-88), all on the device."""
     two_RDM = np.asarray(two_RDM) if not torch.is_tensor(two_RDM) else two_RDM
     assert two_RDM.ndim in (6, 5, 3, 2)          # reference: `assert False` otherwise (:70-71)
@@ -50,7 +74,9 @@ def _solve_from_integrals(h1, h2, one_RDM, two_RDM, S, nroots):
         v, alpha = h2d.reshape(-1), 0.5
     rows2 = ops.gemv_rows(t.two, t.cols, v, alpha)[: t.rows_total]
     rows1 = ops.gemv_rows(t.one, t.n * t.n, h1d)          # t.one rows are padded to an even length
-    ev, vec, _, _, _ = ops.subspace_solve(rows1, rows2.contiguous(), t.S, t.layout, nroots)
+    ev, vec, _, _, Hd = ops.subspace_solve(rows1, rows2.contiguous(), t.S, t.layout, nroots)
+    if not hermitian:
+        return _select(*_eig_nonhermitian(Hd.cpu().numpy(), t.S.cpu().numpy(), t.layout), nroots, ground_state)
     e = ev.cpu().numpy()
     if not np.all(np.isfinite(e)):
         raise np.linalg.LinAlgError("generalised eigenproblem failed (overlap not positive definite?)")
@@ -60,38 +86,39 @@ def _solve_from_integrals(h1, h2, one_RDM, two_RDM, S, nroots):
 def approximate_ground_state(h1, h2, one_RDM, two_RDM, S, hermitian=True):
     """(E, c) of the lowest generalised eigenpair (reference :12-90)."""
     if not hermitian:
-        _nonhermitian_unsupported()
+        return _solve_from_integrals(h1, h2, one_RDM, two_RDM, S, 1, hermitian=False, ground_state=True)
     e, c = _solve_from_integrals(h1, h2, one_RDM, two_RDM, S, 1)
     return float(e[0]), c[0].copy()
 
 
 def approximate_multistate(h1, h2, one_RDM, two_RDM, S, nroots=1, hermitian=True):
     """(E[nroots], C[nroots,T]) lowest eigenpairs, rows S-orthonormal (reference :93-175)."""
-    if not hermitian:
-        _nonhermitian_unsupported()
     T = np.asarray(S).shape[0]
     assert T >= nroots                               # reference :166
-    return _solve_from_integrals(h1, h2, one_RDM, two_RDM, S, int(nroots))
+    return _solve_from_integrals(h1, h2, one_RDM, two_RDM, S, int(nroots), hermitian=bool(hermitian))
 
 
-def _oao(mol, one_RDM, two_RDM, S, nroots):
+def _oao(mol, one_RDM, two_RDM, S, nroots, hermitian=True, ground_state=False):
     ao = ao_arrays(mol, need_grad=False)
     ev = _evaluator(one_RDM, two_RDM, S, int(np.asarray(ao.aoslices).shape[0]))
     dao = DeviceAO.from_arrays(ao, ev.t.device, energy_only=True)
-    return ev.energies(dao, nroots)
+    res = ev.energies(dao, nroots)
+    if hermitian:
+        return res
+    # same device pipeline (Loewdin, rotation, H build); only the T x T eigensolve differs
+    e, c = _select(*_eig_nonhermitian(ev.hmat.cpu().numpy(), ev.t.S.cpu().numpy(), ev.t.layout), nroots, ground_state)
+    return e + float(ao.enuc), c
 
 
 def approximate_ground_state_OAO(mol, one_RDM, two_RDM, S, hermitian=True):
     """Total energy (incl. nuclear repulsion) and coefficients at the geometry of ``mol``
     (reference :178-211); Loewdin trafo, integral rotation, H build and eigensolve fused on the GPU."""
     if not hermitian:
-        _nonhermitian_unsupported()
+        return _oao(mol, one_RDM, two_RDM, S, 1, hermitian=False, ground_state=True)
     e, c = _oao(mol, one_RDM, two_RDM, S, 1)
     return float(e[0]), c[0].copy()
 
 
 def approximate_multistate_OAO(mol, one_RDM, two_RDM, S, nroots=1, hermitian=True):
     """Reference :214-250."""
-    if not hermitian:
-        _nonhermitian_unsupported()
-    return _oao(mol, one_RDM, two_RDM, S, int(nroots))
+    return _oao(mol, one_RDM, two_RDM, S, int(nroots), hermitian=bool(hermitian))

@@ -68,8 +68,19 @@ def test_continuation_module(case, lname, load_golden):
     assert abs(et - float(g[f"gsoao_E_{lname}_h"])) < 1e-10
     emt, _ = evc.approximate_multistate_OAO(mol, g["one_RDM"], two, g["S_train"], nroots=nroots)
     np.testing.assert_allclose(emt - float(g["enuc"]), g[f"ms_E_{lname}_h"], rtol=0, atol=1e-10)
-    with pytest.raises(NotImplementedError):
-        evc.approximate_ground_state(g["h1"], g["h2"], g["one_RDM"], two, g["S_train"], hermitian=False)
+    # non-Hermitian branch (scipy.linalg.eig, reference :76-81) on the device-assembled H
+    e, c = evc.approximate_ground_state(g["h1"], g["h2"], g["one_RDM"], two, g["S_train"], hermitian=False)
+    assert abs(e - float(g[f"gs_E_{lname}_nh"])) < 1e-10
+    r = g[f"gs_c_{lname}_nh"]
+    assert min(np.abs(c - r).max(), np.abs(c + r).max()) < 1e-7
+    em, cm = evc.approximate_multistate(g["h1"], g["h2"], g["one_RDM"], two, g["S_train"], nroots=nroots,
+                                        hermitian=False)
+    np.testing.assert_allclose(em, g[f"ms_E_{lname}_nh"], rtol=0, atol=1e-10)
+    assert cm.shape == (nroots, len(c))
+    et, _ = evc.approximate_ground_state_OAO(mol, g["one_RDM"], two, g["S_train"], hermitian=False)
+    assert abs(et - float(g[f"gsoao_E_{lname}_nh"])) < 1e-10
+    emt, _ = evc.approximate_multistate_OAO(mol, g["one_RDM"], two, g["S_train"], nroots=nroots, hermitian=False)
+    np.testing.assert_allclose(emt - float(g["enuc"]), g[f"ms_E_{lname}_nh"], rtol=0, atol=1e-10)
     with pytest.raises(AssertionError):
         evc.approximate_ground_state(g["h1"], g["h2"], g["one_RDM"], two.reshape(-1), g["S_train"])
 
