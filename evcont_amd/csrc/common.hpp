@@ -37,6 +37,13 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- device side -----------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence
+// and therefore waits for vmcnt(0): every global load AND store of the wave must have completed
+// before it reaches the barrier.  Where the barrier only hands an LDS buffer from one set of lanes to
+// another, waiting for the wave's own LDS operations is enough, and the global stores (or prefetches)
+// issued before it keep draining behind the work that follows.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Sum over the 64 lanes of a wave; every lane gets the total.  Fixed butterfly order,
 // so results are reproducible run to run.
 __device__ __forceinline__ double wave_sum(double v) {

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
         if (d < n && q < n) v = a.ct ? C[q * n + d] : C[d * n + q];
         Xs[d * LDX + q] = v;
     }
-    __syncthreads();
+    lds_barrier();
     double xf[KS][NT];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = mn[rt][kk];
     }
-    __syncthreads();
+    lds_barrier();
     // write-out: 8 lanes cover the q run of one (r',s')
     const int ql = threadIdx.x & 7;
     if (a.out) {
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
         }
     }
-    __syncthreads();  // the stage is free again; the stores above drain while the next tile is computed
+    lds_barrier();  // the stage is free again; the stores above drain while the next tile is computed
     }
     (void)n3;
 }
@@ -286,7 +286,7 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     const int n = a.n;
     const int npad = (n + 15) / 16 * 16;
     const int ntq = (n + 7) / 8;
-    static const int tpw_env = getenv("EVC_PT_TILES") ? atoi(getenv("EVC_PT_TILES")) : 2;
+    static const int tpw_env = getenv("EVC_PT_TILES") ? atoi(getenv("EVC_PT_TILES")) : 4;
     // few geometries: keep one tile per workgroup so that there are enough workgroups for the chip
     a.tiles_per_wg = (count < 4 || tpw_env < 1) ? 1 : (tpw_env > ntq ? ntq : tpw_env);
     const dim3 grid(n * ((ntq + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restric
         if (Gout) Gout[o] = p1;
         tile[l * (n + 1) + i] = 2.0 * p1 + p2 + p3;
     }
-    __syncthreads();
+    lds_barrier();
     double *dst = GsT + ((int64_t)j * n + k) * n2;
     for (int idx = threadIdx.x; idx < n * n; idx += 256) {
         const int l = idx / n, i = idx - l * n;
