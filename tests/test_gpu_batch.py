@@ -93,3 +93,58 @@ def test_batched_phase_api_emulated_pair_sharding(lname, world, G):
     for ev in evs:
         np.testing.assert_allclose(ev.energy[:, 0].cpu().numpy(), Eref, rtol=0, atol=1e-11)
     np.testing.assert_allclose(total.cpu().numpy(), gref, rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,T,A,G,lname", [
+    (18, 6, 3, 9, "pack2"),      # 16 < N <= 32: pair transform <32> with a ragged last q tile; 9 = 8 + 1 geometries
+    (21, 5, 3, 17, "pack2"),     # odd N, two matrix-core groups (16 + 1)
+    (18, 4, 2, 13, "full6"),     # general (unpacked) path, one matrix-core group of 13
+])
+def test_batch_vs_oracle_midsize(n, T, A, G, lname):
+    """Batched pipeline at sizes where the batch-only code paths are live (matrix-core streaming kernels,
+    XCD-ordered unpack with a remainder, several q tiles per workgroup), against the CPU oracle."""
+    from oracle import evcont_oracle as orc
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, DeviceAOBatch, BatchedEvaluator
+    dev = torch.device("cuda:0")
+    S, one, two = make_trdms(n, T, 300 + n)
+    two_l = layout(two, lname)
+    aos = [make_ao_arrays(n, A, 800 + k) for k in range(G)]
+    be = BatchedEvaluator(DeviceTRDMs(one, two_l, S, dev), A, G, keep_density_matrices=True)
+    E, grad = be.energies_with_grads(DeviceAOBatch.stack([DeviceAO.from_arrays(a, dev) for a in aos]))
+    for k in (0, 7, 8, G - 1):
+        a = aos[k]
+        b = orc.AOBundle(a.S, a.hcore, a.eri, a.ipovlp, a.dhcore, a.eri_ip1, a.aoslices, a.enuc, a.gnuc)
+        Eo, go, Do, Go = orc.energy_with_grad(b, one, two_l, S, True, True)
+        assert abs(E[k] - Eo) < 1e-9, k
+        np.testing.assert_allclose(grad[k], go, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(be.d_pred[k].cpu().numpy(), Do, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(be.g_pred[k].cpu().numpy(), Go, rtol=0, atol=1e-10)
+
+
+def test_h30_batch16_matches_single_full_size():
+    """BASELINE metric configuration at FULL size (N=30, A=30, T=20, packed 210 x 405450 t-RDM, 16 geometries
+    per pass): the batched pipeline must reproduce the single-geometry pipeline, which is pinned to the
+    reference at small sizes and by the layout-equivalence property at N=30."""
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, ContinuationEvaluator, BatchedEvaluator
+    from evcont_amd.synthetic import make_device_ao, make_device_trdm_rows
+    dev = torch.device("cuda:0")
+    n, A, T, G = 30, 30, 20, 16
+    S, one, rows = make_device_trdm_rows(n, T, 2, 1236, dev)
+    trd = DeviceTRDMs.from_device_rows(one, rows, S, 2)
+    del rows
+    aos = [make_device_ao(n, A, 5000 + k, dev) for k in range(G)]
+    be = BatchedEvaluator(trd, A, G)
+    be.enqueue(DeviceAOBatch.stack(aos))
+    be.synchronize()
+    E = be.energy[:, 0].cpu().numpy()
+    grad = be.grad.cpu().numpy()
+    assert np.all(np.isfinite(E)) and np.all(np.isfinite(grad))
+    single = ContinuationEvaluator(trd, A)
+    for k in (0, 5, 15):
+        Es, gs = single.energy_with_grad(aos[k])
+        assert abs(E[k] - Es) < 1e-9, (k, E[k], Es)
+        np.testing.assert_allclose(grad[k], gs, rtol=0, atol=1e-8)
+    # a second, identical pass is bit-identical (fixed reduction orders, no atomics)
+    be.enqueue(DeviceAOBatch.stack(aos))
+    be.synchronize()
+    assert np.array_equal(be.energy[:, 0].cpu().numpy(), E) and np.array_equal(be.grad.cpu().numpy(), grad)
