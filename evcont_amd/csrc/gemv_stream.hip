@@ -271,12 +271,13 @@ int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     static const int v8 = env_int("EVC_ROWS_G8", 0);   // 0: wave-rows kernel RBW=4; 1: lane-private RB=2
     static const int v4 = env_int("EVC_ROWS_G4", 0);   // 0: wave-rows RBW=8; 1: wave-rows RBW=4; 2: lane-private RB=4
     static const int mfma_min = env_int("EVC_MFMA_MIN_G", 12);   // groups of >= this many geometries use the matrix cores
+    static const int mfma_max = env_int("EVC_MFMA_MAX_G", 32);   // geometries per pass over the matrix (16 or 32)
     static const int mfma_tiles = env_int("EVC_MFMA_TILES", 0);   // 0: pipelined 4-tile kernel; 4/8/16: un-pipelined variants
     int g0 = 0;
     while (g0 < count) {
         const int left = count - g0;
         if (left >= mfma_min) {
-            const int G = left < 16 ? left : 16;
+            const int G = left < mfma_max ? left : mfma_max;
             int rc = launch_gemv_rows_mfma(L, g0, G, mfma_tiles, st);
             if (rc) return rc;
             g0 += G;
@@ -416,11 +417,12 @@ int launch_gemv_cols(ColProblem p0, ColProblem p1, int count, hipStream_t st) {
     const int total = L.nblk0 + (int)ceil_div(p1.cols, kChunk);
     if (total == 0 || count <= 0) return 0;
     static const int mfma_min = env_int("EVC_MFMA_MIN_G", 12);
+    static const int mfma_max = env_int("EVC_MFMA_MAX_G", 32);
     int g0 = 0;
     while (g0 < count) {
         const int left = count - g0;
         if (left >= mfma_min) {
-            const int G = left < 16 ? left : 16;
+            const int G = left < mfma_max ? left : mfma_max;
             int rc = launch_gemv_cols_mfma(L, g0, G, st);
             if (rc) return rc;
             g0 += G;

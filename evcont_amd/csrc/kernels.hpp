@@ -9,7 +9,7 @@
 
 namespace evc {
 
-constexpr int kMaxBatchG = 16;  // geometries contracted per pass of the streaming kernels (MFMA variants)
+constexpr int kMaxBatchG = 32;  // geometries contracted per pass of the streaming kernels (matrix-core variants)
 
 // ---- gemv_stream.hip ---------------------------------------------------------------
 struct RowProblem {

@@ -36,7 +36,7 @@ def kernel_means(tag):
 
 
 os.makedirs(OUT, exist_ok=True)
-for tag in ("stats_default", "stats_b16s1", "stats_md"):
+for tag in ("stats_default", "stats_b32s1", "stats_b16s1", "stats_md"):
     f = first(f"{tag}/*/*kernel_stats.csv")
     if f:
         rows = [r for r in csv.DictReader(open(f)) if "evc::" in r["Name"]]
@@ -46,7 +46,7 @@ for tag in ("stats_default", "stats_b16s1", "stats_md"):
             w.writerows(rows)
 traffic = {}
 table = []
-for regime, key in (("b16", "batch16"), ("md", "batch1")):
+for regime, key in (("b32", "batch32"), ("b16", "batch16"), ("md", "batch1")):
     fe, wr = kernel_means(f"pmc_fetch_{regime}"), kernel_means(f"pmc_write_{regime}")
     for k in sorted(set(fe) | set(wr)):
         fetch_kib = fe.get(k, {}).get("FETCH_SIZE", 0.0)
@@ -64,10 +64,10 @@ with open(os.path.join(OUT, f"{ROUND}_pmc_hbm_traffic.csv"), "w") as fo:
     fo.write("regime,kernel,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_per_launch\n")
     for r in table:
         fo.write(",".join(str(x) for x in r) + "\n")
-sq = kernel_means("pmc_sq_b16")
+sq = kernel_means("pmc_sq_b32")
 if sq:
     cols = sorted({c for d in sq.values() for c in d})
-    with open(os.path.join(OUT, f"{ROUND}_pmc_sq_batch16.csv"), "w") as fo:
+    with open(os.path.join(OUT, f"{ROUND}_pmc_sq_batch32.csv"), "w") as fo:
         fo.write("kernel," + ",".join(cols) + "\n")
         for k, d in sq.items():
             fo.write(k + "," + ",".join(f"{d.get(c, 0):.0f}" for c in cols) + "\n")
