@@ -9,7 +9,7 @@ training geometry, by default the trajectory point whose OAO integrals are farth
 integrals, ``min_j |h1-h1_j|^2 + 1/2 |h2-h2_j|^2`` (``:363-405``), rotating the integrals of every
 point once more.
 
-Here (i) costs ONE batched pass per 16 geometries: the subspace matrix of a subset of the training
+Here (i) costs ONE batched pass per 32 geometries: the subspace matrix of a subset of the training
 states is the corresponding sub-matrix of the full ``H(R)``, so the t-RDM is contracted once per
 geometry (``evc_energy_with_grad_batch`` with ``hmat`` kept) and all ``T+1`` subset problems are small
 generalised eigenproblems solved as one batched launch (``evc_subspace_solve_batch``); (ii) is one

@@ -37,7 +37,7 @@ struct GemvColsLaunch {
     ColProblem p[2];
     int nblk0;
 };
-// gemv_mfma.hip: matrix-core variants, G <= 16 geometries [g0, g0+G) per launch
+// gemv_mfma.hip: matrix-core variants, G <= kMaxBatchG geometries [g0, g0+G) per launch
 int launch_gemv_rows_mfma(const GemvRowsLaunch &L, int g0, int G, int tiles, hipStream_t st);
 int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st);
 void plan_rows(RowProblem &P, bool batched);

@@ -243,7 +243,7 @@ class DeviceAOBatch:
 
 class BatchedEvaluator:
     """``count`` independent geometries per call (``evc_energy_with_grad_batch``): every launch covers
-    the whole batch and the t-RDM is streamed once per up to 16 geometries.  Results stay on the device in
+    the whole batch and the t-RDM is streamed once per up to 32 geometries.  Results stay on the device in
     ``energy (G,T)``, ``coeffs (G,T,T)``, ``grad (G,A,3)``."""
 
     def __init__(self, trdms: DeviceTRDMs, natm: int, count: int, stream: Optional["torch.cuda.Stream"] = None,

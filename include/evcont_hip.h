@@ -201,7 +201,7 @@ int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g, const evc
 /* ---------------------------------------------------------------------------------
  * Batched form: `count` independent geometries of the SAME molecule (same N, A, aoslices) per call.
  * Every launch of the pipeline covers the whole batch, and the two streaming kernels read the
- * t-RDM ONCE for up to 16 geometries (K5 becomes (rows,cols)x(cols,G), K8 (G,rows)x(rows,cols)),
+ * t-RDM ONCE for up to 32 geometries (K5 becomes (rows,cols)x(cols,G), K8 (G,rows)x(rows,cols)),
  * so the HBM cost of the t-RDM per evaluation drops by the batch size.  This is the throughput
  * form for PES scans / batched re-evaluations; an MD run is count = 1.
  * All arrays are stacked along a leading batch axis, C order.
