@@ -299,6 +299,37 @@ def main():
                                 "note": "one geometry per step on one stream (no batching, no overlap)",
                                 "k5_rows_ms": md["k5_ms"], "k5_GBs": md["k5_GBs"], "k5_frac": md["k5_GBs"] / HBM_PEAK_GBS,
                                 "k8_cols_ms": md["k8_ms"], "k8_GBs": md["k8_GBs"]}
+    if world == 1 and not a.no_md_regime and not a.energy_only:
+        # an MD-like sequence: geometries that change slowly from step to step (linear blend of two of the
+        # synthetic geometries in 0.1 % steps), one per step on one stream, the eigensolvers warm-started
+        # from the previous step (EVC_FLAG_WARM_START) as evcont_amd.MD_utils.get_scanner does
+        from evcont_amd.evaluator import DeviceAO
+        a0, a1 = aos[0], aos[1]
+        nsteps = 40
+        lerp = lambda x, y, t: torch.lerp(x, y, t)
+        traj = [DeviceAO(S=lerp(a0.S, a1.S, t), hcore=lerp(a0.hcore, a1.hcore, t), eri=lerp(a0.eri, a1.eri, t),
+                         enuc=(1 - t) * a0.enuc + t * a1.enuc, natm=a0.natm, ipovlp=lerp(a0.ipovlp, a1.ipovlp, t),
+                         dhcore=lerp(a0.dhcore, a1.dhcore, t), eri_ip1=lerp(a0.eri_ip1, a1.eri_ip1, t),
+                         gnuc=lerp(a0.gnuc, a1.gnuc, t), aoslices=a0.aoslices)
+                for t in (1e-3 * k for k in range(nsteps))]
+        res = {}
+        for name, warm in (("cold", False), ("warm", True)):
+            ev = ContinuationEvaluator(trd, A, warm_start=warm)
+            for k in range(8):
+                ev.enqueue(traj[k])
+            fence()
+            t0 = time.perf_counter()
+            for k in range(8, nsteps):
+                ev.enqueue(traj[k])
+            fence()
+            res[name] = (nsteps - 8) / (time.perf_counter() - t0)
+            res[name + "_E"] = float(ev.energy[0].item())
+        del traj
+        if rank == 0:
+            out["md_trajectory"] = {"value": res["warm"], "unit": "geometries/s", "cold_start_value": res["cold"],
+                                    "note": "one slowly varying geometry per step, one stream, eigensolvers "
+                                            "warm-started from the previous step; cold_start_value = same sequence "
+                                            "without warm start", "energy_difference": abs(res["warm_E"] - res["cold_E"])}
     if rank == 0:
         if not a.no_cpu_baseline and world == 1 and not a.energy_only:
             samples = a.cpu_samples or (8 if a.workload in ("H30", "Zundel") else 50)

@@ -10,9 +10,10 @@ from __future__ import annotations
 import numpy as np
 
 from .ab_initio_gradients_loewdin import get_energy_with_grad
-from .ab_initio_eigenvector_continuation import approximate_ground_state_OAO  # noqa: F401 (re-export)
+from .ab_initio_eigenvector_continuation import approximate_ground_state_OAO, _trdms  # noqa: F401 (re-export)
 from .electron_integral_utils import get_basis, get_integrals  # noqa: F401 (re-export)
-from .integrals import energy_nuc, grad_nuc
+from .evaluator import ContinuationEvaluator, DeviceAO
+from .integrals import ao_arrays, energy_nuc, grad_nuc
 
 
 def _grad_scanner_base():
@@ -39,12 +40,23 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True):
         def __init__(self):
             self.mol = mol
             self.base = Base()
+            self._ev = None
 
         def __call__(self, mol):
             self.mol = mol
             if one_rdm is not None and two_rdm is not None and overlap is not None:
-                en, grad, rdm_o, rdm_t = get_energy_with_grad(
-                    mol, one_rdm, two_rdm, overlap, hermitian=hermitian, return_density_matrices=True)
+                if not hermitian:
+                    en, grad, rdm_o, rdm_t = get_energy_with_grad(
+                        mol, one_rdm, two_rdm, overlap, hermitian=hermitian, return_density_matrices=True)
+                else:
+                    # the scanner is called once per MD step on slowly moving geometries: it owns an evaluator
+                    # whose eigensolvers start from the previous step's eigenvectors (EVC_FLAG_WARM_START)
+                    ao = ao_arrays(mol, need_grad=True)
+                    if self._ev is None:
+                        self._ev = ContinuationEvaluator(_trdms(one_rdm, two_rdm, overlap),
+                                                         int(np.asarray(ao.aoslices).shape[0]), warm_start=True)
+                    en, grad, rdm_o, rdm_t = self._ev.energy_with_grad(
+                        DeviceAO.from_arrays(ao, self._ev.t.device), return_density_matrices=True)
                 self.base.predicted_one_rdm = rdm_o
                 self.base.predicted_two_rdm = rdm_t
                 return en, grad

@@ -87,12 +87,14 @@ __device__ __forceinline__ void jacobi_rotation(double app, double aqq, double a
     }
 }
 
-__device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double *red) {
+// init_v = false: V already holds an orthogonal matrix and A the matrix in THAT basis (warm start).
+__device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double *red, bool init_v = true) {
     const int tid = threadIdx.x;
     const int tk = tid & 15, tj = tid >> 4;
     const int half = m >> 1;
-    for (int i = tj; i < m; i += 16)
-        for (int j = tk; j < m; j += 16) V[i * m + j] = (i == j) ? 1.0 : 0.0;
+    if (init_v)
+        for (int i = tj; i < m; i += 16)
+            for (int j = tk; j < m; j += 16) V[i * m + j] = (i == j) ? 1.0 : 0.0;
     __syncthreads();
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0.0, dg = 0.0;
@@ -156,6 +158,43 @@ __device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double
     __syncthreads();
 }
 
+// Warm start (EVC_FLAG_WARM_START): `prev` holds the eigenvectors of the previous, nearby problem.  If they
+// are orthonormal to 1e-8 (a stale or never-written buffer is not), V <- prev (padded with the identity) and
+// A <- V^T A V, which is nearly diagonal, so the sweeps that follow are two or three instead of seven or eight.
+// Returns whether the rotation was applied (uniform over the workgroup).  Tmp: n*n doubles of LDS.
+__device__ bool warm_start_rotate(double *A, double *V, double *Tmp, int n, int m, const double *__restrict__ prev,
+                                  int ldp, double *red) {
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < m * m; idx += kThreads) {
+        const int i = idx / m, j = idx - i * m;
+        V[idx] = (i < n && j < n) ? prev[i * ldp + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    mm16(n, [&](int i, int k) { return V[k * m + i]; }, [&](int k, int j) { return V[k * m + j]; },
+         [&](int i, int j, double v) { Tmp[i * n + j] = v - (i == j ? 1.0 : 0.0); });
+    __syncthreads();
+    double dev = 0.0;
+    for (int idx = tid; idx < n * n; idx += kThreads) dev = fma(Tmp[idx], Tmp[idx], dev);
+    dev = block_sum<4>(dev, red);
+    if (!(dev < 1.0e-16)) return false;  // also catches NaN
+    mm16(n, [&](int i, int k) { return A[i * m + k]; }, [&](int k, int j) { return V[k * m + j]; },
+         [&](int i, int j, double v) { Tmp[i * n + j] = v; });
+    __syncthreads();
+    mm16(n, [&](int i, int k) { return V[k * m + i]; }, [&](int k, int j) { return Tmp[k * n + j]; },
+         [&](int i, int j, double v) { A[i * m + j] = v; });
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += kThreads) {  // exact symmetry, as the rotations assume
+        const int i = idx / n, j = idx - i * n;
+        if (i > j) {
+            const double v = 0.5 * (A[i * m + j] + A[j * m + i]);
+            A[i * m + j] = v;
+            A[j * m + i] = v;
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
 // ------------------------------------------------------------------ Loewdin
 __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     const int n = a.n;
@@ -187,7 +226,9 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
         }
     }
     __syncthreads();
-    jacobi_eigh_lds(A, V, m, rot, red);
+    // warm start from the eigenvectors the previous call left in U (same workspace, nearby geometry)
+    const bool warm = a.warm && warm_start_rotate(A, V, Xs, n, m, U, n, red);
+    jacobi_eigh_lds(A, V, m, rot, red, !warm);
     if (tid < m) {
         const double s = A[tid * m + tid];
         f[tid] = (tid < n && s > 1.0e-15) ? 1.0 / sqrt(s) : 0.0;
@@ -250,6 +291,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         if (a.Hout) a.Hout += g * a.sH;
         if (a.w1) a.w1 += g * a.sw;
         if (a.w2) a.w2 += g * a.sw;
+        if (a.vstd) a.vstd += g * a.sw;
         if (a.e_shift_dev) a.e_shift = a.e_shift_dev[g];
     }
     const int T = a.T;
@@ -351,7 +393,11 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         Cm[idx] = v;  // the dummy dimension (odd T) stays decoupled and is skipped below
     }
     __syncthreads();
-    jacobi_eigh_lds(Cm, V, m, rot, red);
+    // warm start from the standard-form eigenvectors of the previous call (H is free as scratch here)
+    const bool warm = a.warm && a.vstd && warm_start_rotate(Cm, V, H, T, m, a.vstd, m, red);
+    jacobi_eigh_lds(Cm, V, m, rot, red, !warm);
+    if (a.vstd)
+        for (int idx = tid; idx < m * m; idx += kThreads) a.vstd[idx] = V[idx];
     // (5) ascending order
     if (tid < T) ev[tid] = Cm[tid * m + tid];
     __syncthreads();

@@ -102,6 +102,7 @@ struct LoewdinArgs {
     double *X, *U, *s, *h1;  // + g*sws        (h1 may be NULL)
     int64_t sS, sh, sws;
     int n;
+    int warm;  // U holds the eigenvectors of a previous, nearby S: start the Jacobi sweeps from them
 };
 int launch_loewdin(const LoewdinArgs &a, int count, hipStream_t st);
 struct SolveArgs {
@@ -120,6 +121,9 @@ struct SolveArgs {
     double *w2, *w1;               // + g*sw
     int64_t sh1, sh2, sev, svec, sH, sw;
     int64_t w2_offset, w2_count;  // slice of the global weight vector to write (multi-GPU)
+    double *vstd;                 // (m,m), m = T rounded up to even: standard-form eigenvectors, kept in the
+                                  // workspace from call to call (+ g*sw); may be NULL
+    int warm;                     // start the Jacobi sweeps from vstd
 };
 int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st);
 struct GradPrepArgs {

@@ -57,6 +57,9 @@ struct Ws {
     double *y2part, *y2, *t2part, *term3;
     // scratch outputs when the caller passes NULL
     double *evals, *evecs;
+    // eigenvectors kept from call to call for EVC_FLAG_WARM_START (U above serves the Loewdin step)
+    double *vstd;
+    bool warm;
     size_t bytes;    // of ONE geometry
     int64_t stride;  // the same in doubles
     RowProblem rp2, rp1;
@@ -141,6 +144,8 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.term3 = take((size_t)(natm > 0 ? natm : 1) * 3);
     w.evals = take(T);
     w.evecs = take(T * T);
+    w.vstd = take(((T + 1) & ~(size_t)1) * ((T + 1) & ~(size_t)1));
+    w.warm = false;
     w.bytes = off;
     w.stride = (int64_t)(off / sizeof(double));
 }
@@ -199,6 +204,7 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
     la.sh = g.sh;
     la.sws = sw;
     la.n = n;
+    la.warm = w.warm ? 1 : 0;
     if ((rc = launch_loewdin(la, cnt, st))) return rc;
     // (ab|cd) -> K3[jkl][a] -> h2[ijkl]
     const double *v2;
@@ -318,6 +324,8 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
     a.sw = sw;
     a.w2_offset = t->row_offset;
     a.w2_count = t->rows2;
+    a.vstd = w.vstd;
+    a.warm = w.warm ? 1 : 0;
     return launch_subspace_solve(a, g.count, st);
 }
 
@@ -640,6 +648,7 @@ extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g
     EVC_REQUIRE(energy_only || out->grad, "outputs.grad is required unless EVC_FLAG_ENERGY_ONLY");
     const Out o = out_single(out);
     int rc;
+    w.warm = (flags & EVC_FLAG_WARM_START) != 0;
     if ((rc = phase_hamiltonian(t, geo, w, false, st))) return rc;
     if ((rc = phase_solve(t, geo, nullptr, 0, o, nroots, w, st))) return rc;
     if (energy_only) return 0;
@@ -714,6 +723,7 @@ extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geome
                 "evc_energy_with_grad_batch needs the complete t-RDM on this device (use the phase calls when sharded)");
     hipStream_t st = as_stream(stream);
     int rc;
+    w.warm = (flags & EVC_FLAG_WARM_START) != 0;
     if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
     if ((rc = phase_solve(t, g, nullptr, 0, o, nroots, w, st))) return rc;
     if (energy_only) return 0;

@@ -322,13 +322,20 @@ class ContinuationEvaluator:
     """Energy / energy+force of the continuation at one geometry per call
     (``get_energy_with_grad``, ``ab_initio_gradients_loewdin.py:308-379``)."""
 
-    def __init__(self, trdms: DeviceTRDMs, natm: int, stream: Optional["torch.cuda.Stream"] = None):
+    def __init__(self, trdms: DeviceTRDMs, natm: int, stream: Optional["torch.cuda.Stream"] = None,
+                 warm_start: bool = False):
         """``stream``: HIP stream every call of this evaluator is enqueued on (default: torch's current
         stream at call time).  Several evaluators on different streams may share one ``DeviceTRDMs``:
-        each owns its workspace and outputs, so independent geometries overlap on the device."""
+        each owns its workspace and outputs, so independent geometries overlap on the device.
+
+        ``warm_start``: consecutive calls are steps of one trajectory (``EVC_FLAG_WARM_START``): from the
+        second call on, the two Jacobi eigensolvers start from the eigenvectors the previous call left in the
+        workspace.  Same results to solver tolerance (~1e-14), not bit for bit."""
         self.t = trdms
         self.natm = int(natm)
         self.stream = stream
+        self.warm_start = bool(warm_start)
+        self._primed = False
         self.lib = _lib.load()
         d, n, T = trdms.device, trdms.n, trdms.T
         nbytes = self.lib.evc_workspace_bytes(C.byref(trdms.cstruct), self.natm)
@@ -356,9 +363,12 @@ class ContinuationEvaluator:
         """Enqueue one evaluation on torch's current stream; no synchronisation."""
         g = ao.cstruct()
         flags = _lib.FLAG_ENERGY_ONLY if energy_only else 0
+        if self.warm_start and self._primed:
+            flags |= _lib.FLAG_WARM_START
         rc = self.lib.evc_energy_with_grad(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out), int(nroots), flags,
                                            self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_energy_with_grad")
+        self._primed = True
 
     def energy_with_grad(self, ao: DeviceAO, return_density_matrices: bool = False):
         self.enqueue(ao, 1, False)

@@ -180,6 +180,11 @@ typedef struct evc_outputs {
 #define EVC_FLAG_ENERGY_ONLY 1  /* stop after the eigensolve */
 #define EVC_FLAG_PARTIAL_RANK 2 /* multi-GPU: this rank is not rank 0 -> its partial gradient carries
                                    only the two-body contribution of its rows */
+#define EVC_FLAG_WARM_START 4   /* the workspace holds the results of a previous evaluation at a NEARBY geometry
+                                   (an MD step): the two Jacobi eigensolvers (overlap matrix, subspace problem) start
+                                   from its eigenvectors and converge in 2-3 sweeps instead of 7-8.  Results agree
+                                   with a cold start to solver tolerance (~1e-14), not bit for bit; stale or
+                                   never-written eigenvectors are detected and ignored.  Fused entry points only. */
 
 size_t evc_workspace_bytes(const evc_trdm_set *t, int natm);
 
