@@ -56,8 +56,8 @@ MAX_G_PER_LAUNCH = 32   # geometries that share one pass over the t-RDM (csrc/ge
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=60)
-    p.add_argument("--warmup", type=int, default=6)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--workload", default="H30", choices=list(WORKLOADS))
     p.add_argument("--layout", default="pack2", choices=list(LAYOUT_ND))
     p.add_argument("--geoms", type=int, default=64, help="distinct synthetic geometries resident on the device")
