@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libevcont_hip.so")
 
 LAYOUT_FULL6, LAYOUT_PAIR5, LAYOUT_ELEC3, LAYOUT_PACK2 = 6, 5, 3, 2
 FLAG_ENERGY_ONLY, FLAG_PARTIAL_RANK, FLAG_WARM_START = 1, 2, 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_double_p = C.c_void_p  # device pointers travel as integers
 

@@ -272,7 +272,7 @@ int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     static const int v4 = env_int("EVC_ROWS_G4", 0);   // 0: wave-rows RBW=8; 1: wave-rows RBW=4; 2: lane-private RB=4
     static const int mfma_min = env_int("EVC_MFMA_MIN_G", 12);   // groups of >= this many geometries use the matrix cores
     static const int mfma_max = env_int("EVC_MFMA_MAX_G", 32);   // geometries per pass over the matrix (16 or 32)
-    static const int mfma_tiles = env_int("EVC_MFMA_TILES", 0);   // 0: pipelined 4-tile kernel; 4/8/16: un-pipelined variants
+    static const int mfma_tiles = env_int("EVC_MFMA_TILES", 0);   // most 16-row tiles per row group (0: default, 3)
     int g0 = 0;
     while (g0 < count) {
         const int left = count - g0;
@@ -356,9 +356,10 @@ __global__ __launch_bounds__(256) void gemv_cols_kernel(GemvColsLaunch L, int g0
         for (int64_t r0 = 0; r0 < rows; r0 += kWTile) {
             const int nr = (int)min((int64_t)kWTile, rows - r0);
             __syncthreads();
+            // consecutive lanes read consecutive rows of one geometry's weight vector (coalesced)
             for (int idx = threadIdx.x; idx < nr * G; idx += 256) {
-                const int r = idx / G, g = idx - r * G;
-                wl[idx] = w[(int64_t)g * P.wstride + r0 + r];
+                const int g = idx / nr, r = idx - g * nr;
+                wl[r * G + g] = w[(int64_t)g * P.wstride + r0 + r];
             }
             __syncthreads();
             if (active && two) {

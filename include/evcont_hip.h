@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 1
+#define EVC_ABI_VERSION 2 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
