@@ -2,7 +2,7 @@
 //   K5/K4  rows GEMV   y[g][r]   = sum_c A[r,c] v[g][c]     (H_ab build,      evcont.py:38-68)
 //   K8/K7  cols GEMV   out[g][c] = sum_r w[g][r] A[r,c]     (predicted RDMs,  gradients_loewdin.py:343-356)
 // A (the t-RDM) is shared by a batch of geometries, so one pass over the 0.68-2.6 GB matrix serves
-// G evaluations: G <= 8 per pass with the VALU kernels of this file, 12..16 with the matrix-core
+// G evaluations: G <= 8 per pass with the VALU kernels of this file, 12..32 with the matrix-core
 // variants of gemv_mfma.hip (the dispatch at the bottom of this file picks per group).
 // Each launch carries TWO problems (the two-body and the one-body t-RDM) so the small one rides
 // along with the big one instead of costing a kernel boundary.
