@@ -48,7 +48,8 @@ WORKLOADS = {
     "H2O": (13, 3, 10, (9, 2, 2)),        # configs[3] (T assumed 10)
     "Zundel": (28, 7, 30, (9, 2, 2, 2, 9, 2, 2)),  # configs[4]
 }
-LAYOUT_ND = {"full6": 6, "pair5": 5, "elec3": 3, "pack2": 2}
+LAYOUT_ND = {"full6": 6, "pair5": 5, "elec3": 3, "pack2": 2,
+             "sym8": 8}   # sym8: 8-fold compressed device layout, built from the pack2 rows (include/evcont_hip.h)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (~6 TB/s achievable by a plain streaming read)
 MAX_G_PER_LAUNCH = 32   # geometries that share one pass over the t-RDM (csrc/gemv_mfma.hip)
 
@@ -78,7 +79,11 @@ def cpu_baseline(workload, layout_nd, trd, aos, samples):
     host cores for a bounded sample of the same workload."""
     from oracle import evcont_oracle as orc
     n, A, T, _ = WORKLOADS[workload]
-    two = trd.two[: trd.rows_local, : trd.cols].cpu().numpy()
+    if layout_nd == 8:
+        # the CPU path works on the reference's own layout: the pack2 rows the compressed set was built from
+        two, layout_nd = trd.source_rows().cpu().numpy(), 2
+    else:
+        two = trd.two[: trd.rows_local, : trd.cols].cpu().numpy()
     if layout_nd == 6:
         two = two.reshape(T, T, n, n, n, n)
     elif layout_nd == 5:
@@ -146,11 +151,18 @@ def main():
     lib = _lib.load()
 
     def trdms(row_range):
-        S_train, one, two_rows = make_device_trdm_rows(n, T, nd, seed, dev, row_range)
-        return DeviceTRDMs.from_device_rows(one, two_rows, S_train, nd, row_range[0], rows)
+        src_nd = 2 if nd == 8 else nd
+        S_train, one, two_rows = make_device_trdm_rows(n, T, src_nd, seed, dev, row_range)
+        t = DeviceTRDMs.from_device_rows(one, two_rows, S_train, src_nd, row_range[0], rows)
+        if nd == 8:
+            del two_rows
+            t.compress_sym8_()
+            t.source_rows = lambda: make_device_trdm_rows(n, T, 2, seed, dev, row_range)[2]
+        return t
 
     def geometries(first_seed):
-        return [make_device_ao(n, A, first_seed + k, dev, sizes) for k in range(a.geoms)]
+        # eri 8-fold symmetric and eri_ip1 symmetric in its last two indices, as real int2e / int2e_ip1 are
+        return [make_device_ao(n, A, first_seed + k, dev, sizes, ip1_rs_symmetric=True) for k in range(a.geoms)]
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -13,8 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libevcont_hip.so")
 
 LAYOUT_FULL6, LAYOUT_PAIR5, LAYOUT_ELEC3, LAYOUT_PACK2 = 6, 5, 3, 2
+LAYOUT_SYM8 = 8   # device-side 8-fold compressed layout (include/evcont_hip.h EVC_LAYOUT_SYM8)
 FLAG_ENERGY_ONLY, FLAG_PARTIAL_RANK, FLAG_WARM_START = 1, 2, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_double_p = C.c_void_p  # device pointers travel as integers
 

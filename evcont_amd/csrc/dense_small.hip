@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     int *order = reinterpret_cast<int *>(ev + m);                              // m
     const int tid = threadIdx.x;
     const int64_t P = (int64_t)T * (T + 1) / 2;
-    const bool pairs = (a.layout == EVC_LAYOUT_PAIR5 || a.layout == EVC_LAYOUT_PACK2);
+    const bool pairs = (a.layout == EVC_LAYOUT_PAIR5 || a.layout == EVC_LAYOUT_PACK2 || a.layout == EVC_LAYOUT_SYM8);
     const int64_t rows2 = pairs ? P : (int64_t)T * T;
 
     // (1) one-body rows (partials are stored [span][row]: coalesced over rows)

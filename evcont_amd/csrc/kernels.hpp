@@ -60,11 +60,17 @@ struct PairTransformArgs {
     double diag_mult;
     int ct, n;
     int tiles_per_wg;   // set by launch_pair_transform: consecutive 8-wide q tiles per workgroup
+    int sym8;           // `packed` is the 8-fold compressed vector (EVC_LAYOUT_SYM8), multiplicities folded in
 };
 constexpr int kPairTransformMaxN = 32;
 int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);
 int launch_pack(const double *h2, int64_t sh2, int n, double diag_mult, double *out, int64_t sout, int64_t out_len,
                 int count, hipStream_t st);
+// 8-fold compressed vector of a tensor with the index symmetries of real two-electron integrals:
+//   out[tri(u,v)] = h2[i,j,k,l] * (u == v ? diag_mult : 1) * (i != j ? 2 : 1) * (k != l ? 2 : 1),
+//   u = tri(i,j) (i >= j), v = tri(k,l) (k >= l), u >= v
+int launch_pack_sym8(const double *h2, int64_t sh2, int n, double diag_mult, double *out, int64_t sout,
+                     int64_t out_len, int count, hipStream_t st);
 int launch_unpack(const double *packed, int64_t sp, int n, double *out, int64_t sout, int count, hipStream_t st);
 // Gs^T[jkl][i] = G[i,j,k,l] + G[j,i,k,l] + G[l,k,j,i] + G[k,l,i,j]   (gradients_loewdin.py:213-215)
 int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t sout, int count, hipStream_t st);
@@ -73,8 +79,9 @@ int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t so
 //   SB[i,j,k,l] = 2 (p(ij,kl) + p(ji,lk))                  (= AO-type symmetrisation, gradients_loewdin.py:238-240,
 //                                                             applied BEFORE the OAO->AO rotation, with which it commutes)
 //   G[i,j,k,l]  = p(ij,kl)                                 (optional: the unpacked 2-RDM, eiu:69-88)
+// sym8: `packed` is the 8-fold compressed vector p8 of a fully symmetric 2-RDM: GsT = SB = 4 p8(ijkl), G = p8(ijkl)
 int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
-                      int64_t sG, int count, hipStream_t st);
+                      int64_t sG, int count, int sym8, hipStream_t st);
 // partial[b][i][a] = sum_{k in slab b} GsT[k][i] * K3[k][a]   (k = jkl)
 int y2_slabs(int n);
 int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);

@@ -84,17 +84,18 @@ static int stage_chunk(int count) {
 // Many spans: sum the partials in a multi-workgroup launch instead of inside the eigensolver kernel.
 static bool reduce_in_own_launch(const Ws &w) { return w.rp2.nspans > 48; }
 
-static bool is_packed(int layout) { return layout == EVC_LAYOUT_ELEC3 || layout == EVC_LAYOUT_PACK2; }
-static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout == EVC_LAYOUT_PACK2; }
+static bool is_sym8(int layout) { return layout == EVC_LAYOUT_SYM8; }
+static bool is_packed(int layout) { return layout == EVC_LAYOUT_ELEC3 || layout == EVC_LAYOUT_PACK2 || is_sym8(layout); }
+static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout == EVC_LAYOUT_PACK2 || is_sym8(layout); }
 
 static int check_set(const evc_trdm_set *t) {
     EVC_REQUIRE(t != nullptr, "trdm_set is NULL");
     EVC_REQUIRE(t->n >= 1 && t->n <= 64, "trdm_set: n=%d out of range 1..64", t->n);
     EVC_REQUIRE(t->ntrain >= 1 && t->ntrain <= 64, "trdm_set: ntrain=%d out of range 1..64", t->ntrain);
-    EVC_REQUIRE(t->layout == 6 || t->layout == 5 || t->layout == 3 || t->layout == 2,
-                "trdm_set: layout=%d (must be the ndim of two_RDM: 6, 5, 3 or 2)", t->layout);
-    const int64_t n2 = (int64_t)t->n * t->n;
-    const int64_t cols = is_packed(t->layout) ? n2 * (n2 + 1) / 2 : n2 * n2;
+    EVC_REQUIRE(t->layout == 6 || t->layout == 5 || t->layout == 3 || t->layout == 2 || t->layout == EVC_LAYOUT_SYM8,
+                "trdm_set: layout=%d (must be the ndim of two_RDM: 6, 5, 3 or 2, or EVC_LAYOUT_SYM8)", t->layout);
+    const int64_t n2 = (int64_t)t->n * t->n, ns = (int64_t)t->n * (t->n + 1) / 2;
+    const int64_t cols = is_sym8(t->layout) ? ns * (ns + 1) / 2 : is_packed(t->layout) ? n2 * (n2 + 1) / 2 : n2 * n2;
     const int64_t rows = is_pairs(t->layout) ? (int64_t)t->ntrain * (t->ntrain + 1) / 2
                                               : (int64_t)t->ntrain * t->ntrain;
     EVC_REQUIRE(t->cols2 == cols, "trdm_set: cols2=%lld, expected %lld", (long long)t->cols2, (long long)cols);
@@ -247,6 +248,7 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
                 pa.spacked = sw;
                 pa.packed_len = t->ld2;
                 pa.diag_mult = 0.5;
+                pa.sym8 = is_sym8(t->layout) ? 1 : 0;
             } else {
                 pa.out = w.B2 + o;
             }
@@ -259,7 +261,9 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
         if ((rc = launch_quarter_transform(w.K3, sw, w.X, sw, 0, n, w.B1, sw, cnt, st))) return rc;
         v2 = w.B1;
         if (is_packed(t->layout)) {
-            if ((rc = launch_pack(w.B1, sw, n, 0.5, w.vec2, sw, t->ld2, cnt, st))) return rc;
+            rc = is_sym8(t->layout) ? launch_pack_sym8(w.B1, sw, n, 0.5, w.vec2, sw, t->ld2, cnt, st)
+                                    : launch_pack(w.B1, sw, n, 0.5, w.vec2, sw, t->ld2, cnt, st);
+            if (rc) return rc;
             v2 = w.vec2;
         }
     }
@@ -347,10 +351,11 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
 // Gradient of the energy functional defined by (D, G) [G unpacked, N^4] given X,U,s,K3 in the
 // workspace.  scale1 = 0 drops everything that is not linear in G (multi-GPU partial ranks).
 // `packed` != NULL selects the fast path for pair-symmetric (packed) predicted 2-RDMs: both symmetrisations
-// are taken straight from the packed vector (G is then only written when the caller wants it, G may be NULL).
+// are taken straight from the packed vector (G is then only written when the caller wants it, G may be NULL);
+// sym8: the packed vector is the 8-fold compressed one (EVC_LAYOUT_SYM8).
 static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, double *G, int64_t sG,
-                              const double *packed, int64_t spacked, double scale1, bool add_gnuc, double *grad,
-                              int64_t sgrad, Ws &w, hipStream_t st) {
+                              const double *packed, int64_t spacked, int sym8, double scale1, bool add_gnuc,
+                              double *grad, int64_t sgrad, Ws &w, hipStream_t st) {
     const int cnt = g.count;
     const int64_t sw = w.stride;
     int rc;
@@ -426,7 +431,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 const int cc = cnt - c0 < chunk ? cnt - c0 : chunk;
                 const int64_t o = (int64_t)c0 * sw;
                 if ((rc = launch_unpack_sym(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, w.B1 + o, sw,
-                                            G ? G + (int64_t)c0 * sG : nullptr, sG, cc, st)))
+                                            G ? G + (int64_t)c0 * sG : nullptr, sG, cc, sym8, st)))
                     return rc;
                 if ((rc = launch_y2(w.B2 + o, w.K3 + o, n, w.y2part + o, sw, cc, st))) return rc;
                 PairTransformArgs pa;
@@ -447,7 +452,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
             }
             ip1_done = true;
         } else {
-            if ((rc = launch_unpack_sym(packed, spacked, n, w.B2, w.B1, sw, G, sG, cnt, st))) return rc;
+            if ((rc = launch_unpack_sym(packed, spacked, n, w.B2, w.B1, sw, G, sG, cnt, sym8, st))) return rc;
             if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, sw, cnt, st))) return rc;
             if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
             if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
@@ -523,9 +528,9 @@ static int phase_gradient(const evc_trdm_set *t, const Geo &g, const Out &out, i
     const bool partial = (flags & EVC_FLAG_PARTIAL_RANK) != 0;
     if (is_packed(t->layout))
         // the unpacked 2-RDM is only materialised when the caller asked for it
-        return gradient_from_rdms(n, g, D, sD, out.g_pred, out.sG, w.vec2, sw, partial ? 0.0 : 1.0, !partial,
-                                  out.grad, out.sg, w, st);
-    return gradient_from_rdms(n, g, D, sD, G, sG, nullptr, 0, partial ? 0.0 : 1.0, !partial, out.grad, out.sg, w,
+        return gradient_from_rdms(n, g, D, sD, out.g_pred, out.sG, w.vec2, sw, is_sym8(t->layout) ? 1 : 0,
+                                  partial ? 0.0 : 1.0, !partial, out.grad, out.sg, w, st);
+    return gradient_from_rdms(n, g, D, sD, G, sG, nullptr, 0, 0, partial ? 0.0 : 1.0, !partial, out.grad, out.sg, w,
                               st);
 }
 
@@ -806,7 +811,8 @@ extern "C" int evc_subspace_solve(const double *h1rows, const double *h2rows, co
                                   double *w2, double *w1, double *Hout, void *stream) {
     EVC_REQUIRE(h1rows && h2rows && S_train && evals && evecs, "evc_subspace_solve: null pointer");
     EVC_REQUIRE(T >= 1 && T <= 64, "evc_subspace_solve: T=%d out of range 1..64", T);
-    EVC_REQUIRE(layout == 6 || layout == 5 || layout == 3 || layout == 2, "evc_subspace_solve: layout=%d", layout);
+    EVC_REQUIRE(layout == 6 || layout == 5 || layout == 3 || layout == 2 || layout == EVC_LAYOUT_SYM8,
+                "evc_subspace_solve: layout=%d", layout);
     EVC_REQUIRE(nroots >= 1 && nroots <= T, "evc_subspace_solve: nroots=%d out of range", nroots);
     SolveArgs a;
     memset(&a, 0, sizeof(a));
@@ -987,6 +993,6 @@ extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *tra
     if ((rc = launch_quarter_transform(g->eri, 0, w.X, 0, 0, n, w.B1, 0, 1, st))) return rc;
     if ((rc = launch_quarter_transform(w.B1, 0, w.X, 0, 0, n, w.B2, 0, 1, st))) return rc;
     if ((rc = launch_quarter_transform(w.B2, 0, w.X, 0, 0, n, w.K3, 0, 1, st))) return rc;
-    return gradient_from_rdms(n, geo, one_rdm, 0, const_cast<double *>(two_rdm), 0, nullptr, 0, 1.0, false, grad, 0,
+    return gradient_from_rdms(n, geo, one_rdm, 0, const_cast<double *>(two_rdm), 0, nullptr, 0, 0, 1.0, false, grad, 0,
                               w, st);
 }

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
         for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32)
             if (ql < nq) out[(int64_t)rs * n2 + (int64_t)p * n + q0 + ql] = stage[rs * QP + ql];
     }
-    if (a.packed) {
+    if (a.packed && !a.sym8) {
         double *pk = a.packed + g * a.spacked;
         for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {
             const int64_t R = rs, Cc = (int64_t)p * n + q0 + ql;
@@ -273,6 +273,26 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
         // zero the padding [M, packed_len) once per geometry
         if (blockIdx.x == 0 && tq == tq_begin) {
             const int64_t M = n2 * (n2 + 1) / 2;
+            for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
+        }
+    }
+    if (a.packed && a.sym8) {
+        // 8-fold compressed vector: only r' >= s', p >= q, (r's') >= (pq) is kept, with its multiplicity
+        double *pk = a.packed + g * a.spacked;
+        const int q = q0 + ql;
+        if (ql < nq && p >= q) {
+            const int64_t v = tri_index(p, q);
+            const double mq = (p != q) ? 2.0 : 1.0;
+            for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {
+                const int r2 = rs / n, s2 = rs - r2 * n;
+                const int64_t u = tri_index(r2, s2);
+                if (r2 >= s2 && u >= v)
+                    pk[tri_index(u, v)] =
+                        stage[rs * QP + ql] * ((u == v ? a.diag_mult : 1.0) * mq * (r2 != s2 ? 2.0 : 1.0));
+            }
+        }
+        if (blockIdx.x == 0 && tq == tq_begin) {
+            const int64_t mm = (int64_t)n * (n + 1) / 2, M = mm * (mm + 1) / 2;
             for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
         }
     }
@@ -340,6 +360,26 @@ __global__ void unpack_kernel(const double *__restrict__ p, int64_t sp, int n, d
     }
 }
 
+// 8-fold compressed form (EVC_LAYOUT_SYM8) of a tensor with the symmetries of real two-electron integrals
+__global__ void pack_sym8_kernel(const double *__restrict__ h2, int64_t sh2, int n, double mult,
+                                 double *__restrict__ out, int64_t sout, int64_t M, int64_t out_len) {
+    const int64_t n2 = (int64_t)n * n;
+    h2 += (int64_t)blockIdx.y * sh2;
+    out += (int64_t)blockIdx.y * sout;
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < out_len;
+         m += (int64_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (m < M) {
+            const int64_t u = tri_row(m), w = m - u * (u + 1) / 2;
+            const int64_t i = tri_row(u), j = u - i * (i + 1) / 2;
+            const int64_t k = tri_row(w), l = w - k * (k + 1) / 2;
+            v = h2[(i * n + j) * n2 + k * n + l] *
+                ((u == w ? mult : 1.0) * (i != j ? 2.0 : 1.0) * (k != l ? 2.0 : 1.0));
+        }
+        out[m] = v;
+    }
+}
+
 static unsigned grid_for(int64_t work, int block) {
     int64_t g = (work + block - 1) / block;
     if (g > 8192) g = 8192;
@@ -353,6 +393,15 @@ int launch_pack(const double *h2, int64_t sh2, int n, double mult, double *out, 
     hipLaunchKernelGGL(pack_kernel, dim3(grid_for(out_len, 256), (unsigned)count), dim3(256), 0, st, h2, sh2, n, mult,
                        out, sout, M, out_len);
     EVC_LAUNCH_CHECK("pack_pair_sym");
+    return 0;
+}
+
+int launch_pack_sym8(const double *h2, int64_t sh2, int n, double mult, double *out, int64_t sout, int64_t out_len,
+                     int count, hipStream_t st) {
+    const int64_t mm = (int64_t)n * (n + 1) / 2, M = mm * (mm + 1) / 2;
+    hipLaunchKernelGGL(pack_sym8_kernel, dim3(grid_for(out_len, 256), (unsigned)count), dim3(256), 0, st, h2, sh2, n,
+                       mult, out, sout, M, out_len);
+    EVC_LAUNCH_CHECK("pack_sym8");
     return 0;
 }
 
@@ -397,7 +446,7 @@ int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t so
 __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restrict__ p, int64_t sp, int n,
                                                          double *__restrict__ GsT, double *__restrict__ SB,
                                                          int64_t sws, double *__restrict__ Gout, int64_t sG,
-                                                         int count) {
+                                                         int count, int sym8) {
     extern __shared__ __align__(16) double tile[];  // [l][i], row length n+1
     const int64_t n2 = (int64_t)n * n, n3 = n2 * n;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; the blocks an XCD receives work
@@ -425,9 +474,17 @@ __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restric
     auto P = [&](int64_t a, int64_t b) { return a >= b ? p[tri_index(a, b)] : p[tri_index(b, a)]; };
     for (int idx = threadIdx.x; idx < n * n; idx += 256) {
         const int i = idx / n, l = idx - i * n;
+        const int64_t o = i * n3 + j * n2 + k * n + l;
+        if (sym8) {
+            // fully symmetric 2-RDM: every image of (i,j,k,l) is the same element of the compressed vector
+            const double p1 = P(i >= j ? tri_index(i, j) : tri_index(j, i), k >= l ? tri_index(k, l) : tri_index(l, k));
+            SB[o] = 4.0 * p1;
+            if (Gout) Gout[o] = p1;
+            tile[l * (n + 1) + i] = 4.0 * p1;
+            continue;
+        }
         const int64_t R = (int64_t)i * n + j, Rt = (int64_t)j * n + i, Cc = (int64_t)k * n + l, Ct = (int64_t)l * n + k;
         const double p1 = P(R, Cc), p2 = P(Rt, Cc), p3 = P(Rt, Ct);
-        const int64_t o = i * n3 + j * n2 + k * n + l;
         SB[o] = 2.0 * (p1 + p3);
         if (Gout) Gout[o] = p1;
         tile[l * (n + 1) + i] = 2.0 * p1 + p2 + p3;
@@ -441,10 +498,10 @@ __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restric
 }
 
 int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
-                      int64_t sG, int count, hipStream_t st) {
+                      int64_t sG, int count, int sym8, hipStream_t st) {
     const size_t lds = sizeof(double) * (size_t)n * (n + 1);
     hipLaunchKernelGGL(unpack_sym_kernel, dim3((unsigned)(n * n * count)), dim3(256), lds, st, packed, sp, n, GsT, SB,
-                       sws, G, sG, count);
+                       sws, G, sG, count, sym8);
     EVC_LAUNCH_CHECK("unpack_sym");
     return 0;
 }

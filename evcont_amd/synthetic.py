@@ -58,7 +58,11 @@ def equal_aoslices(nao: int, natm: int) -> np.ndarray:
 def make_ao_arrays(nao: int, natm: int, seed: int,
                    ao_sizes: Optional[Sequence[int]] = None,
                    degenerate_S: bool = False,
-                   with_ip1: bool = True) -> AOArrays:
+                   with_ip1: bool = True,
+                   ip1_rs_symmetric: bool = False) -> AOArrays:
+    """``ip1_rs_symmetric``: give ``eri_ip1`` the one index symmetry ``int2e_ip1 = (grad p q|r s)`` has,
+    r <-> s (the default leaves it a general tensor, which exercises the gradient formula harder; the
+    8-fold compressed t-RDM layout needs the symmetry, as real integrals have it)."""
     rng = np.random.default_rng(seed)
     n = nao
     B = rng.standard_normal((n, n))
@@ -81,6 +85,8 @@ def make_ao_arrays(nao: int, natm: int, seed: int,
     dhcore = 0.5 * (dh + dh.transpose(0, 1, 3, 2))
     if with_ip1:
         eri_ip1 = 0.1 * rng.standard_normal((3, n, n, n, n))
+        if ip1_rs_symmetric:
+            eri_ip1 = np.ascontiguousarray(0.5 * (eri_ip1 + eri_ip1.transpose(0, 1, 2, 4, 3)))
     else:
         eri_ip1 = np.zeros((3, n, n, n, n))
     if ao_sizes is None:
@@ -130,7 +136,8 @@ def pack_rows(two_rdm_full: np.ndarray, pair_sym: bool, elec_sym: bool) -> np.nd
 # symmetries, generated with torch.Generator(device) so that multi-GB inputs
 # never cross PCIe.  Imported lazily so that the numpy part works without torch.
 # --------------------------------------------------------------------------
-def make_device_ao(nao: int, natm: int, seed: int, device, ao_sizes: Optional[Sequence[int]] = None):
+def make_device_ao(nao: int, natm: int, seed: int, device, ao_sizes: Optional[Sequence[int]] = None,
+                   ip1_rs_symmetric: bool = False):
     """One synthetic geometry resident on the device (evaluator.DeviceAO)."""
     import torch
     from .evaluator import DeviceAO
@@ -149,6 +156,8 @@ def make_device_ao(nao: int, natm: int, seed: int, device, ao_sizes: Optional[Se
     dh = rn(natm, 3, n, n)
     dhcore = 0.5 * (dh + dh.transpose(2, 3))
     ip1 = 0.1 * rn(3, n, n, n, n)
+    if ip1_rs_symmetric:
+        ip1 = 0.5 * (ip1 + ip1.transpose(3, 4))
     if ao_sizes is None:
         sl = equal_aoslices(n, natm)
     else:

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 2 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START */
+#define EVC_ABI_VERSION 3 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
+                             3: EVC_LAYOUT_SYM8 */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
@@ -35,6 +36,16 @@ extern "C" {
 #define EVC_LAYOUT_PAIR5 5 /* (P,N,N,N,N)    rows=T(T+1)/2   cols=N^4          */
 #define EVC_LAYOUT_ELEC3 3 /* (T,T,M)        rows=T*T        cols=N^2(N^2+1)/2 */
 #define EVC_LAYOUT_PACK2 2 /* (P,M)          rows=T(T+1)/2   cols=M            */
+/* Device-side compressed layout (no counterpart in the reference): per training pair (a >= b) the
+ * 8-fold symmetrised t-RDM
+ *   Gs[i,j,k,l] = mean of Gamma over (i<->j), (k<->l), (ij<->kl)
+ * stored for i >= j, k >= l, u = i(i+1)/2+j >= v = k(k+1)/2+l at column u(u+1)/2+v:
+ *   rows = T(T+1)/2, cols = Ms(Ms+1)/2 with Ms = N(N+1)/2      (3.7x fewer bytes than PACK2 at N = 30).
+ * H_ab and the nuclear gradient only see this part of Gamma WHEN THE AO INTEGRALS HAVE THE INDEX
+ * SYMMETRIES OF REAL TWO-ELECTRON INTEGRALS: eri[p,q,r,s] 8-fold symmetric and eri_ip1[x,p,q,r,s] =
+ * eri_ip1[x,p,q,s,r] (true for every int2e / int2e_ip1 of real AOs).  Energies, coefficients and gradients are
+ * then those of the reference layouts to rounding; g_pred is the symmetrised predicted 2-RDM. */
+#define EVC_LAYOUT_SYM8 8
 
 int evc_abi_version(void);
 /* Message of the last failing call on this host thread ("" if none). */

@@ -1,0 +1,183 @@
+"""GPU tests of the 8-fold compressed t-RDM layout (EVC_LAYOUT_SYM8, include/evcont_hip.h): built on the
+device from any of the reference's four layouts, it must give the reference's energies, coefficients and
+forces (the oracle is run on the ORIGINAL, un-symmetrised t-RDMs) whenever the AO integrals carry the index
+symmetries of real two-electron integrals -- on seeded tensors with those symmetries and on physical
+hydrogen-chain integrals.  Tolerances as in test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from evcont_amd.synthetic import make_ao_arrays, make_trdms, pack_rows
+from oracle import evcont_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+LAYOUTS = {"full6": (False, False), "pair5": (True, False), "elec3": (False, True), "pack2": (True, True)}
+
+
+def layout(two, name):
+    p, e = LAYOUTS[name]
+    return pack_rows(two, p, e) if (p or e) else two
+
+
+def sym8(G):
+    """Mean over the index permutations of real two-electron integrals (last four axes)."""
+    a = G + np.swapaxes(G, -4, -3)
+    a = a + np.swapaxes(a, -2, -1)
+    a = a + np.moveaxis(a, (-2, -1), (-4, -3))
+    return a / 8.0
+
+
+def bundle(a):
+    return orc.AOBundle(a.S, a.hcore, a.eri, a.ipovlp, a.dhcore, a.eri_ip1, a.aoslices, a.enuc, a.gnuc)
+
+
+def test_layout_shape_and_column_order():
+    """Column u(u+1)/2+v, u = i(i+1)/2+j: the compressed rows are the symmetrised tensor at those indices."""
+    from evcont_amd.evaluator import DeviceTRDMs, layout_shape
+    dev = torch.device("cuda:0")
+    n, T = 5, 3
+    S, one, two = make_trdms(n, T, 11)
+    assert layout_shape(8, T, n) == (T * (T + 1) // 2, 15 * 16 // 2)
+    ref = None
+    for lname in LAYOUTS:
+        t = DeviceTRDMs(one, layout(two, lname), S, dev, compress="sym8")
+        assert t.layout == 8 and (t.rows_total, t.cols) == layout_shape(8, T, n) and t.ld % 16 == 0
+        rows = t.two[:, : t.cols].cpu().numpy()
+        if ref is None:
+            gs = sym8(two)
+            a, b = np.tril_indices(T)
+            iu, ju = np.tril_indices(n)
+            U, V = np.tril_indices(len(iu))
+            ref = gs[a, b][:, iu[U], ju[U], iu[V], ju[V]]
+        np.testing.assert_allclose(rows, ref, rtol=0, atol=1e-15)
+        assert float(t.two[:, t.cols:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,T,A,lname", [
+    (4, 2, 2, "full6"), (6, 3, 3, "pair5"), (7, 4, 2, "elec3"), (10, 5, 10, "pack2"),
+    (17, 4, 3, "pack2"),       # pair transform <32>, ragged q tile
+    (30, 3, 5, "pack2"),       # N of the headline workload
+    (34, 2, 2, "pack2"),       # N > 32: quarter steps + pack_sym8 kernel
+])
+def test_sym8_matches_reference_layouts(n, T, A, lname):
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
+    dev = torch.device("cuda:0")
+    S, one, two = make_trdms(n, T, 40 + n)
+    two_l = layout(two, lname)
+    ao = make_ao_arrays(n, A, 90 + n, ip1_rs_symmetric=True)
+    ev = ContinuationEvaluator(DeviceTRDMs(one, two_l, S, dev, compress="sym8"), A)
+    E, g, D, G = ev.energy_with_grad(DeviceAO.from_arrays(ao, dev), return_density_matrices=True)
+    Eo, go, Do, Go = orc.energy_with_grad(bundle(ao), one, two_l, S, True, True)
+    assert abs(E - Eo) < 1e-10
+    np.testing.assert_allclose(g, go, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(D, Do, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(G, sym8(np.asarray(Go).reshape(n, n, n, n)), rtol=0, atol=1e-11)
+    # excited roots and coefficient vectors of the energy-only call
+    nroots = min(T, 3)
+    e, c = ev.energies(DeviceAO.from_arrays(ao, dev), nroots)
+    X = orc.loewdin_trafo(ao.S)
+    h1, h2 = orc.integrals_oao(bundle(ao), X)
+    eo, co = orc.approximate_multistate(h1, h2, one, two_l, S, nroots)
+    np.testing.assert_allclose(e, np.asarray(eo) + ao.enuc, rtol=0, atol=1e-10)
+
+
+def test_sym8_needs_the_integral_symmetry():
+    """With a general (not r<->s symmetric) eri_ip1 the compressed layout must NOT be expected to agree:
+    documents the precondition (energies still agree, forces differ)."""
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
+    dev = torch.device("cuda:0")
+    n, T, A = 6, 3, 3
+    S, one, two = make_trdms(n, T, 5)
+    ao = make_ao_arrays(n, A, 6)                       # general eri_ip1
+    ev = ContinuationEvaluator(DeviceTRDMs(one, two, S, dev, compress="sym8"), A)
+    E, g = ev.energy_with_grad(DeviceAO.from_arrays(ao, dev))
+    Eo, go = orc.energy_with_grad(bundle(ao), one, two, S)
+    assert abs(E - Eo) < 1e-10
+    assert np.abs(g - go).max() > 1e-4
+    # ... and it is exactly the reference formula applied to the symmetrised t-RDMs
+    Es, gs = orc.energy_with_grad(bundle(ao), one, sym8(two), S)
+    np.testing.assert_allclose(g, gs, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,T,A,G", [(10, 5, 10, 3), (18, 6, 3, 9), (21, 5, 3, 17), (12, 4, 4, 33)])
+def test_sym8_batched(n, T, A, G):
+    """Batched evaluator on the compressed layout (VALU, wave-rows and matrix-core streaming kernels)."""
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, DeviceAOBatch, BatchedEvaluator
+    dev = torch.device("cuda:0")
+    S, one, two = make_trdms(n, T, 300 + n)
+    two_l = pack_rows(two, True, True)
+    aos = [make_ao_arrays(n, A, 800 + k, ip1_rs_symmetric=True) for k in range(G)]
+    be = BatchedEvaluator(DeviceTRDMs(one, two_l, S, dev, compress="sym8"), A, G, keep_density_matrices=True)
+    E, grad = be.energies_with_grads(DeviceAOBatch.stack([DeviceAO.from_arrays(a, dev) for a in aos]))
+    for k in sorted({0, G // 2, G - 1}):
+        Eo, go, Do, Go = orc.energy_with_grad(bundle(aos[k]), one, two_l, S, True, True)
+        assert abs(E[k] - Eo) < 1e-9, k
+        np.testing.assert_allclose(grad[k], go, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(be.g_pred[k].cpu().numpy(), sym8(np.asarray(Go).reshape(n, n, n, n)), rtol=0,
+                                   atol=1e-10)
+
+
+def test_sym8_pair_sharded_rows():
+    """Row-sharded compressed sets (pair sharding): shards of the pack2 rows compress to the
+    corresponding shards of the compressed rows."""
+    from evcont_amd.evaluator import DeviceTRDMs
+    dev = torch.device("cuda:0")
+    n, T = 8, 5
+    S, one, two = make_trdms(n, T, 77)
+    two_l = pack_rows(two, True, True)
+    full = DeviceTRDMs(one, two_l, S, dev, compress="sym8")
+    P = T * (T + 1) // 2
+    for r0, r1 in ((0, 7), (7, P), (4, 4)):
+        part = DeviceTRDMs(one, two_l, S, dev, row_range=(r0, r1), compress="sym8")
+        assert (part.row_offset, part.rows_local, part.rows_total) == (r0, r1 - r0, P)
+        if r1 > r0:
+            assert torch.equal(part.two[: r1 - r0], full.two[r0:r1])
+
+
+def test_sym8_h10_physical(h10_fci):
+    """configs[1] on physical integrals: H10 / STO-3G / 5 FCI training states, compressed layout vs the CPU
+    path on the stored (pair-packed) t-RDMs, at training points (exact FCI energies) and at a bent geometry."""
+    from evcont_amd.hchain import s_gaussian_mol, hydrogen_chain
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
+    dev = torch.device("cuda:0")
+    h10 = h10_fci
+    S, one, two = h10["overlap"], h10["one_rdm"], h10["two_rdm_pack2"]
+    ev = ContinuationEvaluator(DeviceTRDMs(one, two, S, dev, compress="sym8"), 10)
+    mols = [hydrogen_chain(10, float(d)) for d in h10["spacings"]] + [s_gaussian_mol(h10["R_test"])]
+    for k, m in enumerate(mols):
+        E, g = ev.energy_with_grad(DeviceAO.from_arrays(m, dev))
+        Eo, go = orc.energy_with_grad(bundle(m), one, two, S)
+        assert abs(E - Eo) < 1e-10 and np.abs(g - go).max() < 1e-9
+        if k < len(h10["ens"]):
+            assert abs(E - float(h10["ens"][k])) < 1e-8
+
+
+def test_sym8_h30_full_size_against_pack2():
+    """Headline workload at FULL size (N=30, A=30, T=20): the compressed set built from the resident pack2 rows
+    reproduces the pack2 pipeline (itself pinned to the reference at small sizes) on integrals with the
+    symmetries of real ones; batch of 16 through the matrix-core kernels and single geometries."""
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, ContinuationEvaluator, BatchedEvaluator
+    from evcont_amd.synthetic import make_device_ao, make_device_trdm_rows
+    dev = torch.device("cuda:0")
+    n, A, T, G = 30, 30, 20, 16
+    S, one, rows = make_device_trdm_rows(n, T, 2, 1236, dev)
+    trd = DeviceTRDMs.from_device_rows(one, rows, S, 2)
+    aos = [make_device_ao(n, A, 5000 + k, dev, ip1_rs_symmetric=True) for k in range(G)]
+    ref = ContinuationEvaluator(trd, A)
+    want = {k: ref.energy_with_grad(aos[k]) for k in (0, 5, 15)}
+    del ref
+    trd8 = DeviceTRDMs.from_device_rows(one, rows, S, 2).compress_sym8_()
+    del rows, trd
+    assert trd8.cols == 108345 and trd8.two.shape == (210, 108352)
+    be = BatchedEvaluator(trd8, A, G)
+    be.enqueue(DeviceAOBatch.stack(aos))
+    be.synchronize()
+    E, grad = be.energy[:, 0].cpu().numpy(), be.grad.cpu().numpy()
+    single = ContinuationEvaluator(trd8, A)
+    for k, (Ep, gp) in want.items():
+        assert abs(E[k] - Ep) < 1e-9, (k, E[k], Ep)
+        np.testing.assert_allclose(grad[k], gp, rtol=0, atol=1e-8)
+        Es, gs = single.energy_with_grad(aos[k])
+        assert abs(Es - Ep) < 1e-9
+        np.testing.assert_allclose(gs, gp, rtol=0, atol=1e-8)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# like scan_env.sh but with 32 geometries per step
+# like scan_env.sh but with 32 geometries per step (BATCH, LAYOUT, STREAMS from the environment)
 mkdir -p gpurun_out
 var=$1; shift
 for v in "$@"; do
-env $var=$v timeout -k 10 200 python bench.py --no-cpu-baseline --no-md-regime --batch 32 --streams ${STREAMS:-1} --steps 30 > gpurun_out/scan.json 2>gpurun_out/err.log || { tail -5 gpurun_out/err.log; exit 1; }
+env $var=$v timeout -k 10 200 python bench.py --no-cpu-baseline --no-md-regime --batch ${BATCH:-32} --layout ${LAYOUT:-pack2} --streams ${STREAMS:-1} --steps 30 > gpurun_out/scan.json 2>gpurun_out/err.log || { tail -5 gpurun_out/err.log; exit 1; }
 python - <<PY
 import json
 d=json.load(open("gpurun_out/scan.json"))
