@@ -61,6 +61,8 @@ struct PairTransformArgs {
     int ct, n;
     int tiles_per_wg;   // set by launch_pair_transform: consecutive 8-wide q tiles per workgroup
     int sym8;           // `packed` is the 8-fold compressed vector (EVC_LAYOUT_SYM8), multiplicities folded in
+    int lead_sym;       // in[p][q][..] = in[q][p][..]: only q <= p (whole 8-wide q tiles) is computed and stored
+    int in_lower;       // in[p][q][r][s] = in[p][q][s][r] and only r >= s is valid (output of a lead_sym step)
 };
 constexpr int kPairTransformMaxN = 32;
 int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);
@@ -79,9 +81,14 @@ int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t so
 //   SB[i,j,k,l] = 2 (p(ij,kl) + p(ji,lk))                  (= AO-type symmetrisation, gradients_loewdin.py:238-240,
 //                                                             applied BEFORE the OAO->AO rotation, with which it commutes)
 //   G[i,j,k,l]  = p(ij,kl)                                 (optional: the unpacked 2-RDM, eiu:69-88)
-// sym8: `packed` is the 8-fold compressed vector p8 of a fully symmetric 2-RDM: GsT = SB = 4 p8(ijkl), G = p8(ijkl)
 int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
-                      int64_t sG, int count, int sym8, hipStream_t st);
+                      int64_t sG, int count, hipStream_t st);
+// EVC_LAYOUT_SYM8: `packed` is the 8-fold compressed vector p8 of a fully symmetric 2-RDM:
+//   SB[i,j,k,l] = 4 p8(ijkl) (only for i >= j when lead_half), G[i,j,k,l] = p8(ijkl) (optional)
+int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t sws, double *G, int64_t sG, int count,
+                   int lead_half, hipStream_t st);
+// partial[b][i][a] = sum_{k in slab b} SB[i][k] * K3[k][a]: the Y2 contraction with the row-major operand
+int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);
 // partial[b][i][a] = sum_{k in slab b} GsT[k][i] * K3[k][a]   (k = jkl)
 int y2_slabs(int n);
 int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);
@@ -100,6 +107,7 @@ struct Ip1Args {
     int64_t sip1, sdh, sws;
     int n, natm, nslab, nchunk;
     int presym;            // Gao already carries the 4-fold AO symmetrisation (packed fast path)
+    int fold_cd;           // (with presym) Gao[m,b,c,d] is symmetric in c <-> d and only valid for d <= c
 };
 int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st);
 

@@ -237,7 +237,11 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
             pa.n = n;
             pa.out = w.B1 + o;
             pa.sout = sw;
+            // compressed layout: the AO integrals are 8-fold symmetric by contract, the first step only
+            // produces the q <= p half of its output and the second one reads the lower triangles
+            pa.lead_sym = is_sym8(t->layout) ? 1 : 0;
             if ((rc = launch_pair_transform(pa, cc, st))) return rc;
+            pa.in_lower = pa.lead_sym;   // ... and again only needs the q <= p half of ITS leading pair
             pa.in = w.B1 + o;
             pa.sin = sw;
             pa.k3 = w.K3 + o;
@@ -406,6 +410,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
         ia.ip1 = g.eri_ip1 + (int64_t)c0 * g.sip1;
         ia.Gao = gao_ + o;
         ia.presym = packed ? 1 : 0;
+        ia.fold_cd = (packed && sym8 && use_pair_transform(n)) ? 1 : 0;
         ia.t2part = w.t2part + o;
         ia.dh = g.dhcore ? g.dhcore + (int64_t)c0 * g.sdh : nullptr;
         ia.Pao = w.Pao + o;
@@ -430,10 +435,17 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
             for (int c0 = 0; c0 < cnt; c0 += chunk) {
                 const int cc = cnt - c0 < chunk ? cnt - c0 : chunk;
                 const int64_t o = (int64_t)c0 * sw;
-                if ((rc = launch_unpack_sym(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, w.B1 + o, sw,
-                                            G ? G + (int64_t)c0 * sG : nullptr, sG, cc, sym8, st)))
-                    return rc;
-                if ((rc = launch_y2(w.B2 + o, w.K3 + o, n, w.y2part + o, sw, cc, st))) return rc;
+                if (sym8) {
+                    if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, w.B1 + o, sw,
+                                             G ? G + (int64_t)c0 * sG : nullptr, sG, cc, 0, st)))
+                        return rc;
+                    if ((rc = launch_y2_sb(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, st))) return rc;
+                } else {
+                    if ((rc = launch_unpack_sym(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, w.B1 + o, sw,
+                                                G ? G + (int64_t)c0 * sG : nullptr, sG, cc, st)))
+                        return rc;
+                    if ((rc = launch_y2(w.B2 + o, w.K3 + o, n, w.y2part + o, sw, cc, st))) return rc;
+                }
                 PairTransformArgs pa;
                 memset(&pa, 0, sizeof(pa));
                 pa.C = w.X + o;
@@ -444,7 +456,9 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.sin = sw;
                 pa.out = w.B2 + o;
                 pa.sout = sw;
+                pa.lead_sym = sym8;   // SB is fully symmetric
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
+                pa.in_lower = sym8;   // the result is only valid for d <= c of G^AO[m,b,c,d] (fold_cd below)
                 pa.in = w.B2 + o;
                 pa.out = w.B1 + o;
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
@@ -452,8 +466,13 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
             }
             ip1_done = true;
         } else {
-            if ((rc = launch_unpack_sym(packed, spacked, n, w.B2, w.B1, sw, G, sG, cnt, sym8, st))) return rc;
-            if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, sw, cnt, st))) return rc;
+            if (sym8) {
+                if ((rc = launch_unpack8(packed, spacked, n, w.B1, sw, G, sG, cnt, 0, st))) return rc;
+                if ((rc = launch_y2_sb(w.B1, w.K3, n, w.y2part, sw, cnt, st))) return rc;
+            } else {
+                if ((rc = launch_unpack_sym(packed, spacked, n, w.B2, w.B1, sw, G, sG, cnt, st))) return rc;
+                if ((rc = launch_y2(w.B2, w.K3, n, w.y2part, sw, cnt, st))) return rc;
+            }
             if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;
             if ((rc = launch_quarter_transform(w.B2, sw, w.X, sw, 1, n, w.B1, sw, cnt, st))) return rc;
             if ((rc = launch_quarter_transform(w.B1, sw, w.X, sw, 1, n, w.B2, sw, cnt, st))) return rc;

@@ -153,8 +153,14 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     const int ntq = (n + QT - 1) / QT;
     const int tpw = a.tiles_per_wg;
     const int ntg = (ntq + tpw - 1) / tpw;
-    const int p = blockIdx.x / ntg;
-    const int tq_begin = (blockIdx.x - p * ntg) * tpw, tq_end = min(ntq, tq_begin + tpw);
+    // lead_sym: the workgroups with the most q tiles (largest p) are dispatched first
+    const int p = a.lead_sym ? n - 1 - (int)(blockIdx.x / ntg) : (int)(blockIdx.x / ntg);
+    const int tq_begin = (blockIdx.x % ntg) * tpw;
+    // lead_sym: in[p][q] = in[q][p] and the consumer reads out[..][p][q] only for p >= q (in_lower of the next
+    // step): q tiles entirely above the diagonal are skipped
+    const int tq_end = a.lead_sym ? min(min(ntq, tq_begin + tpw), p / QT + 1) : min(ntq, tq_begin + tpw);
+    if (tq_begin >= tq_end) return;
+    const bool lower = a.in_lower != 0;  // the n x n matrices are symmetric and valid for r >= s only
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
 
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 const int r = rt * 16 + l15, s = 4 * kk + l4;
-                mf[rt][kk] = (ok && r < n && s < n) ? Mb[r * n + s] : 0.0;
+                mf[rt][kk] = (ok && r < n && s < n) ? Mb[(lower && s > r) ? s * n + r : r * n + s] : 0.0;
             }
     }
     for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += 256) {
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
                     const int r = rt * 16 + l15, s = 4 * kk + l4;
-                    mn[rt][kk] = (ok && r < n && s < n) ? Mb[r * n + s] : 0.0;
+                    mn[rt][kk] = (ok && r < n && s < n) ? Mb[(lower && s > r) ? s * n + r : r * n + s] : 0.0;
                 }
         }
         // H = M X
@@ -217,8 +223,11 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
                 for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
-        if (a.k3) {
+        if (a.k3 && !(a.lead_sym && q > p)) {
+            // lead_sym: K3[s'][p][q][:] = K3[s'][q][p][:]; the mirror image is stored from here (the matrices
+            // q > p of a diagonal tile are computed but store nothing that another matrix also stores)
             double *K3 = a.k3 + g * a.sk3;
+            const bool mirror = a.lead_sym && q < p;
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
@@ -226,7 +235,10 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int r = rt * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
-                        if (r < n && s2 < n) K3[((int64_t)s2 * n + p) * n2 + (int64_t)q * n + r] = h[rt][st][reg];
+                        if (r < n && s2 < n) {
+                            K3[((int64_t)s2 * n + p) * n2 + (int64_t)q * n + r] = h[rt][st][reg];
+                            if (mirror) K3[((int64_t)s2 * n + q) * n2 + (int64_t)p * n + r] = h[rt][st][reg];
+                        }
                     }
         }
         // N = X^T H : B operand of k-step kk is register kk%4 of H's row tile kk/4
@@ -446,7 +458,7 @@ int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t so
 __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restrict__ p, int64_t sp, int n,
                                                          double *__restrict__ GsT, double *__restrict__ SB,
                                                          int64_t sws, double *__restrict__ Gout, int64_t sG,
-                                                         int count, int sym8) {
+                                                         int count) {
     extern __shared__ __align__(16) double tile[];  // [l][i], row length n+1
     const int64_t n2 = (int64_t)n * n, n3 = n2 * n;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; the blocks an XCD receives work
@@ -475,14 +487,6 @@ __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restric
     for (int idx = threadIdx.x; idx < n * n; idx += 256) {
         const int i = idx / n, l = idx - i * n;
         const int64_t o = i * n3 + j * n2 + k * n + l;
-        if (sym8) {
-            // fully symmetric 2-RDM: every image of (i,j,k,l) is the same element of the compressed vector
-            const double p1 = P(i >= j ? tri_index(i, j) : tri_index(j, i), k >= l ? tri_index(k, l) : tri_index(l, k));
-            SB[o] = 4.0 * p1;
-            if (Gout) Gout[o] = p1;
-            tile[l * (n + 1) + i] = 4.0 * p1;
-            continue;
-        }
         const int64_t R = (int64_t)i * n + j, Rt = (int64_t)j * n + i, Cc = (int64_t)k * n + l, Ct = (int64_t)l * n + k;
         const double p1 = P(R, Cc), p2 = P(Rt, Cc), p3 = P(Rt, Ct);
         SB[o] = 2.0 * (p1 + p3);
@@ -498,11 +502,57 @@ __global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restric
 }
 
 int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
-                      int64_t sG, int count, int sym8, hipStream_t st) {
+                      int64_t sG, int count, hipStream_t st) {
     const size_t lds = sizeof(double) * (size_t)n * (n + 1);
     hipLaunchKernelGGL(unpack_sym_kernel, dim3((unsigned)(n * n * count)), dim3(256), lds, st, packed, sp, n, GsT, SB,
-                       sws, G, sG, count, sym8);
+                       sws, G, sG, count);
     EVC_LAUNCH_CHECK("unpack_sym");
+    return 0;
+}
+
+// 8-fold compressed vector p8 of a fully symmetric 2-RDM (EVC_LAYOUT_SYM8) -> SB[i][j][k][l] = 4 p8(ijkl), the
+// operand of both the Y2 contraction and the OAO->AO rotation (every image of (i,j,k,l) is the same element, so
+// the two symmetrisations of the general path coincide), and optionally G = p8(ijkl).  One workgroup per (i,j)
+// writes a contiguous n*n block; same XCD-aware geometry order as above (0.87 MB per geometry at N = 30).
+// lead_half: SB is only needed for i >= j (its consumers use the i <-> j symmetry).
+__global__ __launch_bounds__(256) void unpack8_kernel(const double *__restrict__ p, int64_t sp, int n,
+                                                      double *__restrict__ SB, int64_t sws,
+                                                      double *__restrict__ Gout, int64_t sG, int count,
+                                                      int lead_half) {
+    const int64_t n2 = (int64_t)n * n;
+    const int nx = count & ~7;
+    const int64_t nxblocks = (int64_t)nx * n * n;
+    int geom, ij;
+    if ((int64_t)blockIdx.x < nxblocks) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        geom = (slot / (n * n)) * 8 + xcd;
+        ij = slot % (n * n);
+    } else {
+        const int64_t b = (int64_t)blockIdx.x - nxblocks;
+        geom = nx + (int)(b / (n * n));
+        ij = (int)(b % (n * n));
+    }
+    const int i = ij / n, j = ij - i * n;
+    const bool want_sb = !(lead_half && i < j);
+    if (!want_sb && !Gout) return;
+    p += (int64_t)geom * sp;
+    double *sb = SB + (int64_t)geom * sws + (int64_t)ij * n2;
+    double *go = Gout ? Gout + (int64_t)geom * sG + (int64_t)ij * n2 : nullptr;
+    const int64_t u = i >= j ? tri_index(i, j) : tri_index(j, i);
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int k = idx / n, l = idx - k * n;
+        const int64_t v = k >= l ? tri_index(k, l) : tri_index(l, k);
+        const double val = u >= v ? p[tri_index(u, v)] : p[tri_index(v, u)];
+        if (want_sb) sb[idx] = 4.0 * val;
+        if (go) go[idx] = val;
+    }
+}
+
+int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t sws, double *G, int64_t sG, int count,
+                   int lead_half, hipStream_t st) {
+    hipLaunchKernelGGL(unpack8_kernel, dim3((unsigned)(n * n * count)), dim3(256), 0, st, packed, sp, n, SB, sws, G, sG,
+                       count, lead_half);
+    EVC_LAUNCH_CHECK("unpack8");
     return 0;
 }
 
@@ -561,6 +611,91 @@ __global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT,
     }
 }
 
+// Same contraction with the first operand given as SB[i][k] (row i = n^3 contiguous doubles), i.e.
+// partial[slab][i][a] = sum_{k in slab} SB[i][k] * K3[k][a]: for a fully symmetric 2-RDM the transposed operand GsT
+// of the general path is SB itself read row-wise.  A lane fetches two consecutive k of "its" row i with one 16-byte
+// load and feeds them to two MFMAs (the K slot of a lane can be any k as long as both operands agree).
+template <int NT>
+__global__ __launch_bounds__(256) void y2_sb_kernel(const double *__restrict__ SB, const double *__restrict__ K3,
+                                                    int n, int64_t ktot, double *__restrict__ partial, int64_t sws) {
+    __shared__ double red[4][NT * 16][NT * 16 + 1];
+    SB += (int64_t)blockIdx.y * sws;
+    K3 += (int64_t)blockIdx.y * sws;
+    partial += (int64_t)blockIdx.y * sws;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t ksteps = (ktot + 7) / 8;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int64_t per = (ksteps + nw - 1) / nw;
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t ks0 = w * per, ks1 = min(ksteps, ks0 + per);
+    const bool even = (ktot & 1) == 0;  // rows of SB start 16-byte aligned
+    const double *__restrict__ arow[NT];
+    bool cok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = t * 16 + l15;
+        cok[t] = c < n;
+        arow[t] = SB + (int64_t)(cok[t] ? c : 0) * ktot;
+    }
+    d4 acc[NT][NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int64_t ks = ks0; ks < ks1; ++ks) {
+        const int64_t k = ks * 8 + 2 * l4;
+        const bool k0ok = k < ktot, k1ok = k + 1 < ktot;
+        double2 af[NT];
+        double b0[NT], b1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (even)
+                af[t] = (cok[t] && k0ok) ? *reinterpret_cast<const double2 *>(arow[t] + k) : make_double2(0.0, 0.0);
+            else
+                af[t] = make_double2((cok[t] && k0ok) ? arow[t][k] : 0.0, (cok[t] && k1ok) ? arow[t][k + 1] : 0.0);
+            const int c = t * 16 + l15;
+            b0[t] = (cok[t] && k0ok) ? K3[k * n + c] : 0.0;
+            b1[t] = (cok[t] && k1ok) ? K3[(k + 1) * n + c] : 0.0;
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(af[ti].x, b0[ta], acc[ti][ta]);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(af[ti].y, b1[ta], acc[ti][ta]);
+    }
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
+    __syncthreads();
+    double *dst = partial + (int64_t)blockIdx.x * n * n;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, a = idx % n;
+        dst[idx] = (red[0][i][a] + red[1][i][a]) + (red[2][i][a] + red[3][i][a]);
+    }
+}
+
+int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
+    const int64_t ktot = (int64_t)n * n * n;
+    const int nt = (n + 15) / 16;
+    const dim3 grid(kY2Slabs, (unsigned)count);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(y2_sb_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
+        case 2: hipLaunchKernelGGL(y2_sb_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
+        case 3: hipLaunchKernelGGL(y2_sb_kernel<3>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
+        case 4: hipLaunchKernelGGL(y2_sb_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
+        default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
+    }
+    EVC_LAUNCH_CHECK("y2_sb");
+    return 0;
+}
+
 int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
     const int64_t ktot = (int64_t)n * n * n;
     const int nt = (n + 15) / 16;
@@ -600,7 +735,30 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
         const int m = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         const int64_t e0 = (int64_t)ch * 256 * kIp1PerThread;
-        if (a.presym && (n3 & 1) == 0) {
+        if (a.presym && a.fold_cd && (n3 & 1) == 0) {
+            // symmetrised operand that is only valid for d <= c (and symmetric in c <-> d, like ip1 itself): the
+            // dot runs over the lower triangles with weight 2 off the diagonal; n is even here, so a 16-byte
+            // pair never straddles two c rows
+#pragma unroll
+            for (int u = 0; u < kIp1PerThread / 2; ++u) {
+                const int64_t e = e0 + ((int64_t)u * 256 + threadIdx.x) * 2;
+                if (e < n3) {
+                    const int d = (int)(e % n), c = (int)((e / n) % n);
+                    if (d <= c) {
+                        const int64_t off = m * n3 + e;
+                        const double2 gr = *reinterpret_cast<const double2 *>(G + off);
+                        const double2 p0 = *reinterpret_cast<const double2 *>(ip1 + off);
+                        const double2 p1 = *reinterpret_cast<const double2 *>(ip1 + n4 + off);
+                        const double2 p2 = *reinterpret_cast<const double2 *>(ip1 + 2 * n4 + off);
+                        const double gx = d < c ? 2.0 * gr.x : gr.x;
+                        const double gy = d + 1 < c ? 2.0 * gr.y : (d + 1 == c ? gr.y : 0.0);
+                        a0 = fma(p0.y, gy, fma(p0.x, gx, a0));
+                        a1 = fma(p1.y, gy, fma(p1.x, gx, a1));
+                        a2 = fma(p2.y, gy, fma(p2.x, gx, a2));
+                    }
+                }
+            }
+        } else if (a.presym && (n3 & 1) == 0) {
             // symmetrised operand: a plain streaming dot, 16-byte loads
 #pragma unroll
             for (int u = 0; u < kIp1PerThread / 2; ++u) {
@@ -624,9 +782,11 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
                 const int d = (int)(e % n);
                 const int c = (int)((e / n) % n);
                 const int b = (int)(e / n2);
-                const double gs = a.presym ? G[m * n3 + e]
-                                           : G[m * n3 + e] + G[b * n3 + m * n2 + d * n + c] +
-                                                 G[c * n3 + d * n2 + m * n + b] + G[d * n3 + c * n2 + b * n + m];
+                if (a.fold_cd && d > c) continue;
+                double gs = a.presym ? G[m * n3 + e]
+                                     : G[m * n3 + e] + G[b * n3 + m * n2 + d * n + c] +
+                                           G[c * n3 + d * n2 + m * n + b] + G[d * n3 + c * n2 + b * n + m];
+                if (a.fold_cd && d < c) gs *= 2.0;
                 const int64_t off = m * n3 + e;
                 a0 = fma(ip1[off], gs, a0);
                 a1 = fma(ip1[n4 + off], gs, a1);

@@ -84,7 +84,8 @@ def test_sym8_matches_reference_layouts(n, T, A, lname):
 
 def test_sym8_needs_the_integral_symmetry():
     """With a general (not r<->s symmetric) eri_ip1 the compressed layout must NOT be expected to agree:
-    documents the precondition (energies still agree, forces differ)."""
+    documents the precondition (energies still agree, forces differ: the pipeline reads eri_ip1 and the
+    intermediates of the two rotations in their lower triangles only)."""
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
     dev = torch.device("cuda:0")
     n, T, A = 6, 3, 3
@@ -95,9 +96,12 @@ def test_sym8_needs_the_integral_symmetry():
     Eo, go = orc.energy_with_grad(bundle(ao), one, two, S)
     assert abs(E - Eo) < 1e-10
     assert np.abs(g - go).max() > 1e-4
-    # ... and it is exactly the reference formula applied to the symmetrised t-RDMs
-    Es, gs = orc.energy_with_grad(bundle(ao), one, sym8(two), S)
-    np.testing.assert_allclose(g, gs, rtol=0, atol=1e-9)
+    # symmetrising eri_ip1 in its last two indices restores the agreement
+    ao.eri_ip1 = np.ascontiguousarray(0.5 * (ao.eri_ip1 + ao.eri_ip1.transpose(0, 1, 2, 4, 3)))
+    E, g = ev.energy_with_grad(DeviceAO.from_arrays(ao, dev))
+    Eo, go = orc.energy_with_grad(bundle(ao), one, two, S)
+    assert abs(E - Eo) < 1e-10
+    np.testing.assert_allclose(g, go, rtol=0, atol=1e-9)
 
 
 @pytest.mark.parametrize("n,T,A,G", [(10, 5, 10, 3), (18, 6, 3, 9), (21, 5, 3, 17), (12, 4, 4, 33)])
