@@ -382,6 +382,93 @@ __global__ __launch_bounds__(256, MINW) void gemv_cols_mfma_kernel(GemvColsLaunc
     }
 }
 
+// Row-split variant for matrices with few columns (the 8-fold compressed layout: 108 345 columns at N = 30, 3.7x
+// fewer waves than the kernel above gets from the packed layout): a block owns ONE 32-column tile and its four
+// waves take the K steps in turn, so a wave's dependent chain is a quarter as long; the four partial tiles are
+// summed in fixed order through LDS.  The weights are read straight from memory (a wave needs only those of its
+// own K steps: 4 rows x 16 geometries per MFMA operand, L2 resident), so there is no weight tile to fill and no
+// barrier inside the stream.
+template <int KSN, int MINW, int GS>
+__global__ __launch_bounds__(256, MINW) void gemv_cols_mfma_rs_kernel(GemvColsLaunch L, int g0, int G) {
+    __shared__ double red[4 * GS * 2 * 4 * 64];  // [wave][gs][eo][reg][lane]
+    int bid = gridDim.x - 1 - blockIdx.x;
+    const int which = bid >= L.nblk0 ? 1 : 0;
+    if (which) bid -= L.nblk0;
+    const ColProblem &P = L.p[which];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t rows = P.rows, cols = P.cols, ld = P.ld;
+    const int64_t c0 = (int64_t)bid * 32;
+    // lanes whose geometry slot is >= G read geometry g0's weights; their output rows are discarded
+    const double *__restrict__ wg[GS];
+#pragma unroll
+    for (int gs = 0; gs < GS; ++gs) {
+        const int slot = 16 * gs + l15;
+        wg[gs] = P.w + (int64_t)(g0 + (slot < G ? slot : 0)) * P.wstride;
+    }
+    d4 ae[GS], ao[GS];
+#pragma unroll
+    for (int gs = 0; gs < GS; ++gs) {
+        ae[gs] = (d4){0.0, 0.0, 0.0, 0.0};
+        ao[gs] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    const int64_t cl = c0 + 2 * l15;
+    const bool inside = c0 + 32 <= cols;
+    for (int64_t rb = (int64_t)wave * 4 * KSN; rb < rows; rb += 16 * KSN) {
+        double2 x[KSN];
+        double wf[KSN][GS];
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+            const int64_t r = rb + 4 * ks + l4;
+            const bool live = r < rows;   // rows beyond the matrix: zero weight, address clamped to a valid row
+            const double *row = P.A + (live ? r : rows - 1) * ld;
+#pragma unroll
+            for (int gs = 0; gs < GS; ++gs) wf[ks][gs] = live ? wg[gs][r] : 0.0;
+            if (inside) x[ks] = ld2(row + cl);
+            else x[ks] = ld2_guard(row, cl, cols);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+            for (int gs = 0; gs < GS; ++gs) {
+                ae[gs] = mfma_f64(wf[ks][gs], x[ks].x, ae[gs]);
+                ao[gs] = mfma_f64(wf[ks][gs], x[ks].y, ao[gs]);
+            }
+    }
+#pragma unroll
+    for (int gs = 0; gs < GS; ++gs)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[(((wave * GS + gs) * 2 + 0) * 4 + r) * 64 + lane] = ae[gs][r];
+            red[(((wave * GS + gs) * 2 + 1) * 4 + r) * 64 + lane] = ao[gs][r];
+        }
+    __syncthreads();
+    for (int idx = tid; idx < GS * 4 * 64; idx += 256) {
+        const int ln = idx & 63, r = (idx >> 6) & 3, gs = idx >> 8;
+        const int g = 16 * gs + (ln >> 4) + 4 * r;
+        const int64_t c = c0 + 2 * (ln & 15);
+        if (g < G && c < cols) {
+            double v[2];
+#pragma unroll
+            for (int eo = 0; eo < 2; ++eo) {
+                const int o = ((gs * 2 + eo) * 4 + r) * 64 + ln;
+                constexpr int WS = GS * 2 * 4 * 64;  // one wave's slice
+                v[eo] = (red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o]);
+            }
+            double *o = P.out + (int64_t)(g0 + g) * P.ostride + c;
+            if (c + 1 < cols) *reinterpret_cast<double2 *>(o) = make_double2(v[0], v[1]);
+            else *o = v[0];
+        }
+    }
+}
+
+template <int KSN, int MINW, int GS>
+static void cols_mfma_rs_launch(GemvColsLaunch L, int g0, int G, hipStream_t st) {
+    L.nblk0 = (int)ceil_div(L.p[0].cols, 32);
+    const int total = L.nblk0 + (int)ceil_div(L.p[1].cols, 32);
+    hipLaunchKernelGGL((gemv_cols_mfma_rs_kernel<KSN, MINW, GS>), dim3(total), dim3(256), 0, st, L, g0, G);
+}
+
 template <int CT, int KSN, int MINW, int GS>
 static void cols_mfma_launch(GemvColsLaunch L, int g0, int G, hipStream_t st) {
     const int64_t per = 4 * 32 * CT;
@@ -410,6 +497,27 @@ int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
     static const int sh2 = getenv("EVC_COLS_SHAPE2") ? atoi(getenv("EVC_COLS_SHAPE2")) : 224;
 #define EVC_COLS_CASE(CT_, KSN_, MINW_, GS_) \
     case 100 * CT_ + 10 * KSN_ + MINW_: cols_mfma_launch<CT_, KSN_, MINW_, GS_>(L, g0, G, st); break;
+    // shape code 1000 + 10*KSN + MINW = the row-split kernel; it is the default below kRsMaxCols columns
+#define EVC_COLS_RS_CASE(KSN_, MINW_, GS_) \
+    case 1000 + 10 * KSN_ + MINW_: cols_mfma_rs_launch<KSN_, MINW_, GS_>(L, g0, G, st); break;
+    static const int rs1 = getenv("EVC_COLS_RS_SHAPE") ? atoi(getenv("EVC_COLS_RS_SHAPE")) : 1026;
+    static const int rs2 = getenv("EVC_COLS_RS_SHAPE2") ? atoi(getenv("EVC_COLS_RS_SHAPE2")) : 1024;
+    static const int64_t rs_max_cols = getenv("EVC_COLS_RS_MAX") ? atoll(getenv("EVC_COLS_RS_MAX")) : 200000;
+    if (L.p[0].cols <= rs_max_cols) {
+        if (G > 16) {
+            switch (rs2) {
+                EVC_COLS_RS_CASE(2, 4, 2) EVC_COLS_RS_CASE(1, 4, 2) EVC_COLS_RS_CASE(2, 3, 2) EVC_COLS_RS_CASE(4, 3, 2)
+                default: set_error("gemv_cols_mfma: unknown EVC_COLS_RS_SHAPE2=%d", rs2); return -1;
+            }
+        } else {
+            switch (rs1) {
+                EVC_COLS_RS_CASE(2, 6, 1) EVC_COLS_RS_CASE(1, 6, 1) EVC_COLS_RS_CASE(4, 6, 1) EVC_COLS_RS_CASE(2, 4, 1)
+                default: set_error("gemv_cols_mfma: unknown EVC_COLS_RS_SHAPE=%d", rs1); return -1;
+            }
+        }
+        EVC_LAUNCH_CHECK("gemv_cols_mfma_rs");
+        return 0;
+    }
     if (G > 16) {
         switch (sh2) {
             EVC_COLS_CASE(2, 2, 4, 2) EVC_COLS_CASE(2, 1, 4, 2) EVC_COLS_CASE(2, 2, 3, 2) EVC_COLS_CASE(2, 3, 3, 2)
@@ -424,6 +532,7 @@ int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
         }
     }
 #undef EVC_COLS_CASE
+#undef EVC_COLS_RS_CASE
     EVC_LAUNCH_CHECK("gemv_cols_mfma");
     return 0;
 }

@@ -239,9 +239,9 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
             pa.sout = sw;
             // compressed layout: the AO integrals are 8-fold symmetric by contract, the first step only
             // produces the q <= p half of its output and the second one reads the lower triangles
-            pa.lead_sym = is_sym8(t->layout) ? 1 : 0;
+            pa.lead_sym = pa.in_lower = is_sym8(t->layout) ? 1 : 0;   // (in_lower: eri[p,q,r,s] = eri[p,q,s,r])
             if ((rc = launch_pair_transform(pa, cc, st))) return rc;
-            pa.in_lower = pa.lead_sym;   // ... and again only needs the q <= p half of ITS leading pair
+            // ... and the second step again only needs the q <= p half of ITS leading pair
             pa.in = w.B1 + o;
             pa.sin = sw;
             pa.k3 = w.K3 + o;
@@ -456,9 +456,9 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.sin = sw;
                 pa.out = w.B2 + o;
                 pa.sout = sw;
-                pa.lead_sym = sym8;   // SB is fully symmetric
+                pa.lead_sym = pa.in_lower = sym8;   // SB is fully symmetric
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
-                pa.in_lower = sym8;   // the result is only valid for d <= c of G^AO[m,b,c,d] (fold_cd below)
+                // the result is only valid for d <= c of G^AO[m,b,c,d] (fold_cd below)
                 pa.in = w.B2 + o;
                 pa.out = w.B1 + o;
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;

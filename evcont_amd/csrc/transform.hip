@@ -144,45 +144,59 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     double *Xs = sm;                  // NPAD * LDX
     double *stage = Xs + NPAD * LDX;  // n*n*QP
     const int n = a.n;
-    const int64_t n2 = (int64_t)n * n, n3 = n2 * n;
+    const int64_t n2 = (int64_t)n * n;
     const int64_t g = blockIdx.y;
     const double *__restrict__ in = a.in + g * a.sin;
     const double *__restrict__ C = a.C + g * a.sC;
-    // a workgroup owns `tpw` consecutive q tiles of one p: the stores of a tile drain while the next
-    // one is loaded and multiplied, and X is staged once
+    // The leading pairs (p,q) are handled in tiles of 8 (one 64-byte run of the output per (r',s')); a workgroup
+    // owns `tpw` consecutive tiles: the stores of a tile drain while the next one is loaded and multiplied, and
+    // X is staged once.
+    //   plain:    tile t = (p, 8-wide q tile), pairs with q >= n are idle;
+    //   lead_sym: in[p][q] = in[q][p] and the consumer reads out[..][p][q] only for q <= p (in_lower of the next
+    //             step): the tiles run over the n(n+1)/2 pairs q <= p in row-major triangle order.
+    const bool sym = a.lead_sym != 0;
     const int ntq = (n + QT - 1) / QT;
-    const int tpw = a.tiles_per_wg;
-    const int ntg = (ntq + tpw - 1) / tpw;
-    // lead_sym: the workgroups with the most q tiles (largest p) are dispatched first
-    const int p = a.lead_sym ? n - 1 - (int)(blockIdx.x / ntg) : (int)(blockIdx.x / ntg);
-    const int tq_begin = (blockIdx.x % ntg) * tpw;
-    // lead_sym: in[p][q] = in[q][p] and the consumer reads out[..][p][q] only for p >= q (in_lower of the next
-    // step): q tiles entirely above the diagonal are skipped
-    const int tq_end = a.lead_sym ? min(min(ntq, tq_begin + tpw), p / QT + 1) : min(ntq, tq_begin + tpw);
-    if (tq_begin >= tq_end) return;
+    const int npairs = n * (n + 1) / 2;
+    const int ntiles = sym ? (npairs + QT - 1) / QT : n * ntq;
+    const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(ntiles, t_begin + a.tiles_per_wg);
+    if (t_begin >= t_end) return;
     const bool lower = a.in_lower != 0;  // the n x n matrices are symmetric and valid for r >= s only
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-
-    // first matrix of this wave: operand loads issued before the LDS fill of X
-    double mf[NT][KS];
-    {
-        const int q = tq_begin * QT + wave;
-        const bool ok = q < n;
-        const double *Mb = in + ((int64_t)p * n + q) * n2;
+    // pair `ql` of tile t -> (p, q); false if the slot is idle
+    auto pair_of = [&](int t, int ql, int &p, int &q) -> bool {
+        if (sym) {
+            const int e = t * QT + ql;
+            if (e >= npairs) return false;
+            p = (int)tri_row(e);
+            q = e - p * (p + 1) / 2;
+            return true;
+        }
+        p = t / ntq;
+        q = (t - p * ntq) * QT + ql;
+        return q < n;
+    };
+    auto load_matrix = [&](double (&m)[NT][KS], bool ok, int p, int q) {
+        const double *Mb = in + ((int64_t)(ok ? p : 0) * n + (ok ? q : 0)) * n2;
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 const int r = rt * 16 + l15, s = 4 * kk + l4;
-                mf[rt][kk] = (ok && r < n && s < n) ? Mb[(lower && s > r) ? s * n + r : r * n + s] : 0.0;
+                m[rt][kk] = (ok && r < n && s < n) ? Mb[(lower && s > r) ? s * n + r : r * n + s] : 0.0;
             }
-    }
+    };
+
+    // first matrix of this wave: operand loads issued before the LDS fill of X
+    double mf[NT][KS];
+    int p = 0, q = 0;
+    bool have = pair_of(t_begin, wave, p, q);
+    load_matrix(mf, have, p, q);
     for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += 256) {
-        const int d = idx / NPAD, q = idx % NPAD;
+        const int d = idx / NPAD, c = idx % NPAD;
         double v = 0.0;
-        if (d < n && q < n) v = a.ct ? C[q * n + d] : C[d * n + q];
-        Xs[d * LDX + q] = v;
+        if (d < n && c < n) v = a.ct ? C[c * n + d] : C[d * n + c];
+        Xs[d * LDX + c] = v;
     }
     lds_barrier();
     double xf[KS][NT];
@@ -191,126 +205,119 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) xf[kk][t] = Xs[(4 * kk + l4) * LDX + t * 16 + l15];
 
-    for (int tq = tq_begin; tq < tq_end; ++tq) {
-    const int q0 = tq * QT;
-    const int nq = min(QT, n - q0);
-    for (int ql = wave; ql < nq; ql += 4) {
-        const int q = q0 + ql;
-        // prefetch the wave's next matrix: q + 4 of this tile, else its first one of the next tile
-        double mn[NT][KS];
-        {
-            const int qn = (ql + 4 < nq) ? q + 4 : q0 + QT + wave;
-            const bool ok = (ql + 4 < nq) || (tq + 1 < tq_end && qn < n);
-            const double *Mb = in + ((int64_t)p * n + qn) * n2;
+    for (int t = t_begin; t < t_end; ++t) {
+        for (int ql = wave; ql < QT; ql += 4) {
+            // prefetch the wave's next matrix: slot ql + 4 of this tile, else its first slot of the next tile
+            double mn[NT][KS];
+            int pn = 0, qn = 0;
+            const bool have_next = (ql + 4 < QT) ? pair_of(t, ql + 4, pn, qn) : (t + 1 < t_end && pair_of(t + 1, wave, pn, qn));
+            load_matrix(mn, have_next, pn, qn);
+            if (have) {  // wave-uniform
+                // H = M X
+                // (a dependent f64 MFMA costs ~3x the issue interval: the NT*NT tile chains are interleaved)
+                d4 h[NT][NT];
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
+                for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) {
-                    const int r = rt * 16 + l15, s = 4 * kk + l4;
-                    mn[rt][kk] = (ok && r < n && s < n) ? Mb[(lower && s > r) ? s * n + r : r * n + s] : 0.0;
+                    for (int st = 0; st < NT; ++st) h[rt][st] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                        for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
+                if (a.k3) {
+                    // lead_sym: K3[s'][p][q][:] = K3[s'][q][p][:]; the mirror image is stored from here
+                    double *K3 = a.k3 + g * a.sk3;
+                    const bool mirror = sym && q < p;
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                        for (int st = 0; st < NT; ++st)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                const int r = rt * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
+                                if (r < n && s2 < n) {
+                                    K3[((int64_t)s2 * n + p) * n2 + (int64_t)q * n + r] = h[rt][st][reg];
+                                    if (mirror) K3[((int64_t)s2 * n + q) * n2 + (int64_t)p * n + r] = h[rt][st][reg];
+                                }
+                            }
                 }
-        }
-        // H = M X
-        // (a dependent f64 MFMA costs ~3x the issue interval: the NT*NT tile chains are interleaved)
-        d4 h[NT][NT];
+                // N = X^T H : B operand of k-step kk is register kk%4 of H's row tile kk/4
+                d4 nn[NT][NT];
 #pragma unroll
-        for (int rt = 0; rt < NT; ++rt)
+                for (int it = 0; it < NT; ++it)
 #pragma unroll
-            for (int st = 0; st < NT; ++st) h[rt][st] = (d4){0.0, 0.0, 0.0, 0.0};
+                    for (int st = 0; st < NT; ++st) nn[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
+                for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
+                    for (int it = 0; it < NT; ++it)
 #pragma unroll
-                for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
-        if (a.k3 && !(a.lead_sym && q > p)) {
-            // lead_sym: K3[s'][p][q][:] = K3[s'][q][p][:]; the mirror image is stored from here (the matrices
-            // q > p of a diagonal tile are computed but store nothing that another matrix also stores)
-            double *K3 = a.k3 + g * a.sk3;
-            const bool mirror = a.lead_sym && q < p;
+                        for (int st = 0; st < NT; ++st)
+                            nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
+                for (int it = 0; it < NT; ++it)
 #pragma unroll
-                for (int st = 0; st < NT; ++st)
+                    for (int st = 0; st < NT; ++st)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int r = rt * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
-                        if (r < n && s2 < n) {
-                            K3[((int64_t)s2 * n + p) * n2 + (int64_t)q * n + r] = h[rt][st][reg];
-                            if (mirror) K3[((int64_t)s2 * n + q) * n2 + (int64_t)p * n + r] = h[rt][st][reg];
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
+                            if (r2 < n && s2 < n) stage[(r2 * n + s2) * QP + ql] = nn[it][st][reg];
                         }
-                    }
+            }
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = mn[rt][kk];
+            have = have_next;
+            p = pn;
+            q = qn;
         }
-        // N = X^T H : B operand of k-step kk is register kk%4 of H's row tile kk/4
-        d4 nn[NT][NT];
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-#pragma unroll
-            for (int st = 0; st < NT; ++st) nn[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int it = 0; it < NT; ++it)
-#pragma unroll
-                for (int st = 0; st < NT; ++st)
-                    nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-#pragma unroll
-            for (int st = 0; st < NT; ++st)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
-                    if (r2 < n && s2 < n) stage[(r2 * n + s2) * QP + ql] = nn[it][st][reg];
+        lds_barrier();
+        // write-out: 8 lanes cover the pair run of one (r',s')
+        const int wl = threadIdx.x & 7;
+        int wp = 0, wq = 0;
+        const bool wok = pair_of(t, wl, wp, wq);
+        const int64_t Cc = (int64_t)wp * n + wq;
+        if (a.out && wok) {
+            double *out = a.out + g * a.sout;
+            for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) out[(int64_t)rs * n2 + Cc] = stage[rs * QP + wl];
+        }
+        if (a.packed && !a.sym8) {
+            double *pk = a.packed + g * a.spacked;
+            if (wok)
+                for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {
+                    const int64_t R = rs;
+                    if (R >= Cc) pk[tri_index(R, Cc)] = stage[rs * QP + wl] * (R == Cc ? a.diag_mult : 1.0);
                 }
-#pragma unroll
-        for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = mn[rt][kk];
-    }
-    lds_barrier();
-    // write-out: 8 lanes cover the q run of one (r',s')
-    const int ql = threadIdx.x & 7;
-    if (a.out) {
-        double *out = a.out + g * a.sout;
-        for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32)
-            if (ql < nq) out[(int64_t)rs * n2 + (int64_t)p * n + q0 + ql] = stage[rs * QP + ql];
-    }
-    if (a.packed && !a.sym8) {
-        double *pk = a.packed + g * a.spacked;
-        for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {
-            const int64_t R = rs, Cc = (int64_t)p * n + q0 + ql;
-            if (ql < nq && R >= Cc) pk[tri_index(R, Cc)] = stage[rs * QP + ql] * (R == Cc ? a.diag_mult : 1.0);
-        }
-        // zero the padding [M, packed_len) once per geometry
-        if (blockIdx.x == 0 && tq == tq_begin) {
-            const int64_t M = n2 * (n2 + 1) / 2;
-            for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
-        }
-    }
-    if (a.packed && a.sym8) {
-        // 8-fold compressed vector: only r' >= s', p >= q, (r's') >= (pq) is kept, with its multiplicity
-        double *pk = a.packed + g * a.spacked;
-        const int q = q0 + ql;
-        if (ql < nq && p >= q) {
-            const int64_t v = tri_index(p, q);
-            const double mq = (p != q) ? 2.0 : 1.0;
-            for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {
-                const int r2 = rs / n, s2 = rs - r2 * n;
-                const int64_t u = tri_index(r2, s2);
-                if (r2 >= s2 && u >= v)
-                    pk[tri_index(u, v)] =
-                        stage[rs * QP + ql] * ((u == v ? a.diag_mult : 1.0) * mq * (r2 != s2 ? 2.0 : 1.0));
+            // zero the padding [M, packed_len) once per geometry
+            if (blockIdx.x == 0 && t == t_begin) {
+                const int64_t M = n2 * (n2 + 1) / 2;
+                for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
             }
         }
-        if (blockIdx.x == 0 && tq == tq_begin) {
-            const int64_t mm = (int64_t)n * (n + 1) / 2, M = mm * (mm + 1) / 2;
-            for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
+        if (a.packed && a.sym8) {
+            // 8-fold compressed vector: only r' >= s', p >= q, (r's') >= (pq) is kept, with its multiplicity
+            double *pk = a.packed + g * a.spacked;
+            if (wok && wp >= wq) {
+                const int64_t v = tri_index(wp, wq);
+                const double mq = (wp != wq) ? 2.0 : 1.0;
+                for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {
+                    const int r2 = rs / n, s2 = rs - r2 * n;
+                    const int64_t u = tri_index(r2, s2);
+                    if (r2 >= s2 && u >= v)
+                        pk[tri_index(u, v)] =
+                            stage[rs * QP + wl] * ((u == v ? a.diag_mult : 1.0) * mq * (r2 != s2 ? 2.0 : 1.0));
+                }
+            }
+            if (blockIdx.x == 0 && t == t_begin) {
+                const int64_t mm = (int64_t)n * (n + 1) / 2, M = mm * (mm + 1) / 2;
+                for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
+            }
         }
+        lds_barrier();  // the stage is free again; the stores above drain while the next tile is computed
     }
-    lds_barrier();  // the stage is free again; the stores above drain while the next tile is computed
-    }
-    (void)n3;
 }
 
 int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t st) {
@@ -321,7 +328,8 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     static const int tpw_env = getenv("EVC_PT_TILES") ? atoi(getenv("EVC_PT_TILES")) : 4;
     // few geometries: keep one tile per workgroup so that there are enough workgroups for the chip
     a.tiles_per_wg = (count < 4 || tpw_env < 1) ? 1 : (tpw_env > ntq ? ntq : tpw_env);
-    const dim3 grid(n * ((ntq + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
+    const int ntiles = a.lead_sym ? (n * (n + 1) / 2 + 7) / 8 : n * ntq;
+    const dim3 grid((unsigned)((ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
     if (npad == 16) {
         const size_t lds = sizeof(double) * ((size_t)16 * 16 + (size_t)n * n * 9);
         hipLaunchKernelGGL(pt_kernel<16>, grid, dim3(256), lds, st, a);
@@ -716,12 +724,21 @@ int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64
 // GsAO[m,b,c,d] = G[m,b,c,d] + G[b,m,d,c] + G[c,d,m,b] + G[d,c,b,m]   (G = 2-RDM in the AO basis)
 // Blocks [nb1, nb1 + 3A): term3[A*3+x] = sum_ab dhcore[A,x,a,b] * Pao[a,b].
 // Remaining blocks: y2[e] = sum_slab y2part[slab][e].
-constexpr int kIp1PerThread = 4;
+// elements of the (b,c,d) range per thread (EVC_IP1_PT = 4, 8 or 16; fixed for the life of the process: it sizes
+// the t2part workspace)
+static int ip1_per_thread() {
+    static const int pt = [] {
+        const int v = getenv("EVC_IP1_PT") ? atoi(getenv("EVC_IP1_PT")) : 4;
+        return (v == 8 || v == 16) ? v : 4;
+    }();
+    return pt;
+}
 int ip1_chunks(int n) {
     const int64_t n3 = (int64_t)n * n * n;
-    return (int)ceil_div(n3, 256 * kIp1PerThread);
+    return (int)ceil_div(n3, 256 * ip1_per_thread());
 }
 
+template <int kIp1PerThread>
 __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
     __shared__ double scr[3][4];
     __shared__ double part[4][64];
@@ -840,7 +857,11 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
 
 int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st) {
     const int blocks = a.n * a.nchunk + a.natm * 3 + (a.n * a.n + 63) / 64;
-    hipLaunchKernelGGL(ip1_dh_kernel, dim3(blocks, (unsigned)count), dim3(256), 0, st, a);
+    switch (ip1_per_thread()) {
+        case 16: hipLaunchKernelGGL(ip1_dh_kernel<16>, dim3(blocks, (unsigned)count), dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL(ip1_dh_kernel<8>, dim3(blocks, (unsigned)count), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(ip1_dh_kernel<4>, dim3(blocks, (unsigned)count), dim3(256), 0, st, a); break;
+    }
     EVC_LAUNCH_CHECK("ip1_dh");
     return 0;
 }
