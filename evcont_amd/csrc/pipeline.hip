@@ -239,7 +239,8 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
             pa.sout = sw;
             // compressed layout: the AO integrals are 8-fold symmetric by contract, the first step only
             // produces the q <= p half of its output and the second one reads the lower triangles
-            pa.lead_sym = pa.in_lower = is_sym8(t->layout) ? 1 : 0;   // (in_lower: eri[p,q,r,s] = eri[p,q,s,r])
+            // (in_lower: eri[p,q,r,s] = eri[p,q,s,r]; rs_lower: the next step's leading pairs are (r',s'), s' <= r')
+            pa.lead_sym = pa.in_lower = pa.rs_lower = is_sym8(t->layout) ? 1 : 0;
             if ((rc = launch_pair_transform(pa, cc, st))) return rc;
             // ... and the second step again only needs the q <= p half of ITS leading pair
             pa.in = w.B1 + o;
@@ -436,10 +437,11 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 const int cc = cnt - c0 < chunk ? cnt - c0 : chunk;
                 const int64_t o = (int64_t)c0 * sw;
                 if (sym8) {
+                    // (K3 was written for l <= k only by the symmetric second step of phase A)
                     if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, w.B1 + o, sw,
-                                             G ? G + (int64_t)c0 * sG : nullptr, sG, cc, 0, st)))
+                                             G ? G + (int64_t)c0 * sG : nullptr, sG, cc, 1, st)))
                         return rc;
-                    if ((rc = launch_y2_sb(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, st))) return rc;
+                    if ((rc = launch_y2_fold(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, st))) return rc;
                 } else {
                     if ((rc = launch_unpack_sym(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, w.B1 + o, sw,
                                                 G ? G + (int64_t)c0 * sG : nullptr, sG, cc, st)))
@@ -456,8 +458,9 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.sin = sw;
                 pa.out = w.B2 + o;
                 pa.sout = sw;
-                pa.lead_sym = pa.in_lower = sym8;   // SB is fully symmetric
+                pa.lead_sym = pa.in_lower = pa.rs_lower = sym8;   // SB is fully symmetric
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
+                pa.rs_lower = 0;   // every (m,b) of G^AO[m,b,c,d] is needed
                 // the result is only valid for d <= c of G^AO[m,b,c,d] (fold_cd below)
                 pa.in = w.B2 + o;
                 pa.out = w.B1 + o;

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     constexpr int QT = 8, QP = QT + 1;
     extern __shared__ __align__(16) double sm[];
     double *Xs = sm;                  // NPAD * LDX
-    double *stage = Xs + NPAD * LDX;  // n*n*QP
+    double *stage = Xs + NPAD * LDX;  // n*n*QP, or n(n+1)/2*QP with rs_lower
     const int n = a.n;
     const int64_t n2 = (int64_t)n * n;
     const int64_t g = blockIdx.y;
@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(ntiles, t_begin + a.tiles_per_wg);
     if (t_begin >= t_end) return;
     const bool lower = a.in_lower != 0;  // the n x n matrices are symmetric and valid for r >= s only
+    // rs_lower: the consumer needs the result N[r'][s'] for s' <= r' only: upper tiles of X^T H are not computed,
+    // the stage holds the lower triangle (row index tri(r',s')) and only those rows of `out` are written
+    const bool rsl = a.rs_lower != 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     // pair `ql` of tile t -> (p, q); false if the slot is idle
@@ -227,9 +230,8 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
                         for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
                 if (a.k3) {
-                    // lead_sym: K3[s'][p][q][:] = K3[s'][q][p][:]; the mirror image is stored from here
+                    // lead_sym: only K3[s'][p][q][:] with q <= p is written (its consumer folds the p <-> q symmetry)
                     double *K3 = a.k3 + g * a.sk3;
-                    const bool mirror = sym && q < p;
 #pragma unroll
                     for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
@@ -237,10 +239,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
                             for (int reg = 0; reg < 4; ++reg) {
                                 const int r = rt * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
-                                if (r < n && s2 < n) {
-                                    K3[((int64_t)s2 * n + p) * n2 + (int64_t)q * n + r] = h[rt][st][reg];
-                                    if (mirror) K3[((int64_t)s2 * n + q) * n2 + (int64_t)p * n + r] = h[rt][st][reg];
-                                }
+                                if (r < n && s2 < n) K3[((int64_t)s2 * n + p) * n2 + (int64_t)q * n + r] = h[rt][st][reg];
                             }
                 }
                 // N = X^T H : B operand of k-step kk is register kk%4 of H's row tile kk/4
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
                     for (int it = 0; it < NT; ++it)
 #pragma unroll
                         for (int st = 0; st < NT; ++st)
-                            nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
+                            if (!(rsl && st > it)) nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
 #pragma unroll
                 for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -263,7 +262,10 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg) {
                             const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
-                            if (r2 < n && s2 < n) stage[(r2 * n + s2) * QP + ql] = nn[it][st][reg];
+                            if (r2 < n && s2 < n) {
+                                if (!rsl) stage[(r2 * n + s2) * QP + ql] = nn[it][st][reg];
+                                else if (s2 <= r2) stage[(r2 * (r2 + 1) / 2 + s2) * QP + ql] = nn[it][st][reg];
+                            }
                         }
             }
 #pragma unroll
@@ -282,7 +284,14 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
         const int64_t Cc = (int64_t)wp * n + wq;
         if (a.out && wok) {
             double *out = a.out + g * a.sout;
-            for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) out[(int64_t)rs * n2 + Cc] = stage[rs * QP + wl];
+            if (!rsl) {
+                for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) out[(int64_t)rs * n2 + Cc] = stage[rs * QP + wl];
+            } else {
+                for (int u = threadIdx.x >> 3; u < npairs; u += 32) {
+                    const int r2 = (int)tri_row(u), s2 = u - r2 * (r2 + 1) / 2;
+                    out[((int64_t)r2 * n + s2) * n2 + Cc] = stage[u * QP + wl];
+                }
+            }
         }
         if (a.packed && !a.sym8) {
             double *pk = a.packed + g * a.spacked;
@@ -303,12 +312,22 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             if (wok && wp >= wq) {
                 const int64_t v = tri_index(wp, wq);
                 const double mq = (wp != wq) ? 2.0 : 1.0;
-                for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {
-                    const int r2 = rs / n, s2 = rs - r2 * n;
-                    const int64_t u = tri_index(r2, s2);
-                    if (r2 >= s2 && u >= v)
+                if (rsl) {
+                    // the stage row index IS u = tri(r',s'); r' == s' <=> u + 1 is a triangular number's end
+                    for (int u = (int)v + (threadIdx.x >> 3); u < npairs; u += 32) {
+                        const int r2 = (int)tri_row(u);
+                        const bool diag = (u - r2 * (r2 + 1) / 2) == r2;
                         pk[tri_index(u, v)] =
-                            stage[rs * QP + wl] * ((u == v ? a.diag_mult : 1.0) * mq * (r2 != s2 ? 2.0 : 1.0));
+                            stage[u * QP + wl] * ((u == v ? a.diag_mult : 1.0) * mq * (diag ? 1.0 : 2.0));
+                    }
+                } else {
+                    for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {
+                        const int r2 = rs / n, s2 = rs - r2 * n;
+                        const int64_t u = tri_index(r2, s2);
+                        if (r2 >= s2 && u >= v)
+                            pk[tri_index(u, v)] =
+                                stage[rs * QP + wl] * ((u == v ? a.diag_mult : 1.0) * mq * (r2 != s2 ? 2.0 : 1.0));
+                    }
                 }
             }
             if (blockIdx.x == 0 && t == t_begin) {
@@ -330,11 +349,12 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     a.tiles_per_wg = (count < 4 || tpw_env < 1) ? 1 : (tpw_env > ntq ? ntq : tpw_env);
     const int ntiles = a.lead_sym ? (n * (n + 1) / 2 + 7) / 8 : n * ntq;
     const dim3 grid((unsigned)((ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
+    const size_t stage_rows = a.rs_lower ? (size_t)n * (n + 1) / 2 : (size_t)n * n;
     if (npad == 16) {
-        const size_t lds = sizeof(double) * ((size_t)16 * 16 + (size_t)n * n * 9);
+        const size_t lds = sizeof(double) * ((size_t)16 * 16 + stage_rows * 9);
         hipLaunchKernelGGL(pt_kernel<16>, grid, dim3(256), lds, st, a);
     } else if (npad == 32) {
-        const size_t lds = sizeof(double) * ((size_t)32 * 48 + (size_t)n * n * 9);
+        const size_t lds = sizeof(double) * ((size_t)32 * 48 + stage_rows * 9);
         static bool attr = false;
         if (!attr) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pt_kernel<32>),
@@ -522,7 +542,7 @@ int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, doub
 // operand of both the Y2 contraction and the OAO->AO rotation (every image of (i,j,k,l) is the same element, so
 // the two symmetrisations of the general path coincide), and optionally G = p8(ijkl).  One workgroup per (i,j)
 // writes a contiguous n*n block; same XCD-aware geometry order as above (0.87 MB per geometry at N = 30).
-// lead_half: SB is only needed for i >= j (its consumers use the i <-> j symmetry).
+// lead_half: SB is only needed for i >= j and l <= k (its consumers fold both symmetries).
 __global__ __launch_bounds__(256) void unpack8_kernel(const double *__restrict__ p, int64_t sp, int n,
                                                       double *__restrict__ SB, int64_t sws,
                                                       double *__restrict__ Gout, int64_t sG, int count,
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(256) void unpack8_kernel(const double *__restrict__
         const int k = idx / n, l = idx - k * n;
         const int64_t v = k >= l ? tri_index(k, l) : tri_index(l, k);
         const double val = u >= v ? p[tri_index(u, v)] : p[tri_index(v, u)];
-        if (want_sb) sb[idx] = 4.0 * val;
+        if (want_sb && !(lead_half && l > k)) sb[idx] = 4.0 * val;
         if (go) go[idx] = val;
     }
 }
@@ -689,6 +709,96 @@ __global__ __launch_bounds__(256) void y2_sb_kernel(const double *__restrict__ S
     }
 }
 
+// Folded form for the symmetric pipeline: SB is only valid for i >= j, l <= k and K3[j][k][l][:] only for l <= k;
+// both are symmetric under i <-> j resp. k <-> l, so
+//   partial[slab][i][a] = sum_j sum_{l <= k} (l < k ? 2 : 1) SB[max(i,j)][min(i,j)][k][l] K3[j][k][l][a].
+// A K step covers 8 consecutive l of one (j,k) row: k/8 + 1 steps per row.
+template <int NT>
+__global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__ SB, const double *__restrict__ K3,
+                                                      int n, double *__restrict__ partial, int64_t sws) {
+    __shared__ double red[4][NT * 16][NT * 16 + 1];
+    SB += (int64_t)blockIdx.y * sws;
+    K3 += (int64_t)blockIdx.y * sws;
+    partial += (int64_t)blockIdx.y * sws;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int spj = 0;  // steps per j
+    for (int k = 0; k < n; ++k) spj += k / 8 + 1;
+    const int64_t nsteps = (int64_t)n * spj;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int64_t per = (nsteps + nw - 1) / nw;
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t s0 = w * per, s1 = min(nsteps, s0 + per);
+    const bool even = (n & 1) == 0;  // every (i,j,k) row of SB starts 16-byte aligned
+    d4 acc[NT][NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int64_t s = s0; s < s1; ++s) {
+        const int j = (int)(s / spj);
+        const int r = (int)(s - (int64_t)j * spj);
+        int b = 0;  // k / 8: 8 rows with b + 1 steps each
+        while (4 * (b + 1) * (b + 2) <= r) ++b;
+        const int rp = r - 4 * b * (b + 1);
+        const int k = 8 * b + rp / (b + 1), ls = rp % (b + 1);
+        const int l = ls * 8 + 2 * l4;  // this lane's K slots: l, l + 1
+        const bool v0 = l <= k, v1 = l + 1 <= k;
+        const double w0 = l < k ? 2.0 : 1.0, w1 = l + 1 < k ? 2.0 : 1.0;
+        const double *kb = K3 + (((int64_t)j * n + k) * n + l) * n;
+        double a0[NT], a1[NT], b0[NT], b1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int i = t * 16 + l15;
+            const bool iok = i < n;
+            const int ii = iok ? i : 0;
+            const int hi = ii > j ? ii : j, lo = ii > j ? j : ii;
+            const double *ap = SB + (((int64_t)hi * n + lo) * n + k) * n + l;
+            double2 af;
+            if (even) af = (iok && v0) ? *reinterpret_cast<const double2 *>(ap) : make_double2(0.0, 0.0);
+            else af = make_double2((iok && v0) ? ap[0] : 0.0, (iok && v1) ? ap[1] : 0.0);
+            a0[t] = (iok && v0) ? af.x * w0 : 0.0;
+            a1[t] = (iok && v1) ? af.y * w1 : 0.0;
+            b0[t] = (iok && v0) ? kb[i] : 0.0;
+            b1[t] = (iok && v1) ? kb[n + i] : 0.0;
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(a0[ti], b0[ta], acc[ti][ta]);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(a1[ti], b1[ta], acc[ti][ta]);
+    }
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
+    __syncthreads();
+    double *dst = partial + (int64_t)blockIdx.x * n * n;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, a = idx % n;
+        dst[idx] = (red[0][i][a] + red[1][i][a]) + (red[2][i][a] + red[3][i][a]);
+    }
+}
+
+int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
+    const int nt = (n + 15) / 16;
+    const dim3 grid(kY2Slabs, (unsigned)count);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(y2_fold_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
+        case 2: hipLaunchKernelGGL(y2_fold_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
+        case 3: hipLaunchKernelGGL(y2_fold_kernel<3>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
+        case 4: hipLaunchKernelGGL(y2_fold_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
+        default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
+    }
+    EVC_LAUNCH_CHECK("y2_fold");
+    return 0;
+}
+
 int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
     const int64_t ktot = (int64_t)n * n * n;
     const int nt = (n + 15) / 16;
@@ -752,28 +862,33 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
         const int m = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         const int64_t e0 = (int64_t)ch * 256 * kIp1PerThread;
-        if (a.presym && a.fold_cd && (n3 & 1) == 0) {
+        if (a.presym && a.fold_cd && (n & 1) == 0) {
             // symmetrised operand that is only valid for d <= c (and symmetric in c <-> d, like ip1 itself): the
-            // dot runs over the lower triangles with weight 2 off the diagonal; n is even here, so a 16-byte
-            // pair never straddles two c rows
-#pragma unroll
-            for (int u = 0; u < kIp1PerThread / 2; ++u) {
-                const int64_t e = e0 + ((int64_t)u * 256 + threadIdx.x) * 2;
-                if (e < n3) {
-                    const int d = (int)(e % n), c = (int)((e / n) % n);
-                    if (d <= c) {
-                        const int64_t off = m * n3 + e;
-                        const double2 gr = *reinterpret_cast<const double2 *>(G + off);
-                        const double2 p0 = *reinterpret_cast<const double2 *>(ip1 + off);
-                        const double2 p1 = *reinterpret_cast<const double2 *>(ip1 + n4 + off);
-                        const double2 p2 = *reinterpret_cast<const double2 *>(ip1 + 2 * n4 + off);
-                        const double gx = d < c ? 2.0 * gr.x : gr.x;
-                        const double gy = d + 1 < c ? 2.0 * gr.y : (d + 1 == c ? gr.y : 0.0);
-                        a0 = fma(p0.y, gy, fma(p0.x, gx, a0));
-                        a1 = fma(p1.y, gy, fma(p1.x, gx, a1));
-                        a2 = fma(p2.y, gy, fma(p2.x, gx, a2));
-                    }
-                }
+            // dot runs over the lower triangles with weight 2 off the diagonal.  The 16-byte pairs (d, d+1), d even,
+            // d <= c, of one b are numbered row by row (rows 2h and 2h+1 hold h+1 pairs each, h(h+1) pairs precede
+            // row 2h), so every lane of the chunk has a live pair; n is even here.
+            const int hp = n / 2, ppb = hp * (hp + 1);
+            const int64_t npairs = (int64_t)n * ppb;
+            const int64_t per = (npairs + nchunk - 1) / nchunk;
+            const int64_t pe = min(npairs, (int64_t)(ch + 1) * per);
+            for (int64_t ep = (int64_t)ch * per + threadIdx.x; ep < pe; ep += 256) {
+                const int b = (int)(ep / ppb), t = (int)(ep - (int64_t)b * ppb);
+                int h = (int)sqrt((double)t);
+                while (h * (h + 1) > t) --h;
+                while ((h + 1) * (h + 2) <= t) ++h;
+                const int tp = t - h * (h + 1);
+                const int up = tp >= h + 1 ? 1 : 0;
+                const int c = 2 * h + up, d = 2 * (tp - up * (h + 1));
+                const int64_t off = m * n3 + (int64_t)b * n2 + c * n + d;
+                const double2 gr = *reinterpret_cast<const double2 *>(G + off);
+                const double2 p0 = *reinterpret_cast<const double2 *>(ip1 + off);
+                const double2 p1 = *reinterpret_cast<const double2 *>(ip1 + n4 + off);
+                const double2 p2 = *reinterpret_cast<const double2 *>(ip1 + 2 * n4 + off);
+                const double gx = d < c ? 2.0 * gr.x : gr.x;
+                const double gy = d + 1 < c ? 2.0 * gr.y : (d + 1 == c ? gr.y : 0.0);
+                a0 = fma(p0.y, gy, fma(p0.x, gx, a0));
+                a1 = fma(p1.y, gy, fma(p1.x, gx, a1));
+                a2 = fma(p2.y, gy, fma(p2.x, gx, a2));
             }
         } else if (a.presym && (n3 & 1) == 0) {
             // symmetrised operand: a plain streaming dot, 16-byte loads
