@@ -10,7 +10,8 @@ from __future__ import annotations
 import numpy as np
 
 from .ab_initio_gradients_loewdin import get_energy_with_grad
-from .ab_initio_eigenvector_continuation import approximate_ground_state_OAO, _trdms  # noqa: F401 (re-export)
+from .ab_initio_eigenvector_continuation import (approximate_ground_state_OAO, _trdms,  # noqa: F401 (re-export)
+                                                 get_trdm_compression)
 from .electron_integral_utils import get_basis, get_integrals  # noqa: F401 (re-export)
 from .evaluator import ContinuationEvaluator, DeviceAO
 from .integrals import ao_arrays, energy_nuc, grad_nuc
@@ -24,9 +25,14 @@ def _grad_scanner_base():
         return object
 
 
-def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True):
+def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="default"):
     """Fake PySCF gradient scanner driven by the continuation (reference :20-57): ``scanner(mol)``
-    returns ``(E_tot, grad)`` and stores the predicted RDMs on ``scanner.base``."""
+    returns ``(E_tot, grad)`` and stores the predicted RDMs on ``scanner.base``.
+
+    ``compress``: storage of the resident training data, ``None``, ``"sym8"`` or ``"default"``
+    (= ``set_trdm_compression``); with ``"sym8"`` the stored predicted 2-RDM is the 8-fold symmetrised one."""
+    if compress == "default":
+        compress = get_trdm_compression()
 
     class Base:
         converged = True
@@ -53,7 +59,7 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True):
                     # whose eigensolvers start from the previous step's eigenvectors (EVC_FLAG_WARM_START)
                     ao = ao_arrays(mol, need_grad=True)
                     if self._ev is None:
-                        self._ev = ContinuationEvaluator(_trdms(one_rdm, two_rdm, overlap),
+                        self._ev = ContinuationEvaluator(_trdms(one_rdm, two_rdm, overlap, compress),
                                                          int(np.asarray(ao.aoslices).shape[0]), warm_start=True)
                     en, grad, rdm_o, rdm_t = self._ev.energy_with_grad(
                         DeviceAO.from_arrays(ao, self._ev.t.device), return_density_matrices=True)
@@ -66,7 +72,7 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True):
 
 
 def get_trajectory(init_mol, overlap, one_rdm, two_rdm, dt=10.0, steps=10, init_veloc=None, hermitian=True,
-                   trajectory_output=None, energy_output=None):
+                   trajectory_output=None, energy_output=None, compress="default"):
     """NVE trajectory from the continuation (reference :60-125).  Single process: the reference's
     rank-0-computes / Bcast split exists only to coexist with MPI-parallel training code.
 
@@ -74,7 +80,7 @@ def get_trajectory(init_mol, overlap, one_rdm, two_rdm, dt=10.0, steps=10, init_
     that can be rebuilt at new coordinates (``with_coords``, e.g. ``evcont_amd.hchain.HChainMol``) by the
     velocity-Verlet integrator below, with the same conventions (Bohr, atomic time units, frame 0 = the
     initial geometry, ``steps`` frames)."""
-    scanner_fun = get_scanner(init_mol, one_rdm, two_rdm, overlap, hermitian=hermitian)
+    scanner_fun = get_scanner(init_mol, one_rdm, two_rdm, overlap, hermitian=hermitian, compress=compress)
     if hasattr(init_mol, "with_coords"):
         frames = nve_velocity_verlet(scanner_fun, init_mol, dt=dt, steps=steps, veloc=init_veloc,
                                      trajectory_output=trajectory_output, energy_output=energy_output)

@@ -1,6 +1,8 @@
 """Device-backed mirror of ``evcont/ab_initio_eigenvector_continuation.py``."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -44,19 +46,41 @@ def _select(vals, vecs, nroots, ground_state):
     return np.array(vals[order].real), np.array(vecs[:, order].real.T)
 
 
-def _trdms(one_RDM, two_RDM, S) -> DeviceTRDMs:
-    key = cache.key_of(one_RDM, two_RDM, S, ("trdms",))
+# How the resident copy of the training data is stored by the mol-level entry points (``*_OAO``,
+# ``get_energy_with_grad``, ``MD_utils.get_scanner``): None = in the layout the caller passed (any input),
+# "sym8" = 8-fold compressed (``evaluator.DeviceTRDMs.compress_sym8_``: 3.7x fewer streamed bytes and the
+# symmetric AO-side pipeline; exact for AO integrals with the index symmetries of real two-electron integrals,
+# i.e. for every PySCF molecule; ``predicted_two_rdm`` then is the symmetrised 2-RDM).
+_COMPRESS = os.environ.get("EVCONT_AMD_COMPRESS") or None
+
+
+def set_trdm_compression(mode) -> None:
+    """``None`` (default) or ``"sym8"``; applies to training data uploaded from now on."""
+    global _COMPRESS
+    if mode not in (None, "sym8"):
+        raise ValueError(f"unknown t-RDM compression {mode!r} (known: None, 'sym8')")
+    _COMPRESS = mode
+
+
+def get_trdm_compression():
+    return _COMPRESS
+
+
+def _trdms(one_RDM, two_RDM, S, compress=None) -> DeviceTRDMs:
+    key = cache.key_of(one_RDM, two_RDM, S, ("trdms", compress))
     t = cache.get(key)
     if t is None:
-        t = cache.put(key, DeviceTRDMs(one_RDM, two_RDM, S, _dev()))
+        t = cache.put(key, DeviceTRDMs(one_RDM, two_RDM, S, _dev(), compress=compress))
     return t
 
 
-def _evaluator(one_RDM, two_RDM, S, natm: int) -> ContinuationEvaluator:
-    key = cache.key_of(one_RDM, two_RDM, S, ("evaluator", int(natm)))
+def _evaluator(one_RDM, two_RDM, S, natm: int, compress="default") -> ContinuationEvaluator:
+    if compress == "default":
+        compress = _COMPRESS
+    key = cache.key_of(one_RDM, two_RDM, S, ("evaluator", int(natm), compress))
     ev = cache.get(key)
     if ev is None:
-        ev = cache.put(key, ContinuationEvaluator(_trdms(one_RDM, two_RDM, S), natm))
+        ev = cache.put(key, ContinuationEvaluator(_trdms(one_RDM, two_RDM, S, compress), natm))
     return ev
 
 
@@ -100,7 +124,9 @@ def approximate_multistate(h1, h2, one_RDM, two_RDM, S, nroots=1, hermitian=True
 
 def _oao(mol, one_RDM, two_RDM, S, nroots, hermitian=True, ground_state=False):
     ao = ao_arrays(mol, need_grad=False)
-    ev = _evaluator(one_RDM, two_RDM, S, int(np.asarray(ao.aoslices).shape[0]))
+    # (the non-Hermitian branch works on the subspace matrix of the layout the caller passed)
+    ev = _evaluator(one_RDM, two_RDM, S, int(np.asarray(ao.aoslices).shape[0]),
+                    compress="default" if hermitian else None)
     dao = DeviceAO.from_arrays(ao, ev.t.device, energy_only=True)
     res = ev.energies(dao, nroots)
     if hermitian:

@@ -81,7 +81,8 @@ class TRDMContainer:
         """``evaluator.DeviceTRDMs`` of the current training set, uploaded on first use and whenever the
         arrays were replaced (append, prune, or a script assigning ``np.load`` results to the attributes,
         ``md_H30_evcont_from_DMRG.py:72-85``).  ``layout``: "pack2" (pairs x packed electrons, needs the
-        bra<->ket symmetric data every container of the reference produces), "pair5", "elec3", "full6"."""
+        bra<->ket symmetric data every container of the reference produces), "pair5", "elec3", "full6", or "sym8"
+        (8-fold compressed on the device from the pack2 form, ``DeviceTRDMs.compress_sym8_``)."""
         from .evaluator import DeviceTRDMs
         from .synthetic import pack_rows
         if self.two_rdm is None:
@@ -90,10 +91,11 @@ class TRDMContainer:
         key = key_of(self.one_rdm, self.two_rdm, self.overlap, (layout, str(device)))   # address + content sample
         if self._device is None or self._device_key != key:
             pairs, elec = {"full6": (False, False), "pair5": (True, False), "elec3": (False, True),
-                           "pack2": (True, True)}[layout]
+                           "pack2": (True, True), "sym8": (True, True)}[layout]
             two = np.asarray(self.two_rdm, dtype=np.float64)
             if two.ndim == 6 and (pairs or elec):
                 two = pack_rows(two, pairs, elec)
-            self._device = DeviceTRDMs(self.one_rdm, two, self.overlap, device)
+            self._device = DeviceTRDMs(self.one_rdm, two, self.overlap, device,
+                                       compress="sym8" if layout == "sym8" else None)
             self._device_key = key
         return self._device

@@ -405,8 +405,72 @@ __global__ __launch_bounds__(256) void gemv_cols_kernel(GemvColsLaunch L, int g0
     }
 }
 
+// Row-split variant for matrices with few columns (the 8-fold compressed layout: 212 chunks of 512 columns do not
+// fill 256 CUs): a block owns 128 columns, its four waves take every fourth group of 8 rows and the four partial
+// sums are added in fixed order through LDS.  The row weights are wave-uniform loads.
+constexpr int kColsRsMaxCols = 200000;
 template <int G>
-static void cols_launch(const GemvColsLaunch &L, int total, int g0, hipStream_t st) {
+__global__ __launch_bounds__(256) void gemv_cols_rs_kernel(GemvColsLaunch L, int g0) {
+    __shared__ double2 red[4][G][64];
+    constexpr int U = 8;
+    int bid = blockIdx.x;
+    const int which = bid >= L.nblk0 ? 1 : 0;
+    if (which) bid -= L.nblk0;
+    const ColProblem &P = L.p[which];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = (int64_t)bid * 128 + lane * 2;
+    const bool active = c < P.cols;
+    const bool two = c + 1 < P.cols;
+    const double *__restrict__ A = P.A + (active ? c : 0);
+    const double *__restrict__ w = P.w + (int64_t)g0 * P.wstride;
+    const int64_t ld = P.ld, rows = P.rows;
+    double sx[G], sy[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) sx[g] = sy[g] = 0.0;
+    if (active) {
+        for (int64_t r = (int64_t)wave * U; r < rows; r += 4 * U) {
+            double2 a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t rr = r + u < rows ? r + u : rows - 1;   // clamped rows get weight 0 below
+                a[u] = two ? ld_stream(A + rr * ld) : make_double2(A[rr * ld], 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const double wr = r + u < rows ? w[(int64_t)g * P.wstride + r + u] : 0.0;
+                    sx[g] = fma(wr, a[u].x, sx[g]);
+                    sy[g] = fma(wr, a[u].y, sy[g]);
+                }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) red[wave][g][lane] = make_double2(sx[g], sy[g]);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * 64; idx += 256) {
+        const int g = idx >> 6, ln = idx & 63;
+        const int64_t cc = (int64_t)bid * 128 + ln * 2;
+        if (cc < P.cols) {
+            const double2 p0 = red[0][g][ln], p1 = red[1][g][ln], p2 = red[2][g][ln], p3 = red[3][g][ln];
+            const double vx = (p0.x + p1.x) + (p2.x + p3.x), vy = (p0.y + p1.y) + (p2.y + p3.y);
+            double *o = P.out + (int64_t)(g0 + g) * P.ostride + cc;
+            if (cc + 1 < P.cols) *reinterpret_cast<double2 *>(o) = make_double2(vx, vy);
+            else *o = vx;
+        }
+    }
+}
+
+template <int G>
+static void cols_launch(const GemvColsLaunch &Lin, int total, int g0, hipStream_t st) {
+    if (Lin.p[0].cols <= kColsRsMaxCols) {
+        GemvColsLaunch L = Lin;
+        L.nblk0 = (int)ceil_div(L.p[0].cols, 128);
+        const int tot = L.nblk0 + (int)ceil_div(L.p[1].cols, 128);
+        hipLaunchKernelGGL((gemv_cols_rs_kernel<G>), dim3(tot), dim3(256), 0, st, L, g0);
+        return;
+    }
+    const GemvColsLaunch &L = Lin;
     hipLaunchKernelGGL((gemv_cols_kernel<G>), dim3(total), dim3(256), 0, st, L, g0);
 }
 

@@ -149,3 +149,28 @@ def test_synthetic_layouts_consistent():
         E, g = orc.energy_with_grad(b, one, pack_rows(two, p, e), S)
         assert abs(E - ref[0]) < 1e-12
         np.testing.assert_allclose(g, ref[1], rtol=0, atol=1e-11)
+
+
+def test_sym8_layout_shape_and_compression_switch():
+    """Host side of the 8-fold compressed layout: shape arithmetic (include/evcont_hip.h EVC_LAYOUT_SYM8) and the
+    package-level switch (no device needed)."""
+    from evcont_amd import _lib
+    from evcont_amd.evaluator import layout_shape
+    from evcont_amd import ab_initio_eigenvector_continuation as aec
+    assert _lib.LAYOUT_SYM8 == 8
+    text = open(os.path.join(REPO, "include", "evcont_hip.h")).read()
+    assert re.search(r"#define\s+EVC_LAYOUT_SYM8\s+8\b", text)
+    for T, n in ((20, 30), (5, 10), (3, 1), (30, 28)):
+        ms = n * (n + 1) // 2
+        assert layout_shape(8, T, n) == (T * (T + 1) // 2, ms * (ms + 1) // 2)
+    assert layout_shape(8, 20, 30) == (210, 108345)
+    assert layout_shape(2, 20, 30)[1] / layout_shape(8, 20, 30)[1] > 3.7
+    assert aec.get_trdm_compression() in (None, "sym8")
+    old = aec.get_trdm_compression()
+    try:
+        aec.set_trdm_compression("sym8")
+        assert aec.get_trdm_compression() == "sym8"
+        with pytest.raises(ValueError):
+            aec.set_trdm_compression("other")
+    finally:
+        aec.set_trdm_compression(old)
