@@ -13,8 +13,10 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW = os.path.join(REPO, "gpurun_out", "profiles_raw")
-OUT = os.path.join(REPO, "profiles")
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+# on the GPU box (tools/make_profiles.sh) the condensed files go to gpurun_out/profiles_out (merged back by gpurun,
+# the raw traces are deleted there); copy them into the tracked profiles/ directory afterwards
+OUT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles")
 
 
 def first(pattern):
@@ -36,7 +38,7 @@ def kernel_means(tag):
 
 
 os.makedirs(OUT, exist_ok=True)
-for tag in ("stats_default", "stats_b32s1", "stats_b16s1", "stats_md"):
+for tag in ("stats_default", "stats_sym8_b32s1", "stats_pack2_b32s1", "stats_sym8_md", "stats_pack2_md"):
     f = first(f"{tag}/*/*kernel_stats.csv")
     if f:
         rows = [r for r in csv.DictReader(open(f)) if "evc::" in r["Name"]]
@@ -46,28 +48,29 @@ for tag in ("stats_default", "stats_b32s1", "stats_b16s1", "stats_md"):
             w.writerows(rows)
 traffic = {}
 table = []
-for regime, key in (("b32", "batch32"), ("b16", "batch16"), ("md", "batch1")):
-    fe, wr = kernel_means(f"pmc_fetch_{regime}"), kernel_means(f"pmc_write_{regime}")
-    for k in sorted(set(fe) | set(wr)):
-        fetch_kib = fe.get(k, {}).get("FETCH_SIZE", 0.0)
-        write_kib = wr.get(k, {}).get("WRITE_SIZE", 0.0)
-        hbm = (2.0 * fetch_kib + write_kib) * 1024.0
-        table.append((regime, k, fetch_kib, write_kib, hbm))
-        short = "k5" if "gemv_rows" in k else "k8" if "gemv_cols" in k else None
-        if short:
-            traffic[f"H30/pack2/{key}/{short}"] = {
-                "kernel": k, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
-                "hbm_bytes_per_launch": hbm,
-                "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)"}
+for lay in ("sym8", "pack2"):
+    for regime, key in (("b32", "batch32"), ("md", "batch1")):
+        fe, wr = kernel_means(f"pmc_fetch_{lay}_{regime}"), kernel_means(f"pmc_write_{lay}_{regime}")
+        for k in sorted(set(fe) | set(wr)):
+            fetch_kib = fe.get(k, {}).get("FETCH_SIZE", 0.0)
+            write_kib = wr.get(k, {}).get("WRITE_SIZE", 0.0)
+            hbm = (2.0 * fetch_kib + write_kib) * 1024.0
+            table.append((lay, regime, k, fetch_kib, write_kib, hbm))
+            short = "k5" if "gemv_rows" in k and "reduce" not in k else "k8" if "gemv_cols" in k else None
+            if short:
+                traffic[f"H30/{lay}/{key}/{short}"] = {
+                    "kernel": k, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+                    "hbm_bytes_per_launch": hbm,
+                    "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)"}
 json.dump(traffic, open(os.path.join(OUT, "pmc_traffic.json"), "w"), indent=1)
 with open(os.path.join(OUT, f"{ROUND}_pmc_hbm_traffic.csv"), "w") as fo:
-    fo.write("regime,kernel,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_per_launch\n")
+    fo.write("layout,regime,kernel,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_per_launch\n")
     for r in table:
         fo.write(",".join(str(x) for x in r) + "\n")
-sq = kernel_means("pmc_sq_b32")
+sq = kernel_means("pmc_sq_sym8_b32")
 if sq:
     cols = sorted({c for d in sq.values() for c in d})
-    with open(os.path.join(OUT, f"{ROUND}_pmc_sq_batch32.csv"), "w") as fo:
+    with open(os.path.join(OUT, f"{ROUND}_pmc_sq_sym8_batch32.csv"), "w") as fo:
         fo.write("kernel," + ",".join(cols) + "\n")
         for k, d in sq.items():
             fo.write(k + "," + ",".join(f"{d.get(c, 0):.0f}" for c in cols) + "\n")

@@ -1,9 +1,11 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel stats + separate PMC passes for the default bench
-# configuration (32 geometries per pass), for 16 geometries per pass and for the MD regime.  Outputs land in
-# gpurun_out/profiles_raw/ and are condensed into profiles/ by tools/condense_profiles.py in the build container.
+# configuration (compressed layout sym8, 32 geometries per pass, 3 streams), for one stream, for the reference's
+# pack2 layout and for the MD regime.  Outputs land in gpurun_out/profiles_raw/ and are condensed into profiles/
+# by tools/condense_profiles.py in the build container.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_raw
+rm -rf $O
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 run() {  # tag, rocprof args..., -- bench args
@@ -11,16 +13,19 @@ run() {  # tag, rocprof args..., -- bench args
   rocprofv3 "$@" > $O/$tag.log 2>&1
 }
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-md-regime --steps 20 --warmup 4"
-run stats_default --kernel-trace --stats --output-format csv -d $O/stats_default -- $BENCH
-run stats_b32s1   --kernel-trace --stats --output-format csv -d $O/stats_b32s1 -- $BENCH --streams 1
-run stats_b16s1   --kernel-trace --stats --output-format csv -d $O/stats_b16s1 -- $BENCH --batch 16 --streams 1
-run stats_md      --kernel-trace --stats --output-format csv -d $O/stats_md -- $BENCH --batch 1 --streams 1 --steps 60
-for b in 32 16; do
-run pmc_fetch_b$b --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_b$b -- $BENCH --batch $b --streams 1 --steps 8
-run pmc_write_b$b --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_b$b -- $BENCH --batch $b --streams 1 --steps 8
+run stats_default      --kernel-trace --stats --output-format csv -d $O/stats_default -- $BENCH
+run stats_sym8_b32s1   --kernel-trace --stats --output-format csv -d $O/stats_sym8_b32s1 -- $BENCH --streams 1
+run stats_pack2_b32s1  --kernel-trace --stats --output-format csv -d $O/stats_pack2_b32s1 -- $BENCH --layout pack2 --streams 1
+run stats_sym8_md      --kernel-trace --stats --output-format csv -d $O/stats_sym8_md -- $BENCH --batch 1 --streams 1 --steps 60
+run stats_pack2_md     --kernel-trace --stats --output-format csv -d $O/stats_pack2_md -- $BENCH --layout pack2 --batch 1 --streams 1 --steps 60
+for lay in sym8 pack2; do
+run pmc_fetch_${lay}_b32 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_${lay}_b32 -- $BENCH --layout $lay --streams 1 --steps 8
+run pmc_write_${lay}_b32 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_${lay}_b32 -- $BENCH --layout $lay --streams 1 --steps 8
+run pmc_fetch_${lay}_md  --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_${lay}_md -- $BENCH --layout $lay --batch 1 --streams 1 --steps 20
+run pmc_write_${lay}_md  --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_${lay}_md -- $BENCH --layout $lay --batch 1 --streams 1 --steps 20
 done
-run pmc_fetch_md  --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_md -- $BENCH --batch 1 --streams 1 --steps 20
-run pmc_write_md  --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_md -- $BENCH --batch 1 --streams 1 --steps 20
-run pmc_sq_b32    --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_sq_b32 -- $BENCH --streams 1 --steps 8
-find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; grep -h "\"metric\"" $O/stats_*.log | cut -c1-160; du -sh $O
-ls $O
+run pmc_sq_sym8_b32    --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_sq_sym8_b32 -- $BENCH --streams 1 --steps 8
+grep -h "\"metric\"" $O/stats_*.log | cut -c1-160; du -sh $O
+python3 $R/tools/condense_profiles.py ${ROUND:-r01} $R/gpurun_out/profiles_out > $R/gpurun_out/profiles_out.log 2>&1
+rm -rf $O
+ls $R/gpurun_out/profiles_out
