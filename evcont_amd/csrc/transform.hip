@@ -287,9 +287,15 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             if (!rsl) {
                 for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) out[(int64_t)rs * n2 + Cc] = stage[rs * QP + wl];
             } else {
+                // (r', s') of stage row u, advanced incrementally: u += 32
+                int r2 = (int)tri_row(threadIdx.x >> 3), s2 = (threadIdx.x >> 3) - r2 * (r2 + 1) / 2;
                 for (int u = threadIdx.x >> 3; u < npairs; u += 32) {
-                    const int r2 = (int)tri_row(u), s2 = u - r2 * (r2 + 1) / 2;
                     out[((int64_t)r2 * n + s2) * n2 + Cc] = stage[u * QP + wl];
+                    s2 += 32;
+                    while (s2 > r2) {
+                        s2 -= r2 + 1;
+                        ++r2;
+                    }
                 }
             }
         }
@@ -314,11 +320,16 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
                 const double mq = (wp != wq) ? 2.0 : 1.0;
                 if (rsl) {
                     // the stage row index IS u = tri(r',s'); r' == s' <=> u + 1 is a triangular number's end
-                    for (int u = (int)v + (threadIdx.x >> 3); u < npairs; u += 32) {
-                        const int r2 = (int)tri_row(u);
-                        const bool diag = (u - r2 * (r2 + 1) / 2) == r2;
+                    const int u0 = (int)v + (threadIdx.x >> 3);
+                    int r2 = (int)tri_row(u0), s2 = u0 - r2 * (r2 + 1) / 2;
+                    for (int u = u0; u < npairs; u += 32) {
                         pk[tri_index(u, v)] =
-                            stage[u * QP + wl] * ((u == v ? a.diag_mult : 1.0) * mq * (diag ? 1.0 : 2.0));
+                            stage[u * QP + wl] * ((u == v ? a.diag_mult : 1.0) * mq * (s2 == r2 ? 1.0 : 2.0));
+                        s2 += 32;
+                        while (s2 > r2) {
+                            s2 -= r2 + 1;
+                            ++r2;
+                        }
                     }
                 } else {
                     for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) {

@@ -114,9 +114,10 @@ def load_checkpoint(directory: str, device=None, suffix: str = "") -> DeviceTRDM
 
 
 def prefix(t: DeviceTRDMs, ntrain: int) -> DeviceTRDMs:
-    """The first ``ntrain`` training states of a pair-layout set; shares the two-body rows with ``t``."""
+    """The first ``ntrain`` training states of a pair-layout set (pack2, pair5 or the compressed sym8); shares the
+    two-body rows with ``t``."""
     k = int(ntrain)
-    assert t.layout in (2, 5) and 1 <= k <= t.T and t.row_offset == 0 and t.rows_local == t.rows_total
+    assert t.layout in (2, 5, 8) and 1 <= k <= t.T and t.row_offset == 0 and t.rows_local == t.rows_total
     self = DeviceTRDMs.__new__(DeviceTRDMs)
     rows, cols = layout_shape(t.layout, k, t.n)
     self.device, self.T, self.n, self.layout = t.device, k, t.n, t.layout

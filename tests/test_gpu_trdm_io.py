@@ -62,16 +62,18 @@ def test_pair_directories_checkpoints_and_prefix(tmp_path):
             assert abs(E - E0) < 1e-10 and np.abs(g - g0).max() < 1e-9
 
 
-def test_learning_curve_from_one_contraction():
+@pytest.mark.parametrize("compress", [None, "sym8"])
+def test_learning_curve_from_one_contraction(compress):
     """Energy vs. number of training states (the scan of 05_Zundel_test_potential_energy.py) from ONE H(R):
-    prefix subsets through subset_energies == evaluating each prefix training set."""
+    prefix subsets through subset_energies == evaluating each prefix training set (also on the 8-fold
+    compressed resident layout, whose pair rows obey the same prefix rule)."""
     from evcont_amd import trdm_io
     from evcont_amd.active_learning import trajectory_hamiltonians, subset_energies
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
     dev = torch.device("cuda:0")
     n, T, A = 6, 5, 3
     S, one, two = make_trdms(n, T, 33)
-    trd = DeviceTRDMs(one, pack_rows(two, True, True), S, dev)
+    trd = DeviceTRDMs(one, pack_rows(two, True, True), S, dev, compress=compress)
     aos = [DeviceAO.from_arrays(make_ao_arrays(n, A, 90 + k), dev) for k in range(3)]
     H, E, enuc = trajectory_hamiltonians(trd, aos)
     curve = subset_energies(H, trd.S, enuc, [list(range(k)) for k in range(1, T + 1)]).cpu().numpy()
