@@ -110,7 +110,8 @@ struct Ip1Args {
     int64_t sip1, sdh, sws;
     int n, natm, nslab, nchunk;
     int presym;            // Gao already carries the 4-fold AO symmetrisation (packed fast path)
-    int fold_cd;           // (with presym) Gao[m,b,c,d] is symmetric in c <-> d and only valid for d <= c
+    int fold_cd;           // (with presym) Gao[m,b,c,d] is symmetric in c <-> d and in m <-> b and only valid for
+                           // d <= c, b <= m
 };
 int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st);
 

@@ -460,7 +460,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.sout = sw;
                 pa.lead_sym = pa.in_lower = pa.rs_lower = sym8;   // SB is fully symmetric
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
-                pa.rs_lower = 0;   // every (m,b) of G^AO[m,b,c,d] is needed
+                // (the second step keeps rs_lower as well: G^AO[m,b,c,d] = G^AO[b,m,c,d], fold_cd reads b <= m)
                 // the result is only valid for d <= c of G^AO[m,b,c,d] (fold_cd below)
                 pa.in = w.B2 + o;
                 pa.out = w.B1 + o;

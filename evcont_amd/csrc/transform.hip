@@ -891,7 +891,9 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
                 const int up = tp >= h + 1 ? 1 : 0;
                 const int c = 2 * h + up, d = 2 * (tp - up * (h + 1));
                 const int64_t off = m * n3 + (int64_t)b * n2 + c * n + d;
-                const double2 gr = *reinterpret_cast<const double2 *>(G + off);
+                // the operand is also symmetric in m <-> b and only stored for b <= m
+                const int64_t goff = b <= m ? off : (int64_t)b * n3 + (int64_t)m * n2 + c * n + d;
+                const double2 gr = *reinterpret_cast<const double2 *>(G + goff);
                 const double2 p0 = *reinterpret_cast<const double2 *>(ip1 + off);
                 const double2 p1 = *reinterpret_cast<const double2 *>(ip1 + n4 + off);
                 const double2 p2 = *reinterpret_cast<const double2 *>(ip1 + 2 * n4 + off);
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
                 const int c = (int)((e / n) % n);
                 const int b = (int)(e / n2);
                 if (a.fold_cd && d > c) continue;
-                double gs = a.presym ? G[m * n3 + e]
+                double gs = a.presym ? (a.fold_cd && b > m ? G[(int64_t)b * n3 + (int64_t)m * n2 + c * n + d] : G[m * n3 + e])
                                      : G[m * n3 + e] + G[b * n3 + m * n2 + d * n + c] +
                                            G[c * n3 + d * n2 + m * n + b] + G[d * n3 + c * n2 + b * n + m];
                 if (a.fold_cd && d < c) gs *= 2.0;
