@@ -158,6 +158,144 @@ __device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ one-sided Jacobi on ONE wave (m <= 32)
+// Hestenes' method on the columns of G = A V (V orthogonal, A symmetric positive definite): the plane rotation of a
+// column pair (p,q) that makes g_p . g_q = 0 is applied to the columns of G and of V; at convergence the columns of
+// G are orthogonal, g_j = lambda_j v_j.  Same round-robin pairing as above, but a step needs no workgroup barrier
+// and no hand-over of rotation parameters: the four lanes of a pair read their two columns (8 rows each, 16-byte
+// LDS loads), reduce the three dot products among themselves with DPP, compute (c,s) redundantly and write the
+// rotated columns back; LDS operations of one wave execute in order, so the next step sees them.  ~1/3 of the
+// two-sided step's latency.  Columns are stored [col][row] with pitch kJwPitch; rows >= m are zero.
+// Called by wave 0 only.  `worst` convergence: |g_p.g_q| <= 1e-15 |g_p||g_q| for every pair of a sweep.
+constexpr int kJwPitch = 34;
+constexpr int kJwMax = 32;
+
+__device__ __forceinline__ double quad_sum(double v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+
+__device__ void jacobi_onesided_wave(double *Gc, double *Vc, int m) {
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 2, sub = lane & 3;
+    const int half = m >> 1;
+    const bool active = k < half;
+    const int row0 = sub * 8;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool bad = false;
+        for (int step = 0; step < m - 1; ++step) {
+            int p = 0, q = 1;
+            if (active) pair_of(step, k, m, p, q);
+            double *gp = Gc + p * kJwPitch + row0, *gq = Gc + q * kJwPitch + row0;
+            double *vp = Vc + p * kJwPitch + row0, *vq = Vc + q * kJwPitch + row0;
+            double2 xg[4], yg[4], xv[4], yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xg[u] = *reinterpret_cast<const double2 *>(gp + 2 * u);
+                yg[u] = *reinterpret_cast<const double2 *>(gq + 2 * u);
+                xv[u] = *reinterpret_cast<const double2 *>(vp + 2 * u);
+                yv[u] = *reinterpret_cast<const double2 *>(vq + 2 * u);
+            }
+            double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                al = fma(xg[u].x, xg[u].x, fma(xg[u].y, xg[u].y, al));
+                be = fma(yg[u].x, yg[u].x, fma(yg[u].y, yg[u].y, be));
+                ga = fma(xg[u].x, yg[u].x, fma(xg[u].y, yg[u].y, ga));
+            }
+            al = quad_sum(al);
+            be = quad_sum(be);
+            ga = quad_sum(ga);
+            // rotate when the columns are not yet orthogonal to working precision
+            const double ab = al * be, g2 = ga * ga;
+            const bool rot = active && (g2 > 1.0e-30 * ab);
+            bad = bad || (active && g2 > 1.0e-18 * ab);
+            double c = 1.0, s = 0.0;
+            if (rot) {
+                // t = sgn(d) b / (|d| + sqrt(d^2 + b^2)), d = beta - alpha, b = 2 gamma (the smaller root)
+                const double d = be - al, b = 2.0 * ga;
+                const double h2 = fma(d, d, b * b);
+                // (the angle only has to make g_p . g_q small: one Newton step on the seeds; c is refined to full
+                // precision so that c^2 + s^2 = 1 to rounding and V stays orthogonal)
+                double y = __builtin_amdgcn_rsq(h2);
+                y = y * fma(-0.5 * h2 * y, y, 1.5);
+                const double den = fabs(d) + h2 * y;
+                double r = __builtin_amdgcn_rcp(den);
+                r = r * fma(-den, r, 2.0);
+                const double t = copysign(b, d * b == 0.0 ? b : d * b) * r;
+                const double x = fma(t, t, 1.0);
+                double z = __builtin_amdgcn_rsq(x);
+                z = z * fma(-0.5 * x * z, z, 1.5);
+                z = z * fma(-0.5 * x * z, z, 1.5);
+                z = z * fma(-0.5 * x * z, z, 1.5);
+                c = z;
+                s = t * z;
+            }
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double2 a, b2;
+                    a.x = c * xg[u].x - s * yg[u].x;
+                    a.y = c * xg[u].y - s * yg[u].y;
+                    b2.x = s * xg[u].x + c * yg[u].x;
+                    b2.y = s * xg[u].y + c * yg[u].y;
+                    *reinterpret_cast<double2 *>(gp + 2 * u) = a;
+                    *reinterpret_cast<double2 *>(gq + 2 * u) = b2;
+                    a.x = c * xv[u].x - s * yv[u].x;
+                    a.y = c * xv[u].y - s * yv[u].y;
+                    b2.x = s * xv[u].x + c * yv[u].x;
+                    b2.y = s * xv[u].y + c * yv[u].y;
+                    *reinterpret_cast<double2 *>(vp + 2 * u) = a;
+                    *reinterpret_cast<double2 *>(vq + 2 * u) = b2;
+                }
+            }
+        }
+        // every pair of this sweep was orthogonal to 1e-9 BEFORE its rotation: quadratic convergence leaves the
+        // columns orthogonal to rounding after it, a confirming sweep is not needed
+        if (__ballot(bad) == 0) break;
+    }
+}
+
+// Eigen-decomposition of the symmetric m x m matrix A (LDS, both triangles) for m <= 32 through the wave kernel
+// above: on return diag(A) holds the eigenvalues and V (row-major, V[i*m+j]) the eigenvectors as columns.
+// shift: A + shift*I must be positive definite (0 for an overlap matrix).  init_v = false: V holds an orthogonal
+// start matrix and A the matrix in THAT basis (warm start), i.e. G0 = V (A + shift I).
+// Gc, Vc: 2 x kJwMax x kJwPitch doubles of LDS.
+__device__ void jacobi_eigh_wave(double *A, double *V, int m, double shift, bool init_v, double *Gc, double *Vc) {
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < kJwMax * kJwPitch; idx += kThreads) {
+        const int j = idx / kJwPitch, i = idx - j * kJwPitch;
+        double g = 0.0, v = 0.0;
+        if (i < m && j < m) {
+            if (init_v) {
+                v = (i == j) ? 1.0 : 0.0;
+                g = A[i * m + j] + ((i == j) ? shift : 0.0);
+            } else {
+                v = V[i * m + j];
+                double acc = shift * v;
+                for (int kk = 0; kk < m; ++kk) acc = fma(V[i * m + kk], A[kk * m + j], acc);
+                g = acc;
+            }
+        }
+        Gc[idx] = g;
+        Vc[idx] = v;
+    }
+    __syncthreads();
+    if (tid < 64) jacobi_onesided_wave(Gc, Vc, m);
+    __syncthreads();
+    for (int idx = tid; idx < m * m; idx += kThreads) {
+        const int i = idx / m, j = idx - i * m;
+        V[idx] = Vc[j * kJwPitch + i];
+    }
+    if (tid < m) {
+        double lam = 0.0;
+        for (int i = 0; i < m; ++i) lam = fma(Vc[tid * kJwPitch + i], Gc[tid * kJwPitch + i], lam);
+        A[tid * m + tid] = lam - shift;
+    }
+    __syncthreads();
+}
+
 // Warm start (EVC_FLAG_WARM_START): `prev` holds the eigenvectors of the previous, nearby problem.  If they
 // are orthonormal to 1e-8 (a stale or never-written buffer is not), V <- prev (padded with the identity) and
 // A <- V^T A V, which is nearly diagonal, so the sweeps that follow are two or three instead of seven or eight.
@@ -213,6 +351,8 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     double *rot = Xs + m * m;    // m
     double *red = rot + m;       // 8
     double *f = red + 8;         // m
+    double *Gc = f + m;          // 2 x kJwMax x kJwPitch (only carved for m <= kJwMax)
+    double *Vc = Gc + kJwMax * kJwPitch;
     const int tid = threadIdx.x, tk = tid & 15, tj = tid >> 4;
     // LAPACK's eigh reads one triangle; numpy.linalg.eigh uses the lower one.
     for (int idx = tid; idx < m * m; idx += kThreads) A[idx] = 0.0;
@@ -228,7 +368,8 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     __syncthreads();
     // warm start from the eigenvectors the previous call left in U (same workspace, nearby geometry)
     const bool warm = a.warm && warm_start_rotate(A, V, Xs, n, m, U, n, red);
-    jacobi_eigh_lds(A, V, m, rot, red, !warm);
+    if (m <= kJwMax) jacobi_eigh_wave(A, V, m, 0.0, !warm, Gc, Vc);
+    else jacobi_eigh_lds(A, V, m, rot, red, !warm);
     if (tid < m) {
         const double s = A[tid * m + tid];
         f[tid] = (tid < n && s > 1.0e-15) ? 1.0 / sqrt(s) : 0.0;
@@ -256,7 +397,8 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
 }
 
 static size_t jacobi_aux_bytes(int m) {
-    return sizeof(double) * (size_t)(2 * m + 8) + 32;
+    return sizeof(double) * (size_t)(2 * m + 8) + 32 +
+           (m <= kJwMax ? sizeof(double) * 2 * kJwMax * kJwPitch + 16 : 0);
 }
 
 template <typename K>
@@ -304,6 +446,9 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     double *red = rot + m;      // 8
     double *ev = red + 8;       // m
     int *order = reinterpret_cast<int *>(ev + m);                              // m
+    // 2 x kJwMax x kJwPitch doubles for the single-wave eigensolver (only carved for m <= kJwMax), 16-byte aligned
+    double *Gc = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(order + m) + 15) & ~(uintptr_t)15);
+    double *Vc = Gc + kJwMax * kJwPitch;
     const int tid = threadIdx.x;
     const int64_t P = (int64_t)T * (T + 1) / 2;
     const bool pairs = (a.layout == EVC_LAYOUT_PAIR5 || a.layout == EVC_LAYOUT_PACK2 || a.layout == EVC_LAYOUT_SYM8);
@@ -395,7 +540,22 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     __syncthreads();
     // warm start from the standard-form eigenvectors of the previous call (H is free as scratch here)
     const bool warm = a.warm && a.vstd && warm_start_rotate(Cm, V, H, T, m, a.vstd, m, red);
-    jacobi_eigh_lds(Cm, V, m, rot, red, !warm);
+    if (m <= kJwMax) {
+        // the standard-form matrix is indefinite: shift it by a Gershgorin bound (the eigenvectors do not change)
+        if (tid < m) {
+            double rs = 0.0;
+            for (int j = 0; j < m; ++j) rs += fabs(Cm[tid * m + j]);
+            ev[tid] = rs;
+        }
+        __syncthreads();
+        double shift = 0.0;
+        for (int j = 0; j < m; ++j) shift = fmax(shift, ev[j]);
+        shift = 1.0625 * shift + 1.0e-300;
+        __syncthreads();
+        jacobi_eigh_wave(Cm, V, m, shift, !warm, Gc, Vc);
+    } else {
+        jacobi_eigh_lds(Cm, V, m, rot, red, !warm);
+    }
     if (a.vstd)
         for (int idx = tid; idx < m * m; idx += kThreads) a.vstd[idx] = V[idx];
     // (5) ascending order
