@@ -160,13 +160,13 @@ __device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double
 
 // ------------------------------------------------------------------ one-sided Jacobi on ONE wave (m <= 32)
 // Hestenes' method on the columns of G = A V (V orthogonal, A symmetric positive definite): the plane rotation of a
-// column pair (p,q) that makes g_p . g_q = 0 is applied to the columns of G and of V; at convergence the columns of
-// G are orthogonal, g_j = lambda_j v_j.  Same round-robin pairing as above, but a step needs no workgroup barrier
-// and no hand-over of rotation parameters: the four lanes of a pair read their two columns (8 rows each, 16-byte
-// LDS loads), reduce the three dot products among themselves with DPP, compute (c,s) redundantly and write the
-// rotated columns back; LDS operations of one wave execute in order, so the next step sees them.  ~1/3 of the
-// two-sided step's latency.  Columns are stored [col][row] with pitch kJwPitch; rows >= m are zero.
-// Called by wave 0 only.  `worst` convergence: |g_p.g_q| <= 1e-15 |g_p||g_q| for every pair of a sweep.
+// column pair (p,q) that makes g_p . g_q = 0 is applied to the two columns; at convergence the columns of G are
+// orthogonal, g_j = lambda_j v_j.  Same round-robin pairing as above, but a step needs no workgroup barrier and no
+// hand-over of rotation parameters: the four lanes of a pair read their two columns (8 rows each, 16-byte LDS loads),
+// reduce the three dot products among themselves with DPP, compute (c,s) redundantly and write the rotated columns
+// back; LDS operations of one wave execute in order, so the next step sees them.  ~1/3 of the two-sided step's
+// latency.  Columns are stored [col][row] with pitch kJwPitch; rows >= m are zero.  Called by wave 0 only.
+// Convergence: |g_p.g_q| <= 1e-9 |g_p||g_q| for every pair BEFORE the rotations of a sweep.
 constexpr int kJwPitch = 34;
 constexpr int kJwMax = 32;
 
@@ -176,7 +176,7 @@ __device__ __forceinline__ double quad_sum(double v) {
     return v;
 }
 
-__device__ void jacobi_onesided_wave(double *Gc, double *Vc, int m) {
+__device__ void jacobi_onesided_wave(double *Gc, int m) {
     const int lane = threadIdx.x & 63;
     const int k = lane >> 2, sub = lane & 3;
     const int half = m >> 1;
@@ -188,14 +188,11 @@ __device__ void jacobi_onesided_wave(double *Gc, double *Vc, int m) {
             int p = 0, q = 1;
             if (active) pair_of(step, k, m, p, q);
             double *gp = Gc + p * kJwPitch + row0, *gq = Gc + q * kJwPitch + row0;
-            double *vp = Vc + p * kJwPitch + row0, *vq = Vc + q * kJwPitch + row0;
-            double2 xg[4], yg[4], xv[4], yv[4];
+            double2 xg[4], yg[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 xg[u] = *reinterpret_cast<const double2 *>(gp + 2 * u);
                 yg[u] = *reinterpret_cast<const double2 *>(gq + 2 * u);
-                xv[u] = *reinterpret_cast<const double2 *>(vp + 2 * u);
-                yv[u] = *reinterpret_cast<const double2 *>(vq + 2 * u);
             }
             double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
@@ -211,13 +208,12 @@ __device__ void jacobi_onesided_wave(double *Gc, double *Vc, int m) {
             const double ab = al * be, g2 = ga * ga;
             const bool rot = active && (g2 > 1.0e-30 * ab);
             bad = bad || (active && g2 > 1.0e-18 * ab);
-            double c = 1.0, s = 0.0;
             if (rot) {
                 // t = sgn(d) b / (|d| + sqrt(d^2 + b^2)), d = beta - alpha, b = 2 gamma (the smaller root)
+                // (the angle only has to make g_p . g_q small: one Newton step on the seeds; c is refined to full
+                // precision so that c^2 + s^2 = 1 to rounding and the columns keep their norms)
                 const double d = be - al, b = 2.0 * ga;
                 const double h2 = fma(d, d, b * b);
-                // (the angle only has to make g_p . g_q small: one Newton step on the seeds; c is refined to full
-                // precision so that c^2 + s^2 = 1 to rounding and V stays orthogonal)
                 double y = __builtin_amdgcn_rsq(h2);
                 y = y * fma(-0.5 * h2 * y, y, 1.5);
                 const double den = fabs(d) + h2 * y;
@@ -229,10 +225,7 @@ __device__ void jacobi_onesided_wave(double *Gc, double *Vc, int m) {
                 z = z * fma(-0.5 * x * z, z, 1.5);
                 z = z * fma(-0.5 * x * z, z, 1.5);
                 z = z * fma(-0.5 * x * z, z, 1.5);
-                c = z;
-                s = t * z;
-            }
-            if (active) {
+                const double c = z, s = t * z;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     double2 a, b2;
@@ -242,12 +235,6 @@ __device__ void jacobi_onesided_wave(double *Gc, double *Vc, int m) {
                     b2.y = s * xg[u].y + c * yg[u].y;
                     *reinterpret_cast<double2 *>(gp + 2 * u) = a;
                     *reinterpret_cast<double2 *>(gq + 2 * u) = b2;
-                    a.x = c * xv[u].x - s * yv[u].x;
-                    a.y = c * xv[u].y - s * yv[u].y;
-                    b2.x = s * xv[u].x + c * yv[u].x;
-                    b2.y = s * xv[u].y + c * yv[u].y;
-                    *reinterpret_cast<double2 *>(vp + 2 * u) = a;
-                    *reinterpret_cast<double2 *>(vq + 2 * u) = b2;
                 }
             }
         }
@@ -259,39 +246,42 @@ __device__ void jacobi_onesided_wave(double *Gc, double *Vc, int m) {
 
 // Eigen-decomposition of the symmetric m x m matrix A (LDS, both triangles) for m <= 32 through the wave kernel
 // above: on return diag(A) holds the eigenvalues and V (row-major, V[i*m+j]) the eigenvectors as columns.
-// shift: A + shift*I must be positive definite (0 for an overlap matrix).  init_v = false: V holds an orthogonal
-// start matrix and A the matrix in THAT basis (warm start), i.e. G0 = V (A + shift I).
-// Gc, Vc: 2 x kJwMax x kJwPitch doubles of LDS.
-__device__ void jacobi_eigh_wave(double *A, double *V, int m, double shift, bool init_v, double *Gc, double *Vc) {
+// shift: A + shift*I must be positive definite (0 for an overlap matrix): then the converged columns are
+// g_j = lambda_j v_j with lambda_j = |g_j| > 0, so V = G diag(1/|g_j|) and no eigenvector matrix has to be carried
+// through the rotations (its orthogonality is that of the columns of G, which is the convergence criterion).
+// init_v = false: V holds an orthogonal start matrix and A the matrix in THAT basis (warm start), G0 = V (A + shift I).
+// Gc: kJwMax x kJwPitch doubles of LDS.
+__device__ void jacobi_eigh_wave(double *A, double *V, int m, double shift, bool init_v, double *Gc, double *lam) {
     const int tid = threadIdx.x;
     for (int idx = tid; idx < kJwMax * kJwPitch; idx += kThreads) {
         const int j = idx / kJwPitch, i = idx - j * kJwPitch;
-        double g = 0.0, v = 0.0;
+        double g = 0.0;
         if (i < m && j < m) {
             if (init_v) {
-                v = (i == j) ? 1.0 : 0.0;
                 g = A[i * m + j] + ((i == j) ? shift : 0.0);
             } else {
-                v = V[i * m + j];
-                double acc = shift * v;
+                double acc = shift * V[i * m + j];
                 for (int kk = 0; kk < m; ++kk) acc = fma(V[i * m + kk], A[kk * m + j], acc);
                 g = acc;
             }
         }
         Gc[idx] = g;
-        Vc[idx] = v;
     }
     __syncthreads();
-    if (tid < 64) jacobi_onesided_wave(Gc, Vc, m);
+    if (tid < 64) jacobi_onesided_wave(Gc, m);
+    __syncthreads();
+    if (tid < m) {
+        double nn = 0.0;
+        for (int i = 0; i < m; ++i) nn = fma(Gc[tid * kJwPitch + i], Gc[tid * kJwPitch + i], nn);
+        lam[tid] = sqrt(nn);
+    }
     __syncthreads();
     for (int idx = tid; idx < m * m; idx += kThreads) {
         const int i = idx / m, j = idx - i * m;
-        V[idx] = Vc[j * kJwPitch + i];
-    }
-    if (tid < m) {
-        double lam = 0.0;
-        for (int i = 0; i < m; ++i) lam = fma(Vc[tid * kJwPitch + i], Gc[tid * kJwPitch + i], lam);
-        A[tid * m + tid] = lam - shift;
+        const double l = lam[j];
+        // a zero column (the decoupled dummy dimension of an odd problem) keeps its unit vector
+        V[idx] = l > 1.0e-300 ? Gc[j * kJwPitch + i] / l : (i == j ? 1.0 : 0.0);
+        if (i == j) A[idx] = l - shift;
     }
     __syncthreads();
 }
@@ -351,8 +341,7 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     double *rot = Xs + m * m;    // m
     double *red = rot + m;       // 8
     double *f = red + 8;         // m
-    double *Gc = f + m;          // 2 x kJwMax x kJwPitch (only carved for m <= kJwMax)
-    double *Vc = Gc + kJwMax * kJwPitch;
+    double *Gc = f + m;          // kJwMax x kJwPitch (only carved for m <= kJwMax)
     const int tid = threadIdx.x, tk = tid & 15, tj = tid >> 4;
     // LAPACK's eigh reads one triangle; numpy.linalg.eigh uses the lower one.
     for (int idx = tid; idx < m * m; idx += kThreads) A[idx] = 0.0;
@@ -368,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     __syncthreads();
     // warm start from the eigenvectors the previous call left in U (same workspace, nearby geometry)
     const bool warm = a.warm && warm_start_rotate(A, V, Xs, n, m, U, n, red);
-    if (m <= kJwMax) jacobi_eigh_wave(A, V, m, 0.0, !warm, Gc, Vc);
+    if (m <= kJwMax) jacobi_eigh_wave(A, V, m, 0.0, !warm, Gc, f);
     else jacobi_eigh_lds(A, V, m, rot, red, !warm);
     if (tid < m) {
         const double s = A[tid * m + tid];
@@ -398,7 +387,7 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
 
 static size_t jacobi_aux_bytes(int m) {
     return sizeof(double) * (size_t)(2 * m + 8) + 32 +
-           (m <= kJwMax ? sizeof(double) * 2 * kJwMax * kJwPitch + 16 : 0);
+           (m <= kJwMax ? sizeof(double) * kJwMax * kJwPitch + 16 : 0);
 }
 
 template <typename K>
@@ -446,9 +435,8 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     double *red = rot + m;      // 8
     double *ev = red + 8;       // m
     int *order = reinterpret_cast<int *>(ev + m);                              // m
-    // 2 x kJwMax x kJwPitch doubles for the single-wave eigensolver (only carved for m <= kJwMax), 16-byte aligned
+    // kJwMax x kJwPitch doubles for the single-wave eigensolver (only carved for m <= kJwMax), 16-byte aligned
     double *Gc = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(order + m) + 15) & ~(uintptr_t)15);
-    double *Vc = Gc + kJwMax * kJwPitch;
     const int tid = threadIdx.x;
     const int64_t P = (int64_t)T * (T + 1) / 2;
     const bool pairs = (a.layout == EVC_LAYOUT_PAIR5 || a.layout == EVC_LAYOUT_PACK2 || a.layout == EVC_LAYOUT_SYM8);
@@ -550,9 +538,9 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         __syncthreads();
         double shift = 0.0;
         for (int j = 0; j < m; ++j) shift = fmax(shift, ev[j]);
-        shift = 1.0625 * shift + 1.0e-300;
+        shift = 2.0 * shift + 1.0e-300;   // eigenvalues of the shifted matrix within [1, 3] x the bound
         __syncthreads();
-        jacobi_eigh_wave(Cm, V, m, shift, !warm, Gc, Vc);
+        jacobi_eigh_wave(Cm, V, m, shift, !warm, Gc, ev);
     } else {
         jacobi_eigh_lds(Cm, V, m, rot, red, !warm);
     }
