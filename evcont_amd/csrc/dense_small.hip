@@ -673,7 +673,30 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     double *fs = rs + n;       // n   f(s)
     double *ss = fs + n;       // n   s
     double *t2 = ss + n;       // 3*n
+    double *add = t2 + 3 * n;  // 3*natm: scale1 * (term3 + gnuc)
+    int *sl = reinterpret_cast<int *>(add + 3 * a.natm);   // 2*natm: AO slices
     const int tid = threadIdx.x;
+    // n <= 32: the 3 n^2 overlap derivatives are fetched into registers now and parked in the three product
+    // buffers once those are free, so that the per-atom loop at the end runs out of LDS (it is a chain of
+    // dependent global loads otherwise: ~2 us per (atom, x) and wave)
+    const bool stage_ip = n <= 32;
+    double ipf[12];
+    if (stage_ip) {
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int idx = tid + kThreads * u;
+            ipf[u] = idx < 3 * n * n ? a.ipovlp[idx] : 0.0;
+        }
+    }
+    for (int idx = tid; idx < 2 * a.natm; idx += kThreads) sl[idx] = (int)a.aoslices[idx];
+    for (int idx = tid; idx < 3 * a.natm; idx += kThreads) {
+        double g = 0.0;
+        if (a.scale1 != 0.0) {
+            g = a.scale1 * a.term3[idx];
+            if (a.gnuc) g += a.scale1 * a.gnuc[idx];
+        }
+        add[idx] = g;
+    }
     copy_to_lds(Us, a.U, n * n);
     for (int idx = tid; idx < n * n; idx += kThreads) {
         const int ai = idx / n, i = idx - ai * n;  // Y[a][i]; y2 is stored [i][a]
@@ -723,30 +746,38 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     __syncthreads();
     // grad[A,x] = - sum_{mu in A} sum_nu ip[x,mu,nu] (W[mu,nu] + W[nu,mu])
     //             - 1/2 sum_{m in A} t2[x][m] + scale1 * (term3 + gnuc)
+    if (stage_ip) {  // Y, Q, Us are free now: ip[x] -> {Y, Q, Us}[x]
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int idx = tid + kThreads * u;
+            if (idx < 3 * n * n) {
+                const int x = idx / (n * n);
+                (x == 0 ? Y : x == 1 ? Q : Us)[idx - x * n * n] = ipf[u];
+            }
+        }
+        __syncthreads();
+    }
     const int lane = tid & 63, wave = tid >> 6;
     for (int ax = wave; ax < a.natm * 3; ax += 4) {
         const int A = ax / 3, x = ax - 3 * A;
-        const int p0 = (int)a.aoslices[2 * A], p1 = (int)a.aoslices[2 * A + 1];
+        const int p0 = sl[2 * A], p1 = sl[2 * A + 1];
+        const double *ipx = x == 0 ? Y : x == 1 ? Q : Us;
         double s = 0.0;
         for (int mu = p0; mu < p1; ++mu)
-            for (int nu = lane; nu < n; nu += 64)
-                s = fma(a.ipovlp[(x * n + mu) * n + nu], W[mu * n + nu] + W[nu * n + mu], s);
+            for (int nu = lane; nu < n; nu += 64) {
+                const double ip = stage_ip ? ipx[mu * n + nu] : a.ipovlp[(x * n + mu) * n + nu];
+                s = fma(ip, W[mu * n + nu] + W[nu * n + mu], s);
+            }
         s = -s;
         for (int m_ = p0 + lane; m_ < p1; m_ += 64) s -= 0.5 * t2[x * n + m_];
         s = wave_sum(s);
-        if (lane == 0) {
-            double g = s;
-            if (a.scale1 != 0.0) {
-                g += a.scale1 * a.term3[ax];
-                if (a.gnuc) g += a.scale1 * a.gnuc[ax];
-            }
-            a.grad[ax] = g;
-        }
+        if (lane == 0) a.grad[ax] = s + add[ax];
     }
 }
 
 int launch_grad_final(const GradFinalArgs &a, int count, hipStream_t st) {
-    const size_t lds = sizeof(double) * ((size_t)4 * a.n * a.n + 6 * a.n);
+    const size_t lds = sizeof(double) * ((size_t)4 * a.n * a.n + 6 * a.n + 3 * (size_t)a.natm) +
+                       sizeof(int) * 2 * (size_t)a.natm + 16;
     static bool attr_set = false;
     allow_big_lds(grad_final_kernel, attr_set);
     hipLaunchKernelGGL(grad_final_kernel, dim3(count), dim3(kThreads), lds, st, a);
