@@ -58,7 +58,7 @@ def test_batch_golden(load_golden):
     assert abs(E[1] - E[3]) < 1e-13 and abs(E[0] - E[1]) > 1e-6
 
 
-@pytest.mark.parametrize("lname", ["pack2", "full6"])
+@pytest.mark.parametrize("lname", ["pack2", "full6", "sym8"])
 @pytest.mark.parametrize("world,G", [(2, 3), (3, 16)])
 def test_batched_phase_api_emulated_pair_sharding(lname, world, G):
     """Batched three-phase entry points on row slices (one BatchedEvaluator per emulated rank); the two
@@ -69,16 +69,20 @@ def test_batched_phase_api_emulated_pair_sharding(lname, world, G):
     dev = torch.device("cuda:0")
     n, T, A = 6, 4, 3
     S, one, two = make_trdms(n, T, 77)
-    two_l = layout(two, lname)
+    # "sym8": the 8-fold compressed device layout built from (shards of) the pack2 rows; integrals with the
+    # symmetries of real ones, as that layout requires
+    comp = "sym8" if lname == "sym8" else None
+    two_l = layout(two, "pack2" if comp else lname)
     rows, _ = layout_shape(two_l.ndim, T, n)
-    aob = DeviceAOBatch.stack([DeviceAO.from_arrays(make_ao_arrays(n, A, 900 + k), dev) for k in range(G)])
-    full = BatchedEvaluator(DeviceTRDMs(one, two_l, S, dev), A, G)
+    aob = DeviceAOBatch.stack([DeviceAO.from_arrays(make_ao_arrays(n, A, 900 + k, ip1_rs_symmetric=bool(comp)), dev)
+                               for k in range(G)])
+    full = BatchedEvaluator(DeviceTRDMs(one, two_l, S, dev, compress=comp), A, G)
     Eref, gref = full.energies_with_grads(aob)
     chunk = -(-rows // world)
     evs, send = [], []
     for r in range(world):
         r0, r1 = shard_rows(rows, world, r)
-        evs.append(BatchedEvaluator(DeviceTRDMs(one, two_l, S, dev, row_range=(r0, r1)), A, G))
+        evs.append(BatchedEvaluator(DeviceTRDMs(one, two_l, S, dev, row_range=(r0, r1), compress=comp), A, G))
         buf = torch.zeros((G, chunk), dtype=torch.float64, device=dev)
         evs[-1].phase_hamiltonian(aob, buf)
         send.append(buf)
