@@ -132,8 +132,12 @@ int launch_quarter_transform(const double *in, int64_t sin, const double *C, int
 // One wave per matrix: the D tiles of H = M X sit in exactly the lanes/registers the B operand of
 // X^T H needs (row 4*kk + (l>>4) of H lives in register kk%4 of row-tile kk/4), so the second product
 // consumes the accumulators of the first without any data movement; the X fragments serve as B
-// operand of the first and A operand of the second product.  A workgroup owns 8 consecutive q
-// (2 matrices per wave) and stages N in LDS so that the output leaves as 64-byte runs over q.
+// operand of the first and A operand of the second product.  A workgroup works through tiles of 8
+// leading pairs (2 matrices per wave) and stages N in LDS so that the output leaves as 64-byte runs.
+// Symmetric operands (the compressed layout's pipeline) are exploited through three
+// independent flags: lead_sym (in[p][q] = in[q][p]: only the n(n+1)/2 pairs q <= p are computed), in_lower
+// (M = M^T: only its lower triangle is read) and rs_lower (only N[r'][s'], s' <= r', is wanted: 3 of 4
+// result tiles, half the stage, half the output rows / the 8-fold compressed packed vector).
 template <int NPAD>
 __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     constexpr int LDX = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;
