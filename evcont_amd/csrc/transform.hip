@@ -591,8 +591,48 @@ __global__ __launch_bounds__(256) void unpack8_kernel(const double *__restrict__
     }
 }
 
+// The same for lead_half without G: only the quarter i >= j, l <= k of SB is written.  One WAVE per pair (i,j),
+// its lanes run over v = tri(k,l) (the order of the compressed vector: the gather p8[tri(u,v)] is contiguous for
+// v <= u); 4 pairs per workgroup instead of one workgroup per (i,j) with half of them idle.
+__global__ __launch_bounds__(256) void unpack8_half_kernel(const double *__restrict__ p, int64_t sp, int n,
+                                                           double *__restrict__ SB, int64_t sws, int count) {
+    const int64_t n2 = (int64_t)n * n;
+    const int npairs = n * (n + 1) / 2;
+    const int bpg = (npairs + 3) / 4;   // workgroups per geometry
+    const int nx = count & ~7;
+    const int64_t nxblocks = (int64_t)nx * bpg;
+    int geom, blk;
+    if ((int64_t)blockIdx.x < nxblocks) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        geom = (slot / bpg) * 8 + xcd;
+        blk = slot % bpg;
+    } else {
+        const int64_t b = (int64_t)blockIdx.x - nxblocks;
+        geom = nx + (int)(b / bpg);
+        blk = (int)(b % bpg);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = blk * 4 + wave;
+    if (u >= npairs) return;
+    const int i = (int)tri_row(u), j = u - i * (i + 1) / 2;
+    p += (int64_t)geom * sp;
+    double *sb = SB + (int64_t)geom * sws + ((int64_t)i * n + j) * n2;
+    for (int v = lane; v < npairs; v += 64) {
+        const int k = (int)tri_row(v), l = v - k * (k + 1) / 2;
+        const double val = u >= v ? p[tri_index(u, v)] : p[tri_index(v, u)];
+        sb[k * n + l] = 4.0 * val;
+    }
+}
+
 int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t sws, double *G, int64_t sG, int count,
                    int lead_half, hipStream_t st) {
+    if (lead_half && !G) {
+        const int bpg = (n * (n + 1) / 2 + 3) / 4;
+        hipLaunchKernelGGL(unpack8_half_kernel, dim3((unsigned)(bpg * count)), dim3(256), 0, st, packed, sp, n, SB, sws,
+                           count);
+        EVC_LAUNCH_CHECK("unpack8_half");
+        return 0;
+    }
     hipLaunchKernelGGL(unpack8_kernel, dim3((unsigned)(n * n * count)), dim3(256), 0, st, packed, sp, n, SB, sws, G, sG,
                        count, lead_half);
     EVC_LAUNCH_CHECK("unpack8");
