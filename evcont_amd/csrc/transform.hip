@@ -642,7 +642,15 @@ int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t 
 // ------------------------------------------------------------------ Y2 contraction (split-K MFMA GEMM)
 // partial[slab][i][a] = sum_{k in slab} GsT[k][i] * K3[k][a],  k = (j,k,l) flattened, n^3 long.
 // Both operands are [k][n] row-major, so each MFMA fragment load is 16 contiguous doubles.
-constexpr int kY2Slabs = 128;
+// number of K slabs = partial results per geometry (fixed for the life of the process: it sizes the workspace)
+static int y2_slab_count() {
+    static const int v = [] {
+        const int e = getenv("EVC_Y2_SLABS") ? atoi(getenv("EVC_Y2_SLABS")) : 64;
+        return (e >= 8 && e <= 512) ? e : 64;
+    }();
+    return v;
+}
+#define kY2Slabs y2_slab_count()
 int y2_slabs(int) { return kY2Slabs; }
 
 template <int NT>
