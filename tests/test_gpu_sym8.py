@@ -57,7 +57,10 @@ def test_layout_shape_and_column_order():
 @pytest.mark.parametrize("n,T,A,lname", [
     (4, 2, 2, "full6"), (6, 3, 3, "pair5"), (7, 4, 2, "elec3"), (10, 5, 10, "pack2"),
     (17, 4, 3, "pack2"),       # pair transform <32>, ragged q tile
+    (16, 3, 2, "pack2"),       # exactly one MFMA tile
     (30, 3, 5, "pack2"),       # N of the headline workload
+    (31, 2, 3, "pack2"),       # odd N just below the pair-transform limit (dummy dimension in the eigensolver)
+    (32, 2, 4, "pack2"),       # the pair-transform limit, no padding
     (34, 2, 2, "pack2"),       # N > 32: quarter steps + pack_sym8 kernel
 ])
 def test_sym8_matches_reference_layouts(n, T, A, lname):
