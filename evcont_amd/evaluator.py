@@ -61,6 +61,27 @@ def infer_layout(two_RDM, T: int, n: int) -> int:
     return nd
 
 
+def sym8_column_images(layout: int, n: int):
+    """For every column ``u(u+1)/2+v`` of the 8-fold compressed layout (``u = i(i+1)/2+j``, ``i >= j``, ``v`` likewise
+    from ``k >= l``, ``u >= v``) the columns of a SOURCE layout (ndim 6/5: ``N^4`` unpacked, 3/2: lower triangle of the
+    ``(N^2,N^2)`` matrix) that hold the eight images of ``(i,j,k,l)`` under the index permutations of real
+    two-electron integrals: a list of eight int64 arrays.  The compressed entry is the mean over them."""
+    iu, ju = np.tril_indices(n)
+    U, V = np.tril_indices(len(iu))
+    i, j, k, l = iu[U], ju[U], iu[V], ju[V]
+    if layout in (3, 2):
+        def col(a_, b_, c_, d_):
+            R, Cc = a_ * n + b_, c_ * n + d_
+            hi, lo = np.maximum(R, Cc).astype(np.int64), np.minimum(R, Cc).astype(np.int64)
+            return hi * (hi + 1) // 2 + lo
+    else:
+        def col(a_, b_, c_, d_):
+            return ((a_.astype(np.int64) * n + b_) * n + c_) * n + d_
+    images = [(i, j, k, l), (j, i, k, l), (i, j, l, k), (j, i, l, k),
+              (k, l, i, j), (l, k, i, j), (k, l, j, i), (l, k, j, i)]
+    return [np.ascontiguousarray(col(*im)) for im in images]
+
+
 def _upload_rows(src: np.ndarray, rows: int, cols: int, r0: int, r1: int, device) -> Tuple[torch.Tensor, int]:
     """Copy rows [r0,r1) of the (rows, cols) view of `src` into a zero-padded (r1-r0, ld) device matrix."""
     ld = (cols + 15) // 16 * 16
@@ -151,22 +172,7 @@ class DeviceTRDMs:
         else:
             src = torch.arange(self.rows_local, dtype=torch.int64, device=d)
             r0 = self.row_offset
-        iu, ju = np.tril_indices(n)
-        ms = len(iu)
-        U, V = np.tril_indices(ms)
-        i, j, k, l = iu[U], ju[U], iu[V], ju[V]
-        n2 = n * n
-        if self.layout in (3, 2):
-            def col(a_, b_, c_, d_):
-                R, Cc = a_ * n + b_, c_ * n + d_
-                hi, lo = np.maximum(R, Cc).astype(np.int64), np.minimum(R, Cc).astype(np.int64)
-                return hi * (hi + 1) // 2 + lo
-        else:
-            def col(a_, b_, c_, d_):
-                return ((a_.astype(np.int64) * n + b_) * n + c_) * n + d_
-        images = [(i, j, k, l), (j, i, k, l), (i, j, l, k), (j, i, l, k),
-                  (k, l, i, j), (l, k, i, j), (k, l, j, i), (l, k, j, i)]
-        idx = [torch.from_numpy(np.ascontiguousarray(col(*im))).to(d) for im in images]
+        idx = [torch.from_numpy(ix).to(d) for ix in sym8_column_images(self.layout, n)]
         rows8, cols8 = layout_shape(_lib.LAYOUT_SYM8, T, n)
         ld8 = (cols8 + 15) // 16 * 16
         nloc = int(src.numel())

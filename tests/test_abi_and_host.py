@@ -174,3 +174,27 @@ def test_sym8_layout_shape_and_compression_switch():
             aec.set_trdm_compression("other")
     finally:
         aec.set_trdm_compression(old)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_sym8_column_images_reproduce_the_symmetrised_tensor(n):
+    """Host half of DeviceTRDMs.compress_sym8_: the eight gather columns per compressed entry, for the unpacked and
+    the electron-pair-packed source layouts, against a brute-force 8-fold symmetrisation."""
+    from evcont_amd.evaluator import sym8_column_images, layout_shape
+    from evcont_amd.synthetic import make_trdms, pack_rows
+    T = 2
+    _, _, two = make_trdms(n, T, 7 + n)            # (T,T,n,n,n,n), pair symmetric but not 8-fold
+    g = two[1, 0]
+    a = g + g.transpose(1, 0, 2, 3)
+    a = a + a.transpose(0, 1, 3, 2)
+    gs = (a + a.transpose(2, 3, 0, 1)) / 8.0
+    iu, ju = np.tril_indices(n)
+    U, V = np.tril_indices(len(iu))
+    want = gs[iu[U], ju[U], iu[V], ju[V]]
+    assert want.shape[0] == layout_shape(8, T, n)[1]
+    full_row = g.reshape(-1)
+    got6 = sum(full_row[ix] for ix in sym8_column_images(6, n)) / 8.0
+    np.testing.assert_allclose(got6, want, rtol=0, atol=1e-15)
+    packed_row = pack_rows(two, True, True)[1]      # pairs in np.tril_indices order: (0,0), (1,0), (1,1)
+    got2 = sum(packed_row[ix] for ix in sym8_column_images(2, n)) / 8.0
+    np.testing.assert_allclose(got2, want, rtol=0, atol=1e-15)
