@@ -58,6 +58,7 @@ WORKLOADS = {
 LAYOUT_ND = {"full6": 6, "pair5": 5, "elec3": 3, "pack2": 2,
              "sym8": 8}   # sym8: 8-fold compressed device layout, built from the pack2 rows (include/evcont_hip.h)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (~6 TB/s achievable by a plain streaming read)
+MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense FP64 matrix peak (v_mfma_f64_16x16x4_f64)
 MAX_G_PER_LAUNCH = 32   # geometries that share one pass over the t-RDM (csrc/gemv_mfma.hip)
 
 
@@ -205,6 +206,12 @@ def main():
         rows_n, cols_n = C.c_int(), C.c_int()
         _lib.check(lib.evc_profile_end(C.byref(rows_ms), C.byref(rows_n), C.byref(cols_ms), C.byref(cols_n)),
                    "evc_profile_end")
+        stages = {}   # mean duration per launch of every instrumented stage (HIP events on the launch stream)
+        for name, sid in _lib.PROF_STAGES.items():
+            ms_, n_ = C.c_double(), C.c_int()
+            _lib.check(lib.evc_profile_stage(sid, C.byref(ms_), C.byref(n_)), "evc_profile_stage")
+            if n_.value:
+                stages[name + "_ms"] = ms_.value / n_.value
         e_last = float(evs[0].energy.reshape(-1)[0].item())
         assert np.isfinite(e_last), "non-finite energy in the timed region"
         # one more, untimed evaluation of the FIRST input: a number that can be compared between legs
@@ -228,6 +235,7 @@ def main():
                 "k5_ms": k5, "k8_ms": k8, "bytes_per_launch": nbytes, "launches": rows_n.value * lps,
                 "geometries_per_launch": gl, "k5_GBs": nbytes / (k5 * 1e-3) / 1e9,
                 "k8_GBs": (nbytes / (k8 * 1e-3) / 1e9) if k8 else None, "last_energy": e_last, "check_energy": e_check,
+                "stages": stages,
                 "geometries_per_step": job_g}
 
     G, S = max(1, a.batch), max(1, a.streams)
@@ -324,6 +332,28 @@ def main():
             r.update(achieved=one["k5_GBs"], frac=one["k5_GBs"] / HBM_PEAK_GBS, ms_per_launch=one["k5_ms"],
                      launches=one["launches"],
                      region="single_stream leg (HIP events on the launch stream, same batches, one stream)")
+            # the other multi-workgroup stages of the same leg, against their own rooflines
+            st = one["stages"]
+            out["single_stream"]["stages_ms_per_launch"] = st
+            others = []
+            if "pair_transform_ms" in st and n <= 32:
+                pairs = n * (n + 1) // 2 if a.layout == "sym8" else n * n
+                flops = G * pairs * 4.0 * n ** 3          # two N x N x N products per leading pair, unpadded
+                tf = flops / (st["pair_transform_ms"] * 1e-3) / 1e12
+                others.append({"kernel": "pt_kernel: one fused pair step of a four-index rotation (4 launches per "
+                                         "evaluation, the largest share of the step)", "bound": "mfma",
+                               "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / MFMA_F64_PEAK_TFLOPS, "flops_per_launch": flops,
+                               "ms_per_launch": st["pair_transform_ms"]})
+            if "ip1_ms" in st and not a.energy_only:
+                # bytes the kernel has to read: int2e_ip1 and the AO-basis 2-RDM, lower triangles only with sym8
+                tri = (n + 1) / (2.0 * n) if a.layout == "sym8" else 1.0
+                nb = G * (3 * n ** 4 * tri + n ** 4 * tri * (tri if a.layout == "sym8" else 1.0)) * 8.0
+                gbs = nb / (st["ip1_ms"] * 1e-3) / 1e9
+                others.append({"kernel": "ip1_dh_kernel: int2e_ip1 : 2-RDM(AO) contraction", "bound": "hbm",
+                               "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "bytes_per_launch": nb, "ms_per_launch": st["ip1_ms"]})
+            out["roofline_other_kernels"] = others
     if world == 1 and not a.no_md_regime and (G, S) != (1, 1):
         md = measure(trd, aos, 1, 1, max(20, min(a.steps * 2, 200)), 10, False)
         if rank == 0:

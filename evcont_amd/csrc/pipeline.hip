@@ -24,12 +24,29 @@ void set_error(const char *fmt, ...) {
 // Optional in-stream timing of the two streaming kernels (bench.py's roofline leg): hipEvents are
 // recorded on the launch stream right before/after the kernel, so the figure is the kernel's own
 // duration inside the real per-geometry DAG.  Process-wide, off by default.
+// Stages: EVC_PROF_* of include/evcont_hip.h.
+constexpr int kProfStages = 8;
+constexpr int kProfPerSample = 16;   // event pairs one evaluation can record
 struct Prof {
     bool on = false;
-    int cap = 0, n_rows = 0, n_cols = 0;
-    hipEvent_t *ev = nullptr;  // [cap][4]: rows start/stop, cols start/stop
+    int cap = 0, n = 0;          // records: capacity, used
+    hipEvent_t *ev = nullptr;    // [cap][2]: start, stop
+    int *stage = nullptr;        // [cap]
+    double ms[kProfStages] = {0};   // results of the last evc_profile_end
+    int cnt[kProfStages] = {0};
 };
 static Prof g_prof;
+// start of a timed launch: returns the record index or -1
+static int prof_start(int stage, hipStream_t st) {
+    if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
+    const int i = g_prof.n++;
+    g_prof.stage[i] = stage;
+    (void)hipEventRecord(g_prof.ev[2 * i], st);
+    return i;
+}
+static void prof_stop(int i, hipStream_t st) {
+    if (i >= 0) (void)hipEventRecord(g_prof.ev[2 * i + 1], st);
+}
 
 // Internal batch view of the geometry inputs / outputs (strides in doubles; 0 for a single geometry).
 struct Geo {
@@ -215,7 +232,11 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
     la.sws = sw;
     la.n = n;
     la.warm = w.warm ? 1 : 0;
-    if ((rc = launch_loewdin(la, cnt, st))) return rc;
+    {
+        const int pr = prof_start(EVC_PROF_LOEWDIN, st);
+        if ((rc = launch_loewdin(la, cnt, st))) return rc;
+        prof_stop(pr, st);
+    }
     // (ab|cd) -> K3[jkl][a] -> h2[ijkl]
     const double *v2;
     if (use_pair_transform(n)) {
@@ -241,7 +262,9 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
             // produces the q <= p half of its output and the second one reads the lower triangles
             // (in_lower: eri[p,q,r,s] = eri[p,q,s,r]; rs_lower: the next step's leading pairs are (r',s'), s' <= r')
             pa.lead_sym = pa.in_lower = pa.rs_lower = is_sym8(t->layout) ? 1 : 0;
+            int pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
             if ((rc = launch_pair_transform(pa, cc, st))) return rc;
+            prof_stop(pr, st);
             // ... and the second step again only needs the q <= p half of ITS leading pair
             pa.in = w.B1 + o;
             pa.sin = sw;
@@ -257,7 +280,9 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
             } else {
                 pa.out = w.B2 + o;
             }
+            pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
             if ((rc = launch_pair_transform(pa, cc, st))) return rc;
+            prof_stop(pr, st);
         }
     } else {
         if ((rc = launch_quarter_transform(g.eri, g.seri, w.X, sw, 0, n, w.B1, sw, cnt, st))) return rc;
@@ -282,10 +307,9 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
     p1.v = w.h1;
     p1.partial = w.h1part;
     p1.vstride = p1.pstride = sw;
-    const bool prof = g_prof.on && g_prof.n_rows < g_prof.cap;
-    if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_rows + 0], st);
+    const int pr = prof_start(EVC_PROF_ROWS, st);
     if ((rc = launch_gemv_rows(p2, p1, cnt, st))) return rc;
-    if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_rows++ + 1], st);
+    prof_stop(pr, st);
     if ((reduce_rows || reduce_in_own_launch(w)) && t->rows2 > 0) {
         const double alpha2 = is_packed(t->layout) ? 1.0 : 0.5;
         hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)ceil_div(t->rows2, 16), (unsigned)cnt), dim3(256), 0,
@@ -350,7 +374,10 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
     a.w2_count = t->rows2;
     a.vstd = w.vstd;
     a.warm = w.warm ? 1 : 0;
-    return launch_subspace_solve(a, g.count, st);
+    const int pr = prof_start(EVC_PROF_SUBSPACE, st);
+    const int rc = launch_subspace_solve(a, g.count, st);
+    prof_stop(pr, st);
+    return rc;
 }
 
 // Gradient of the energy functional defined by (D, G) [G unpacked, N^4] given X,U,s,K3 in the
@@ -436,18 +463,24 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
             for (int c0 = 0; c0 < cnt; c0 += chunk) {
                 const int cc = cnt - c0 < chunk ? cnt - c0 : chunk;
                 const int64_t o = (int64_t)c0 * sw;
+                int pr = prof_start(EVC_PROF_UNPACK, st);
                 if (sym8) {
                     // (K3 was written for l <= k only by the symmetric second step of phase A)
                     if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, w.B1 + o, sw,
                                              G ? G + (int64_t)c0 * sG : nullptr, sG, cc, 1, st)))
                         return rc;
+                    prof_stop(pr, st);
+                    pr = prof_start(EVC_PROF_Y2, st);
                     if ((rc = launch_y2_fold(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, st))) return rc;
                 } else {
                     if ((rc = launch_unpack_sym(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, w.B1 + o, sw,
                                                 G ? G + (int64_t)c0 * sG : nullptr, sG, cc, st)))
                         return rc;
+                    prof_stop(pr, st);
+                    pr = prof_start(EVC_PROF_Y2, st);
                     if ((rc = launch_y2(w.B2 + o, w.K3 + o, n, w.y2part + o, sw, cc, st))) return rc;
                 }
+                prof_stop(pr, st);
                 PairTransformArgs pa;
                 memset(&pa, 0, sizeof(pa));
                 pa.C = w.X + o;
@@ -459,13 +492,19 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.out = w.B2 + o;
                 pa.sout = sw;
                 pa.lead_sym = pa.in_lower = pa.rs_lower = sym8;   // SB is fully symmetric
+                pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
+                prof_stop(pr, st);
                 // (the second step keeps rs_lower as well: G^AO[m,b,c,d] = G^AO[b,m,c,d], fold_cd reads b <= m)
                 // the result is only valid for d <= c of G^AO[m,b,c,d] (fold_cd below)
                 pa.in = w.B2 + o;
                 pa.out = w.B1 + o;
+                pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
+                prof_stop(pr, st);
+                pr = prof_start(EVC_PROF_IP1, st);
                 if ((rc = ip1_stage(w.B1, c0, cc))) return rc;
+                prof_stop(pr, st);
             }
             ip1_done = true;
         } else {
@@ -543,10 +582,9 @@ static int phase_gradient(const evc_trdm_set *t, const Geo &g, const Out &out, i
     c1.ld = t->ld1;
     c1.out = D;
     c1.ostride = sD;
-    const bool prof = g_prof.on && g_prof.n_cols < g_prof.cap;
-    if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_cols + 2], st);
+    const int pr = prof_start(EVC_PROF_COLS, st);
     if ((rc = launch_gemv_cols(c2, c1, cnt, st))) return rc;
-    if (prof) (void)hipEventRecord(g_prof.ev[4 * g_prof.n_cols++ + 3], st);
+    prof_stop(pr, st);
     const bool partial = (flags & EVC_FLAG_PARTIAL_RANK) != 0;
     if (is_packed(t->layout))
         // the unpacked 2-RDM is only materialised when the caller asked for it
@@ -607,43 +645,56 @@ extern "C" const char *evc_last_error(void) { return g_err; }
 
 extern "C" int evc_profile_begin(int max_samples) {
     EVC_REQUIRE(!g_prof.on, "evc_profile_begin: already profiling");
-    EVC_REQUIRE(max_samples > 0 && max_samples <= 1 << 20, "evc_profile_begin: max_samples=%d", max_samples);
-    g_prof.ev = new hipEvent_t[4 * (size_t)max_samples];
-    for (int i = 0; i < 4 * max_samples; ++i) {
+    EVC_REQUIRE(max_samples > 0 && max_samples <= 1 << 16, "evc_profile_begin: max_samples=%d", max_samples);
+    const int cap = max_samples * kProfPerSample;
+    g_prof.ev = new hipEvent_t[2 * (size_t)cap];
+    g_prof.stage = new int[cap];
+    for (int i = 0; i < 2 * cap; ++i) {
         hipError_t e = hipEventCreate(&g_prof.ev[i]);
         if (e != hipSuccess) {
             set_error("evc_profile_begin: hipEventCreate: %s", hipGetErrorString(e));
             return (int)e;
         }
     }
-    g_prof.cap = max_samples;
-    g_prof.n_rows = g_prof.n_cols = 0;
+    g_prof.cap = cap;
+    g_prof.n = 0;
     g_prof.on = true;
     return 0;
 }
 
 extern "C" int evc_profile_end(double *rows_ms, int *rows_n, double *cols_ms, int *cols_n) {
     EVC_REQUIRE(g_prof.on, "evc_profile_end: not profiling");
-    double tr = 0.0, tc = 0.0;
-    for (int i = 0; i < g_prof.n_rows; ++i) {
-        float ms = 0.f;
-        (void)hipEventSynchronize(g_prof.ev[4 * i + 1]);
-        (void)hipEventElapsedTime(&ms, g_prof.ev[4 * i + 0], g_prof.ev[4 * i + 1]);
-        tr += ms;
+    for (int k = 0; k < kProfStages; ++k) {
+        g_prof.ms[k] = 0.0;
+        g_prof.cnt[k] = 0;
     }
-    for (int i = 0; i < g_prof.n_cols; ++i) {
+    for (int i = 0; i < g_prof.n; ++i) {
         float ms = 0.f;
-        (void)hipEventSynchronize(g_prof.ev[4 * i + 3]);
-        (void)hipEventElapsedTime(&ms, g_prof.ev[4 * i + 2], g_prof.ev[4 * i + 3]);
-        tc += ms;
+        (void)hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        (void)hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        const int k = g_prof.stage[i];
+        g_prof.ms[k] += ms;
+        g_prof.cnt[k] += 1;
     }
-    if (rows_ms) *rows_ms = tr;
-    if (rows_n) *rows_n = g_prof.n_rows;
-    if (cols_ms) *cols_ms = tc;
-    if (cols_n) *cols_n = g_prof.n_cols;
-    for (int i = 0; i < 4 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    if (rows_ms) *rows_ms = g_prof.ms[EVC_PROF_ROWS];
+    if (rows_n) *rows_n = g_prof.cnt[EVC_PROF_ROWS];
+    if (cols_ms) *cols_ms = g_prof.ms[EVC_PROF_COLS];
+    if (cols_n) *cols_n = g_prof.cnt[EVC_PROF_COLS];
+    for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
     delete[] g_prof.ev;
-    g_prof = Prof();
+    delete[] g_prof.stage;
+    g_prof.ev = nullptr;
+    g_prof.stage = nullptr;
+    g_prof.cap = g_prof.n = 0;
+    g_prof.on = false;
+    return 0;
+}
+
+extern "C" int evc_profile_stage(int stage, double *ms, int *launches) {
+    EVC_REQUIRE(stage >= 0 && stage < kProfStages, "evc_profile_stage: stage=%d", stage);
+    EVC_REQUIRE(!g_prof.on, "evc_profile_stage: call evc_profile_end first");
+    if (ms) *ms = g_prof.ms[stage];
+    if (launches) *launches = g_prof.cnt[stage];
     return 0;
 }
 

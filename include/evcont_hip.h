@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 3 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
-                             3: EVC_LAYOUT_SYM8 */
+#define EVC_ABI_VERSION 4 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
+                             3: EVC_LAYOUT_SYM8; 4: evc_profile_stage */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
@@ -297,12 +297,23 @@ int evc_contract_nnA3(const double *T, const double *M, int transposed, int n, i
 
 /* ---------------------------------------------------------------------------------
  * Measurement hook (bench.py): while enabled, the fused pipeline records hipEvents on the launch
- * stream immediately before and after the K5 (rows GEMV) and K8 (cols GEMV) launches of up to
- * max_samples evaluations.  evc_profile_end synchronises those events, returns the summed
- * durations in milliseconds with the number of launches, and frees them.  Process-wide state.
+ * stream immediately before and after the launches of the stages below, for up to max_samples
+ * evaluations.  evc_profile_end synchronises those events, returns the summed durations in
+ * milliseconds with the number of launches for K5 (rows GEMV) and K8 (cols GEMV), and frees them;
+ * afterwards evc_profile_stage reports the same two numbers for any stage of that session.
+ * Process-wide state.
  * --------------------------------------------------------------------------------- */
+#define EVC_PROF_ROWS 0           /* K5  H2 = Gamma . h2 (+ one-body) */
+#define EVC_PROF_COLS 1           /* K8  predicted RDMs */
+#define EVC_PROF_PAIR_TRANSFORM 2 /* fused pair steps of the two four-index rotations (4 launches per call) */
+#define EVC_PROF_IP1 3            /* int2e_ip1 contraction (+ dhcore dots, Y2 slab sums) */
+#define EVC_PROF_Y2 4             /* Y2 = K3 . Gamma_sym */
+#define EVC_PROF_UNPACK 5         /* unpack/symmetrise the predicted 2-RDM */
+#define EVC_PROF_LOEWDIN 6        /* Loewdin orthogonalisation */
+#define EVC_PROF_SUBSPACE 7       /* subspace generalised eigenproblem */
 int evc_profile_begin(int max_samples);
 int evc_profile_end(double *rows_ms, int *rows_n, double *cols_ms, int *cols_n);
+int evc_profile_stage(int stage, double *ms, int *launches);
 
 #ifdef __cplusplus
 }
