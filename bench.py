@@ -79,6 +79,9 @@ def parse():
     p.add_argument("--shard", default="geometries", choices=["geometries", "pairs"],
                    help="what is distributed over the ranks when --gpus N > 1")
     p.add_argument("--no-second-mode", action="store_true", help="N > 1: skip the leg for the other --shard mode")
+    p.add_argument("--ip1", default="packed", choices=["packed", "full"],
+                   help="int2e_ip1 input of the sym8 legs: packed in its last two AO indices (PySCF aosym='s2kl', "
+                        "EVC_FLAG_IP1_S2KL) or the full (3,N,N,N,N) array; other layouts always take the full array")
     return p.parse_args()
 
 
@@ -178,8 +181,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def measure(trd, aos, G, nslots, steps, warmup, sharded_pairs):
-        """Time `steps` passes over batches of G geometries with `nslots` batches in flight on this rank."""
+    def measure(trd, aos, G, nslots, steps, warmup, sharded_pairs, all_stages=False):
+        """Time `steps` passes over batches of G geometries with `nslots` batches in flight on this rank.
+        all_stages: time every instrumented stage (two event records per launch), not only K5 and K8."""
         mk_stream = lambda: (torch.cuda.Stream(dev) if nslots > 1 else None)
         if G > 1:
             nb = max(1, len(aos) // G)
@@ -196,6 +200,7 @@ def main():
         for k in range(warmup):
             step(k)
         fence()
+        _lib.check(lib.evc_profile_select(0xFF if all_stages else 0x3), "evc_profile_select")
         _lib.check(lib.evc_profile_begin(steps), "evc_profile_begin")
         t0 = time.perf_counter()
         for k in range(steps):
@@ -244,7 +249,12 @@ def main():
     # geometry sharding: every rank draws its own geometries; pair sharding: all ranks see the same ones
     trd = trdms(my_range if pairs_first else full_range)
     aos = geometries(seed * 1000 + (0 if pairs_first else rank * a.geoms))
-    m = measure(trd, aos, G, 1 if pairs_first else S, a.steps, a.warmup, pairs_first)
+    # what the sym8 legs are fed: the same integrals with int2e_ip1 packed in (r,s), gathered on the device here,
+    # outside every timed region -- the form PySCF delivers with aosym="s2kl"
+    packed_ip1 = a.layout == "sym8" and a.ip1 == "packed" and n <= 32 and not a.energy_only
+    run_view = (lambda lst: [x.packed_ip1() for x in lst]) if packed_ip1 else (lambda lst: lst)
+    aos_run = run_view(aos)
+    m = measure(trd, aos_run, G, 1 if pairs_first else S, a.steps, a.warmup, pairs_first)
 
     out = None
     if rank == 0:
@@ -282,7 +292,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: N={n} orbitals, A={A} atoms, T={T} training states, "
                                    f"two-body t-RDM layout {a.layout} ({rows}x{cols} f64, "
-                                   f"{rows * cols * 8 / 1e9:.3f} GB resident in HBM), {a.geoms} resident geometries "
+                                   f"{rows * cols * 8 / 1e9:.3f} GB resident in HBM), int2e_ip1 "
+                                   f"{'packed in its last two AO indices (s2kl)' if packed_ip1 else 'full'}, "
+                                   f"{a.geoms} resident geometries "
                                    f"per GPU; step = {m['geometries_per_step']} {what} evaluations",
                        "parallelism": par,
                        "geometries_per_step": m["geometries_per_step"], "batch_per_gpu": G, "streams": m["streams"]},
@@ -304,7 +316,8 @@ def main():
         del aos
         # pair sharding needs identical geometries on all ranks, geometry sharding distinct ones
         aos2 = geometries(seed * 1000 + (0 if second_pairs else rank * a.geoms))
-        m2 = measure(trd2, aos2, G, 1 if second_pairs else S, a.steps, a.warmup, second_pairs)
+        aos_run = run_view(aos2)
+        m2 = measure(trd2, aos_run, G, 1 if second_pairs else S, a.steps, a.warmup, second_pairs)
         if rank == 0:
             out["pair_sharded" if second_pairs else "geometry_sharded"] = {
                 "value": m2["value"], "unit": "geometries/s", "ms_per_step": m2["ms_per_step"],
@@ -316,7 +329,7 @@ def main():
         trd = trd2
     if world == 1 and not a.no_md_regime and S > 1:
         # the same batches on ONE stream: the streaming kernels without another batch's kernels beside them
-        one = measure(trd, aos, G, 1, max(10, a.steps // 2), 3, False)
+        one = measure(trd, aos_run, G, 1, max(10, a.steps // 2), 3, False, all_stages=True)
         if rank == 0:
             out["single_stream"] = {"value": one["value"], "unit": "geometries/s", "ms_per_step": one["ms_per_step"],
                                     "note": "same batch size, one stream: kernels of one batch at a time",
@@ -355,7 +368,7 @@ def main():
                                "bytes_per_launch": nb, "ms_per_launch": st["ip1_ms"]})
             out["roofline_other_kernels"] = others
     if world == 1 and not a.no_md_regime and (G, S) != (1, 1):
-        md = measure(trd, aos, 1, 1, max(20, min(a.steps * 2, 200)), 10, False)
+        md = measure(trd, aos_run, 1, 1, max(20, min(a.steps * 2, 200)), 10, False)
         if rank == 0:
             out["md_regime"] = {"value": md["value"], "unit": "geometries/s", "ms_per_step": md["ms_per_step"],
                                 "note": "one geometry per step on one stream (no batching, no overlap)",
@@ -366,13 +379,13 @@ def main():
         # synthetic geometries in 0.1 % steps), one per step on one stream, the eigensolvers warm-started
         # from the previous step (EVC_FLAG_WARM_START) as evcont_amd.MD_utils.get_scanner does
         from evcont_amd.evaluator import DeviceAO
-        a0, a1 = aos[0], aos[1]
+        a0, a1 = aos_run[0], aos_run[1]
         nsteps = 40
         lerp = lambda x, y, t: torch.lerp(x, y, t)
         traj = [DeviceAO(S=lerp(a0.S, a1.S, t), hcore=lerp(a0.hcore, a1.hcore, t), eri=lerp(a0.eri, a1.eri, t),
                          enuc=(1 - t) * a0.enuc + t * a1.enuc, natm=a0.natm, ipovlp=lerp(a0.ipovlp, a1.ipovlp, t),
                          dhcore=lerp(a0.dhcore, a1.dhcore, t), eri_ip1=lerp(a0.eri_ip1, a1.eri_ip1, t),
-                         gnuc=lerp(a0.gnuc, a1.gnuc, t), aoslices=a0.aoslices)
+                         gnuc=lerp(a0.gnuc, a1.gnuc, t), aoslices=a0.aoslices, ip1_s2kl=a0.ip1_s2kl)
                 for t in (1e-3 * k for k in range(nsteps))]
         res = {}
         for name, warm in (("cold", False), ("warm", True)):

@@ -61,8 +61,10 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="defaul
                     if self._ev is None:
                         self._ev = ContinuationEvaluator(_trdms(one_rdm, two_rdm, overlap, compress),
                                                          int(np.asarray(ao.aoslices).shape[0]), warm_start=True)
+                    # (compressed layout: int2e_ip1 travels packed in its last two AO indices, half the upload)
+                    pack = self._ev.t.layout == 8 and self._ev.t.n <= 32
                     en, grad, rdm_o, rdm_t = self._ev.energy_with_grad(
-                        DeviceAO.from_arrays(ao, self._ev.t.device), return_density_matrices=True)
+                        DeviceAO.from_arrays(ao, self._ev.t.device, pack_ip1=pack), return_density_matrices=True)
                 self.base.predicted_one_rdm = rdm_o
                 self.base.predicted_two_rdm = rdm_t
                 return en, grad

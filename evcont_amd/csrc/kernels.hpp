@@ -112,6 +112,8 @@ struct Ip1Args {
     int presym;            // Gao already carries the 4-fold AO symmetrisation (packed fast path)
     int fold_cd;           // (with presym) Gao[m,b,c,d] is symmetric in c <-> d and in m <-> b and only valid for
                            // d <= c, b <= m
+    int ip1_s2kl;          // (with fold_cd) ip1 is (3,n,n,n(n+1)/2): packed in its last two indices, c >= d
+                           // (EVC_FLAG_IP1_S2KL); sip1 is the packed size
 };
 int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st);
 

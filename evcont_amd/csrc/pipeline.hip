@@ -34,11 +34,12 @@ struct Prof {
     int *stage = nullptr;        // [cap]
     double ms[kProfStages] = {0};   // results of the last evc_profile_end
     int cnt[kProfStages] = {0};
+    unsigned mask = (1u << EVC_PROF_ROWS) | (1u << EVC_PROF_COLS);   // stages that are timed (evc_profile_select)
 };
 static Prof g_prof;
 // start of a timed launch: returns the record index or -1
 static int prof_start(int stage, hipStream_t st) {
-    if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
+    if (!g_prof.on || !(g_prof.mask >> stage & 1u) || g_prof.n >= g_prof.cap) return -1;
     const int i = g_prof.n++;
     g_prof.stage[i] = stage;
     (void)hipEventRecord(g_prof.ev[2 * i], st);
@@ -386,8 +387,8 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
 // are taken straight from the packed vector (G is then only written when the caller wants it, G may be NULL);
 // sym8: the packed vector is the 8-fold compressed one (EVC_LAYOUT_SYM8).
 static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, double *G, int64_t sG,
-                              const double *packed, int64_t spacked, int sym8, double scale1, bool add_gnuc,
-                              double *grad, int64_t sgrad, Ws &w, hipStream_t st) {
+                              const double *packed, int64_t spacked, int sym8, int ip1_s2kl, double scale1,
+                              bool add_gnuc, double *grad, int64_t sgrad, Ws &w, hipStream_t st) {
     const int cnt = g.count;
     const int64_t sw = w.stride;
     int rc;
@@ -439,6 +440,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
         ia.Gao = gao_ + o;
         ia.presym = packed ? 1 : 0;
         ia.fold_cd = (packed && sym8 && use_pair_transform(n)) ? 1 : 0;
+        ia.ip1_s2kl = ip1_s2kl;
         ia.t2part = w.t2part + o;
         ia.dh = g.dhcore ? g.dhcore + (int64_t)c0 * g.sdh : nullptr;
         ia.Pao = w.Pao + o;
@@ -552,8 +554,15 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
     return launch_grad_final(f, cnt, st);
 }
 
-static int phase_gradient(const evc_trdm_set *t, const Geo &g, const Out &out, int flags, Ws &w, hipStream_t st) {
-    const int n = t->n, cnt = g.count;
+static int phase_gradient(const evc_trdm_set *t, const Geo &g_in, const Out &out, int flags, Ws &w, hipStream_t st) {
+    const int n = t->n, cnt = g_in.count;
+    Geo g = g_in;
+    const int s2kl = (flags & EVC_FLAG_IP1_S2KL) ? 1 : 0;
+    if (s2kl) {
+        EVC_REQUIRE(is_sym8(t->layout) && use_pair_transform(n),
+                    "EVC_FLAG_IP1_S2KL needs the compressed layout (EVC_LAYOUT_SYM8) and N <= 32");
+        if (cnt > 1) g.sip1 = (int64_t)3 * n * n * (n * (n + 1) / 2);
+    }
     const int64_t sw = w.stride;
     int rc;
     double *D = out.d_pred ? out.d_pred : w.Dpred;
@@ -588,10 +597,10 @@ static int phase_gradient(const evc_trdm_set *t, const Geo &g, const Out &out, i
     const bool partial = (flags & EVC_FLAG_PARTIAL_RANK) != 0;
     if (is_packed(t->layout))
         // the unpacked 2-RDM is only materialised when the caller asked for it
-        return gradient_from_rdms(n, g, D, sD, out.g_pred, out.sG, w.vec2, sw, is_sym8(t->layout) ? 1 : 0,
+        return gradient_from_rdms(n, g, D, sD, out.g_pred, out.sG, w.vec2, sw, is_sym8(t->layout) ? 1 : 0, s2kl,
                                   partial ? 0.0 : 1.0, !partial, out.grad, out.sg, w, st);
-    return gradient_from_rdms(n, g, D, sD, G, sG, nullptr, 0, 0, partial ? 0.0 : 1.0, !partial, out.grad, out.sg, w,
-                              st);
+    return gradient_from_rdms(n, g, D, sD, G, sG, nullptr, 0, 0, 0, partial ? 0.0 : 1.0, !partial, out.grad, out.sg,
+                              w, st);
 }
 
 static int check_geometry(const evc_geometry *g, bool need_grad) {
@@ -687,6 +696,12 @@ extern "C" int evc_profile_end(double *rows_ms, int *rows_n, double *cols_ms, in
     g_prof.stage = nullptr;
     g_prof.cap = g_prof.n = 0;
     g_prof.on = false;
+    return 0;
+}
+
+extern "C" int evc_profile_select(unsigned stage_mask) {
+    EVC_REQUIRE(!g_prof.on, "evc_profile_select: not while profiling");
+    g_prof.mask = stage_mask & ((1u << kProfStages) - 1u);
     return 0;
 }
 
@@ -837,7 +852,7 @@ extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geome
     if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
     if ((rc = phase_solve(t, g, nullptr, 0, o, nroots, w, st))) return rc;
     if (energy_only) return 0;
-    return phase_gradient(t, g, o, 0, w, st);
+    return phase_gradient(t, g, o, flags & EVC_FLAG_IP1_S2KL, w, st);
 }
 
 extern "C" int evc_phase_hamiltonian_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, double *rows_out,
@@ -1066,6 +1081,6 @@ extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *tra
     if ((rc = launch_quarter_transform(g->eri, 0, w.X, 0, 0, n, w.B1, 0, 1, st))) return rc;
     if ((rc = launch_quarter_transform(w.B1, 0, w.X, 0, 0, n, w.B2, 0, 1, st))) return rc;
     if ((rc = launch_quarter_transform(w.B2, 0, w.X, 0, 0, n, w.K3, 0, 1, st))) return rc;
-    return gradient_from_rdms(n, geo, one_rdm, 0, const_cast<double *>(two_rdm), 0, nullptr, 0, 0, 1.0, false, grad, 0,
+    return gradient_from_rdms(n, geo, one_rdm, 0, const_cast<double *>(two_rdm), 0, nullptr, 0, 0, 0, 1.0, false, grad, 0,
                               w, st);
 }

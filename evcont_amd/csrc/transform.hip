@@ -925,7 +925,48 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
         const int m = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         const int64_t e0 = (int64_t)ch * 256 * kIp1PerThread;
-        if (a.presym && a.fold_cd && (n & 1) == 0) {
+        if (a.presym && a.fold_cd && a.ip1_s2kl) {
+            // int2e_ip1 packed in (c,d), c >= d: per (x,m) one dense [b][v] block of n * n(n+1)/2 doubles; the AO-basis
+            // 2-RDM is read at [max(m,b)][min(m,b)][c][d] (gathers inside a 7 KB block), weight 2 for c != d
+            const int npr = n * (n + 1) / 2;
+            const int64_t len = (int64_t)n * npr;
+            const double *__restrict__ q0 = ip1 + (int64_t)m * len;
+            const double *__restrict__ q1 = q0 + (int64_t)n * len;
+            const double *__restrict__ q2 = q1 + (int64_t)n * len;
+            int64_t per = (len + nchunk - 1) / nchunk;
+            per += per & 1;   // even, so that 16-byte pairs never straddle two chunks
+            const int64_t e1 = min(len, (int64_t)(ch + 1) * per);
+            const bool al = (len & 1) == 0;   // every (x,m) block starts 16-byte aligned
+            for (int64_t e = (int64_t)ch * per + 2 * threadIdx.x; e < e1; e += 512) {
+                double gx = 0.0, gy = 0.0;
+                const bool two = e + 1 < e1;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int64_t ee = e + h;
+                    if (h == 0 || two) {
+                        const int b = (int)(ee / npr), v = (int)(ee - (int64_t)b * npr);
+                        const int c = (int)tri_row(v), d = v - c * (c + 1) / 2;
+                        const int hi = b <= m ? m : b, lo = b <= m ? b : m;
+                        const double gv = G[((int64_t)hi * n + lo) * n2 + c * n + d] * (c != d ? 2.0 : 1.0);
+                        if (h == 0) gx = gv;
+                        else gy = gv;
+                    }
+                }
+                double2 p0, p1, p2;
+                if (al && two) {
+                    p0 = *reinterpret_cast<const double2 *>(q0 + e);
+                    p1 = *reinterpret_cast<const double2 *>(q1 + e);
+                    p2 = *reinterpret_cast<const double2 *>(q2 + e);
+                } else {
+                    p0 = make_double2(q0[e], two ? q0[e + 1] : 0.0);
+                    p1 = make_double2(q1[e], two ? q1[e + 1] : 0.0);
+                    p2 = make_double2(q2[e], two ? q2[e + 1] : 0.0);
+                }
+                a0 = fma(p0.y, gy, fma(p0.x, gx, a0));
+                a1 = fma(p1.y, gy, fma(p1.x, gx, a1));
+                a2 = fma(p2.y, gy, fma(p2.x, gx, a2));
+            }
+        } else if (a.presym && a.fold_cd && (n & 1) == 0) {
             // symmetrised operand that is only valid for d <= c (and symmetric in c <-> d, like ip1 itself): the
             // dot runs over the lower triangles with weight 2 off the diagonal.  The 16-byte pairs (d, d+1), d even,
             // d <= c, of one b are numbered row by row (rows 2h and 2h+1 hold h+1 pairs each, h(h+1) pairs precede

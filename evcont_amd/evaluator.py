@@ -246,22 +246,46 @@ class DeviceAO:
     eri_ip1: Optional[torch.Tensor] = None
     gnuc: Optional[torch.Tensor] = None
     aoslices: Optional[torch.Tensor] = None
+    ip1_s2kl: bool = False   # eri_ip1 is (3,N,N,N(N+1)/2): packed in its last two indices (EVC_FLAG_IP1_S2KL)
 
     @property
     def nao(self) -> int:
         return int(self.S.shape[0])
 
     @staticmethod
-    def from_arrays(ao, device=None, energy_only: bool = False) -> "DeviceAO":
-        """From any object with the AOArrays fields (numpy)."""
+    def from_arrays(ao, device=None, energy_only: bool = False, pack_ip1: bool = False) -> "DeviceAO":
+        """From any object with the AOArrays fields (numpy).  ``pack_ip1``: upload ``eri_ip1`` packed in its last
+        two AO indices (half the bytes; what ``mol.intor("int2e_ip1", aosym="s2kl")`` returns -- an ``eri_ip1`` that
+        already has that shape is taken as is); only for evaluators on the compressed ``sym8`` layout."""
         d = _dev(device)
         up = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(d)
         out = DeviceAO(S=up(ao.S), hcore=up(ao.hcore), eri=up(ao.eri), enuc=float(ao.enuc),
                        natm=int(np.asarray(ao.aoslices).shape[0]))
         if not energy_only:
-            out.ipovlp, out.dhcore, out.eri_ip1, out.gnuc = up(ao.ipovlp), up(ao.dhcore), up(ao.eri_ip1), up(ao.gnuc)
+            ip1 = np.asarray(ao.eri_ip1)
+            n = out.nao
+            if ip1.ndim == 4 or (ip1.ndim == 3 and ip1.shape[-1] == n * (n + 1) // 2):   # already s2kl
+                ip1 = ip1.reshape(3, n, n, n * (n + 1) // 2)
+                out.ip1_s2kl = True
+            elif pack_ip1:
+                iu, ju = np.tril_indices(n)
+                ip1 = ip1.reshape(3, n, n, n, n)[:, :, :, iu, ju]
+                out.ip1_s2kl = True
+            out.ipovlp, out.dhcore, out.eri_ip1, out.gnuc = up(ao.ipovlp), up(ao.dhcore), up(ip1), up(ao.gnuc)
             out.aoslices = torch.from_numpy(np.ascontiguousarray(ao.aoslices, dtype=np.int64)).to(d)
         return out
+
+    def packed_ip1(self) -> "DeviceAO":
+        """A copy (sharing every other array) whose ``eri_ip1`` is packed in its last two indices, gathered on the
+        device from the full array."""
+        if self.ip1_s2kl or self.eri_ip1 is None:
+            return self
+        n = self.nao
+        iu, ju = np.tril_indices(n)
+        idx = torch.from_numpy((iu * n + ju).astype(np.int64)).to(self.eri_ip1.device)
+        ip1 = self.eri_ip1.reshape(3, n, n, n * n).index_select(3, idx).contiguous()
+        return DeviceAO(S=self.S, hcore=self.hcore, eri=self.eri, enuc=self.enuc, natm=self.natm, ipovlp=self.ipovlp,
+                        dhcore=self.dhcore, eri_ip1=ip1, gnuc=self.gnuc, aoslices=self.aoslices, ip1_s2kl=True)
 
     def cstruct(self) -> Geometry:
         p = lambda t: (t.data_ptr() if t is not None else None)
@@ -284,6 +308,7 @@ class DeviceAOBatch:
     eri_ip1: Optional[torch.Tensor] = None   # (G,3,N,N,N,N)
     gnuc: Optional[torch.Tensor] = None      # (G,A,3)
     aoslices: Optional[torch.Tensor] = None  # (A,2) int64, shared
+    ip1_s2kl: bool = False                   # eri_ip1 is (G,3,N,N,N(N+1)/2) (EVC_FLAG_IP1_S2KL)
 
     @property
     def count(self) -> int:
@@ -297,23 +322,34 @@ class DeviceAOBatch:
     def stack(aos) -> "DeviceAOBatch":
         """Stack single-geometry ``DeviceAO`` objects (device-to-device copies)."""
         aos = list(aos)
+        assert len({bool(a.ip1_s2kl) for a in aos}) == 1, "mixed full / packed eri_ip1 in one batch"
         d = aos[0].S.device
         st = lambda name: (torch.stack([getattr(a, name) for a in aos]).contiguous()
                            if getattr(aos[0], name) is not None else None)
         return DeviceAOBatch(S=st("S"), hcore=st("hcore"), eri=st("eri"),
                              enuc=torch.tensor([a.enuc for a in aos], dtype=F64, device=d), natm=aos[0].natm,
                              ipovlp=st("ipovlp"), dhcore=st("dhcore"), eri_ip1=st("eri_ip1"), gnuc=st("gnuc"),
-                             aoslices=aos[0].aoslices)
+                             aoslices=aos[0].aoslices, ip1_s2kl=bool(aos[0].ip1_s2kl))
 
     @staticmethod
-    def from_arrays(ao_list, device=None, energy_only: bool = False) -> "DeviceAOBatch":
-        return DeviceAOBatch.stack([DeviceAO.from_arrays(a, device, energy_only) for a in ao_list])
+    def from_arrays(ao_list, device=None, energy_only: bool = False, pack_ip1: bool = False) -> "DeviceAOBatch":
+        return DeviceAOBatch.stack([DeviceAO.from_arrays(a, device, energy_only, pack_ip1) for a in ao_list])
 
     def cstruct(self) -> "_lib.GeometryBatch":
         p = lambda t: (t.data_ptr() if t is not None else None)
         return _lib.GeometryBatch(natm=self.natm, count=self.count, enuc=p(self.enuc), S=p(self.S),
                                   hcore=p(self.hcore), eri=p(self.eri), ipovlp=p(self.ipovlp), dhcore=p(self.dhcore),
                                   eri_ip1=p(self.eri_ip1), gnuc=p(self.gnuc), aoslices=p(self.aoslices))
+
+
+def _ip1_flag(trdms: "DeviceTRDMs", ao) -> int:
+    """EVC_FLAG_IP1_S2KL for geometries whose ``eri_ip1`` is packed in its last two indices."""
+    if not getattr(ao, "ip1_s2kl", False):
+        return 0
+    if trdms.layout != _lib.LAYOUT_SYM8 or trdms.n > 32:
+        raise _lib.EvcontHipError("a packed (s2kl) eri_ip1 needs training data in the compressed sym8 layout and "
+                                  "N <= 32 (DeviceAO.from_arrays(..., pack_ip1=False) otherwise)")
+    return _lib.FLAG_IP1_S2KL
 
 
 class BatchedEvaluator:
@@ -352,7 +388,7 @@ class BatchedEvaluator:
     def enqueue(self, aob: DeviceAOBatch, nroots: int = 1, energy_only: bool = False) -> None:
         assert aob.count == self.count, "batch size is fixed at construction"
         g = aob.cstruct()
-        flags = _lib.FLAG_ENERGY_ONLY if energy_only else 0
+        flags = (_lib.FLAG_ENERGY_ONLY if energy_only else 0) | _ip1_flag(self.t, aob)
         rc = self.lib.evc_energy_with_grad_batch(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out), int(nroots),
                                                  flags, self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_energy_with_grad_batch")
@@ -388,8 +424,8 @@ class BatchedEvaluator:
     def phase_gradient(self, aob: DeviceAOBatch, partial_rank: bool) -> None:
         g = aob.cstruct()
         rc = self.lib.evc_phase_gradient_batch(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out),
-                                               _lib.FLAG_PARTIAL_RANK if partial_rank else 0, self.ws.data_ptr(),
-                                               self.ws_bytes, self._sp())
+                                               (_lib.FLAG_PARTIAL_RANK if partial_rank else 0) | _ip1_flag(self.t, aob),
+                                               self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_phase_gradient_batch")
 
 
@@ -437,7 +473,7 @@ class ContinuationEvaluator:
     def enqueue(self, ao: DeviceAO, nroots: int = 1, energy_only: bool = False) -> None:
         """Enqueue one evaluation on torch's current stream; no synchronisation."""
         g = ao.cstruct()
-        flags = _lib.FLAG_ENERGY_ONLY if energy_only else 0
+        flags = (_lib.FLAG_ENERGY_ONLY if energy_only else 0) | _ip1_flag(self.t, ao)
         if self.warm_start and self._primed:
             flags |= _lib.FLAG_WARM_START
         rc = self.lib.evc_energy_with_grad(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out), int(nroots), flags,
@@ -491,6 +527,6 @@ class ContinuationEvaluator:
     def phase_gradient(self, ao: DeviceAO, partial_rank: bool) -> None:
         g = ao.cstruct()
         rc = self.lib.evc_phase_gradient(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out),
-                                         _lib.FLAG_PARTIAL_RANK if partial_rank else 0, self.ws.data_ptr(),
-                                         self.ws_bytes, self._sp())
+                                         (_lib.FLAG_PARTIAL_RANK if partial_rank else 0) | _ip1_flag(self.t, ao),
+                                         self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_phase_gradient")

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define EVC_ABI_VERSION 4 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
-                             3: EVC_LAYOUT_SYM8; 4: evc_profile_stage */
+                             3: EVC_LAYOUT_SYM8; 4: evc_profile_stage, EVC_FLAG_IP1_S2KL */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
@@ -197,6 +197,12 @@ typedef struct evc_outputs {
                                    with a cold start to solver tolerance (~1e-14), not bit for bit; stale or
                                    never-written eigenvectors are detected and ignored.  Fused entry points only. */
 
+#define EVC_FLAG_IP1_S2KL 8     /* geometry.eri_ip1 is (3,N,N,N(N+1)/2) [per geometry of a batch]: int2e_ip1 packed in its
+                                   last two AO indices, element (x,p,q,k(k+1)/2+l), k >= l -- what PySCF returns for
+                                   mol.intor("int2e_ip1", aosym="s2kl").  Half the bytes of the largest input; the
+                                   contraction then streams dense rows.  Only with EVC_LAYOUT_SYM8 and N <= 32 (the
+                                   path that uses the r <-> s symmetry of int2e_ip1 anyway). */
+
 size_t evc_workspace_bytes(const evc_trdm_set *t, int natm);
 
 /* Phase A: Loewdin + integrals + H rows.  Writes h2rows_local[rows2] (scaled two-body rows of this
@@ -300,7 +306,7 @@ int evc_contract_nnA3(const double *T, const double *M, int transposed, int n, i
  * stream immediately before and after the launches of the stages below, for up to max_samples
  * evaluations.  evc_profile_end synchronises those events, returns the summed durations in
  * milliseconds with the number of launches for K5 (rows GEMV) and K8 (cols GEMV), and frees them;
- * afterwards evc_profile_stage reports the same two numbers for any stage of that session.
+ * afterwards evc_profile_stage reports the same two numbers for any stage selected for that session.
  * Process-wide state.
  * --------------------------------------------------------------------------------- */
 #define EVC_PROF_ROWS 0           /* K5  H2 = Gamma . h2 (+ one-body) */
@@ -314,6 +320,9 @@ int evc_contract_nnA3(const double *T, const double *M, int transposed, int n, i
 int evc_profile_begin(int max_samples);
 int evc_profile_end(double *rows_ms, int *rows_n, double *cols_ms, int *cols_n);
 int evc_profile_stage(int stage, double *ms, int *launches);
+/* Stages timed by the next sessions: bit s = stage s (default: EVC_PROF_ROWS and EVC_PROF_COLS only -- every timed
+ * launch costs two event records, which is visible in the one-geometry-at-a-time regime). */
+int evc_profile_select(unsigned stage_mask);
 
 #ifdef __cplusplus
 }

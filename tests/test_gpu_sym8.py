@@ -223,3 +223,34 @@ def test_sym8_through_the_reference_api(h10_fci, tmp_path):
     np.testing.assert_allclose(G1, sym8(G1), rtol=0, atol=1e-13)       # the stored 2-RDM is the symmetrised one
     with pytest.raises(ValueError):
         aec.set_trdm_compression("sym4")
+
+
+@pytest.mark.parametrize("n,T,A", [(5, 3, 2), (7, 3, 3), (10, 5, 10), (18, 4, 3), (30, 3, 5), (32, 2, 4)])
+def test_packed_ip1_input(n, T, A):
+    """EVC_FLAG_IP1_S2KL: int2e_ip1 handed over packed in its last two AO indices (PySCF aosym="s2kl"), host-packed
+    and device-gathered, single and batched, against the oracle on the full arrays and the original t-RDMs."""
+    from evcont_amd.evaluator import (DeviceTRDMs, DeviceAO, DeviceAOBatch, ContinuationEvaluator, BatchedEvaluator)
+    dev = torch.device("cuda:0")
+    S, one, two = make_trdms(n, T, 140 + n)
+    two_l = pack_rows(two, True, True)
+    aos = [make_ao_arrays(n, A, 190 + n + k, ip1_rs_symmetric=True) for k in range(3)]
+    trd = DeviceTRDMs(one, two_l, S, dev, compress="sym8")
+    ev = ContinuationEvaluator(trd, A)
+    dao = DeviceAO.from_arrays(aos[0], dev, pack_ip1=True)
+    assert dao.ip1_s2kl and tuple(dao.eri_ip1.shape) == (3, n, n, n * (n + 1) // 2)
+    assert torch.equal(DeviceAO.from_arrays(aos[0], dev).packed_ip1().eri_ip1, dao.eri_ip1)
+    E, g = ev.energy_with_grad(dao)
+    Eo, go = orc.energy_with_grad(bundle(aos[0]), one, two_l, S)
+    assert abs(E - Eo) < 1e-10
+    np.testing.assert_allclose(g, go, rtol=0, atol=1e-9)
+    be = BatchedEvaluator(trd, A, 3)
+    Eb, gb = be.energies_with_grads(DeviceAOBatch.from_arrays(aos, dev, pack_ip1=True))
+    for k in range(3):
+        Eo, go = orc.energy_with_grad(bundle(aos[k]), one, two_l, S)
+        assert abs(Eb[k] - Eo) < 1e-9
+        np.testing.assert_allclose(gb[k], go, rtol=0, atol=1e-8)
+    # the packed form is only understood by the symmetric pipeline of the compressed layout
+    plain = ContinuationEvaluator(DeviceTRDMs(one, two_l, S, dev), A)
+    from evcont_amd._lib import EvcontHipError
+    with pytest.raises(EvcontHipError):
+        plain.energy_with_grad(dao)
