@@ -64,6 +64,8 @@ struct PairTransformArgs {
     int lead_sym;       // in[p][q][..] = in[q][p][..]: only q <= p (whole 8-wide q tiles) is computed and stored
     int in_lower;       // in[p][q][r][s] = in[p][q][s][r] and only r >= s is valid (output of a lead_sym step)
     int rs_lower;       // only the rows (r',s'), s' <= r', of the result are needed (out rows / packed sym8 vector)
+    int out_pairs;      // (with lead_sym and rs_lower) `out` is the dense (pair, pair) matrix
+                        // out[tri(r',s')][tri(p,q)] * (p != q ? 2 : 1) instead of rows of an N^4 tensor
 };
 constexpr int kPairTransformMaxN = 32;
 int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);
@@ -113,7 +115,8 @@ struct Ip1Args {
     int fold_cd;           // (with presym) Gao[m,b,c,d] is symmetric in c <-> d and in m <-> b and only valid for
                            // d <= c, b <= m
     int ip1_s2kl;          // (with fold_cd) ip1 is (3,n,n,n(n+1)/2): packed in its last two indices, c >= d
-                           // (EVC_FLAG_IP1_S2KL); sip1 is the packed size
+                           // (EVC_FLAG_IP1_S2KL); sip1 is the packed size and Gao the dense (pair, pair) matrix
+                           // Gao[tri(m,b)][tri(c,d)] with the multiplicity of (c,d) folded in (out_pairs)
 };
 int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st);
 

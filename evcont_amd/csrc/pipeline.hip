@@ -501,6 +501,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 // the result is only valid for d <= c of G^AO[m,b,c,d] (fold_cd below)
                 pa.in = w.B2 + o;
                 pa.out = w.B1 + o;
+                pa.out_pairs = ip1_s2kl;   // the packed-ip1 dot wants the dense (pair, pair) form
                 pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
                 prof_stop(pr, st);

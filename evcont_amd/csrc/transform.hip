@@ -290,6 +290,12 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             double *out = a.out + g * a.sout;
             if (!rsl) {
                 for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) out[(int64_t)rs * n2 + Cc] = stage[rs * QP + wl];
+            } else if (a.out_pairs) {
+                // dense (pair, pair) result: row tri(r',s'), column = the leading pair's own triangle index, and the
+                // multiplicity of the leading pair folded in (the consumer is a plain dot over v = tri(p,q))
+                const double mq = (wp != wq) ? 2.0 : 1.0;
+                const int e = t * QT + wl;
+                for (int u = threadIdx.x >> 3; u < npairs; u += 32) out[(int64_t)u * npairs + e] = stage[u * QP + wl] * mq;
             } else {
                 // (r', s') of stage row u, advanced incrementally: u += 32
                 int r2 = (int)tri_row(threadIdx.x >> 3), s2 = (threadIdx.x >> 3) - r2 * (r2 + 1) / 2;
@@ -927,7 +933,8 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
         const int64_t e0 = (int64_t)ch * 256 * kIp1PerThread;
         if (a.presym && a.fold_cd && a.ip1_s2kl) {
             // int2e_ip1 packed in (c,d), c >= d: per (x,m) one dense [b][v] block of n * n(n+1)/2 doubles; the AO-basis
-            // 2-RDM is read at [max(m,b)][min(m,b)][c][d] (gathers inside a 7 KB block), weight 2 for c != d
+            // 2-RDM comes as the dense (pair, pair) matrix G[tri(max(m,b),min(m,b))][v] with the weight 2 for c != d
+            // already folded in (out_pairs of the last rotation step): two contiguous streams per lane
             const int npr = n * (n + 1) / 2;
             const int64_t len = (int64_t)n * npr;
             const double *__restrict__ q0 = ip1 + (int64_t)m * len;
@@ -945,9 +952,8 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
                     const int64_t ee = e + h;
                     if (h == 0 || two) {
                         const int b = (int)(ee / npr), v = (int)(ee - (int64_t)b * npr);
-                        const int c = (int)tri_row(v), d = v - c * (c + 1) / 2;
                         const int hi = b <= m ? m : b, lo = b <= m ? b : m;
-                        const double gv = G[((int64_t)hi * n + lo) * n2 + c * n + d] * (c != d ? 2.0 : 1.0);
+                        const double gv = G[(int64_t)(hi * (hi + 1) / 2 + lo) * npr + v];
                         if (h == 0) gx = gv;
                         else gy = gv;
                     }
