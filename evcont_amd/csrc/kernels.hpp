@@ -64,8 +64,9 @@ struct PairTransformArgs {
     int lead_sym;       // in[p][q][..] = in[q][p][..]: only q <= p (whole 8-wide q tiles) is computed and stored
     int in_lower;       // in[p][q][r][s] = in[p][q][s][r] and only r >= s is valid (output of a lead_sym step)
     int rs_lower;       // only the rows (r',s'), s' <= r', of the result are needed (out rows / packed sym8 vector)
-    int out_pairs;      // (with lead_sym and rs_lower) `out` is the dense (pair, pair) matrix
-                        // out[tri(r',s')][tri(p,q)] * (p != q ? 2 : 1) instead of rows of an N^4 tensor
+    int out_pairs;      // (with lead_sym and rs_lower) `out` is the dense (pair, pair) matrix out[tri(r',s')][tri(p,q)]
+                        // instead of rows of an N^4 tensor; 2: times the multiplicity (p != q ? 2 : 1)
+    int in_pairs;       // (with lead_sym) `in` is such a matrix: in[tri(p,q)][tri(r,s)]
 };
 constexpr int kPairTransformMaxN = 32;
 int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);
@@ -87,13 +88,16 @@ int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t so
 int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
                       int64_t sG, int count, hipStream_t st);
 // EVC_LAYOUT_SYM8: `packed` is the 8-fold compressed vector p8 of a fully symmetric 2-RDM:
-//   SB[i,j,k,l] = 4 p8(ijkl) (only for i >= j, l <= k when lead_half), G[i,j,k,l] = p8(ijkl) (optional)
+//   SB[i,j,k,l] = 4 p8(ijkl) (only for i >= j, l <= k when lead_half = 1; lead_half = 2: the dense (pair, pair)
+//   matrix SB[tri(i,j)][tri(k,l)] instead), G[i,j,k,l] = p8(ijkl) (optional)
 int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t sws, double *G, int64_t sG, int count,
                    int lead_half, hipStream_t st);
 // partial[b][i][a] = sum_{k in slab b} SB[i][k] * K3[k][a]: the Y2 contraction with the row-major operand
 int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);
 // ... with SB only valid for i >= j, l <= k and K3[j][k][l][:] only for l <= k (symmetric pair-transform pipeline)
-int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);
+// pairs: SB is the dense (pair, pair) matrix SB[tri(i,j)][tri(k,l)]
+int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, int pairs,
+                   hipStream_t st);
 // partial[b][i][a] = sum_{k in slab b} GsT[k][i] * K3[k][a]   (k = jkl)
 int y2_slabs(int n);
 int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);

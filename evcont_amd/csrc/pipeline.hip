@@ -263,9 +263,12 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
             // produces the q <= p half of its output and the second one reads the lower triangles
             // (in_lower: eri[p,q,r,s] = eri[p,q,s,r]; rs_lower: the next step's leading pairs are (r',s'), s' <= r')
             pa.lead_sym = pa.in_lower = pa.rs_lower = is_sym8(t->layout) ? 1 : 0;
+            pa.out_pairs = pa.lead_sym;   // the intermediate as a dense (pair, pair) matrix
             int pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
             if ((rc = launch_pair_transform(pa, cc, st))) return rc;
             prof_stop(pr, st);
+            pa.in_pairs = pa.out_pairs;
+            pa.out_pairs = 0;
             // ... and the second step again only needs the q <= p half of ITS leading pair
             pa.in = w.B1 + o;
             pa.sin = sw;
@@ -468,12 +471,13 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 int pr = prof_start(EVC_PROF_UNPACK, st);
                 if (sym8) {
                     // (K3 was written for l <= k only by the symmetric second step of phase A)
+                    // (without a request for the unpacked 2-RDM, SB is the dense (pair, pair) matrix)
                     if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, w.B1 + o, sw,
-                                             G ? G + (int64_t)c0 * sG : nullptr, sG, cc, 1, st)))
+                                             G ? G + (int64_t)c0 * sG : nullptr, sG, cc, G ? 1 : 2, st)))
                         return rc;
                     prof_stop(pr, st);
                     pr = prof_start(EVC_PROF_Y2, st);
-                    if ((rc = launch_y2_fold(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, st))) return rc;
+                    if ((rc = launch_y2_fold(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, G ? 0 : 1, st))) return rc;
                 } else {
                     if ((rc = launch_unpack_sym(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, w.B1 + o, sw,
                                                 G ? G + (int64_t)c0 * sG : nullptr, sG, cc, st)))
@@ -494,6 +498,8 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.out = w.B2 + o;
                 pa.sout = sw;
                 pa.lead_sym = pa.in_lower = pa.rs_lower = sym8;   // SB is fully symmetric
+                pa.in_pairs = (sym8 && !G) ? 1 : 0;
+                pa.out_pairs = sym8;
                 pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
                 prof_stop(pr, st);
@@ -501,7 +507,8 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 // the result is only valid for d <= c of G^AO[m,b,c,d] (fold_cd below)
                 pa.in = w.B2 + o;
                 pa.out = w.B1 + o;
-                pa.out_pairs = ip1_s2kl;   // the packed-ip1 dot wants the dense (pair, pair) form
+                pa.in_pairs = pa.out_pairs;
+                pa.out_pairs = ip1_s2kl ? 2 : 0;   // the packed-ip1 dot wants the dense (pair, pair) form, weighted
                 pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
                 prof_stop(pr, st);

@@ -183,14 +183,19 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
         q = (t - p * ntq) * QT + ql;
         return q < n;
     };
+    // in_pairs: the operand is the dense (pair, pair) matrix in[tri(p,q)][tri(r,s)] (out_pairs of the previous step)
+    const bool inp = a.in_pairs != 0;
     auto load_matrix = [&](double (&m)[NT][KS], bool ok, int p, int q) {
-        const double *Mb = in + ((int64_t)(ok ? p : 0) * n + (ok ? q : 0)) * n2;
+        const double *Mb = inp ? in + (int64_t)(ok ? p * (p + 1) / 2 + q : 0) * npairs
+                               : in + ((int64_t)(ok ? p : 0) * n + (ok ? q : 0)) * n2;
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 const int r = rt * 16 + l15, s = 4 * kk + l4;
-                m[rt][kk] = (ok && r < n && s < n) ? Mb[(lower && s > r) ? s * n + r : r * n + s] : 0.0;
+                const int hi = s > r ? s : r, lo = s > r ? r : s;
+                const int off = inp ? hi * (hi + 1) / 2 + lo : ((lower && s > r) ? s * n + r : r * n + s);
+                m[rt][kk] = (ok && r < n && s < n) ? Mb[off] : 0.0;
             }
     };
 
@@ -291,9 +296,9 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             if (!rsl) {
                 for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) out[(int64_t)rs * n2 + Cc] = stage[rs * QP + wl];
             } else if (a.out_pairs) {
-                // dense (pair, pair) result: row tri(r',s'), column = the leading pair's own triangle index, and the
-                // multiplicity of the leading pair folded in (the consumer is a plain dot over v = tri(p,q))
-                const double mq = (wp != wq) ? 2.0 : 1.0;
+                // dense (pair, pair) result: row tri(r',s'), column = the leading pair's own triangle index; with
+                // out_pairs = 2 the multiplicity of the leading pair is folded in (the consumer is a plain dot)
+                const double mq = (a.out_pairs > 1 && wp != wq) ? 2.0 : 1.0;
                 const int e = t * QT + wl;
                 for (int u = threadIdx.x >> 3; u < npairs; u += 32) out[(int64_t)u * npairs + e] = stage[u * QP + wl] * mq;
             } else {
@@ -630,8 +635,41 @@ __global__ __launch_bounds__(256) void unpack8_half_kernel(const double *__restr
     }
 }
 
+// Dense (pair, pair) form of the same: SB[u][v] = 4 p8[tri(max(u,v), min(u,v))], u = tri(i,j), v = tri(k,l) -- the
+// symmetric matrix the compressed vector is the lower triangle of.  One wave per row u.
+__global__ __launch_bounds__(256) void unpack8_pairs_kernel(const double *__restrict__ p, int64_t sp, int n,
+                                                            double *__restrict__ SB, int64_t sws, int count) {
+    const int npairs = n * (n + 1) / 2;
+    const int bpg = (npairs + 3) / 4;   // workgroups per geometry
+    const int nx = count & ~7;
+    const int64_t nxblocks = (int64_t)nx * bpg;
+    int geom, blk;
+    if ((int64_t)blockIdx.x < nxblocks) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        geom = (slot / bpg) * 8 + xcd;
+        blk = slot % bpg;
+    } else {
+        const int64_t b = (int64_t)blockIdx.x - nxblocks;
+        geom = nx + (int)(b / bpg);
+        blk = (int)(b % bpg);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = blk * 4 + wave;
+    if (u >= npairs) return;
+    p += (int64_t)geom * sp;
+    double *sb = SB + (int64_t)geom * sws + (int64_t)u * npairs;
+    for (int v = lane; v < npairs; v += 64) sb[v] = 4.0 * (u >= v ? p[tri_index(u, v)] : p[tri_index(v, u)]);
+}
+
 int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t sws, double *G, int64_t sG, int count,
                    int lead_half, hipStream_t st) {
+    if (lead_half == 2 && !G) {
+        const int bpg = (n * (n + 1) / 2 + 3) / 4;
+        hipLaunchKernelGGL(unpack8_pairs_kernel, dim3((unsigned)(bpg * count)), dim3(256), 0, st, packed, sp, n, SB,
+                           sws, count);
+        EVC_LAUNCH_CHECK("unpack8_pairs");
+        return 0;
+    }
     if (lead_half && !G) {
         const int bpg = (n * (n + 1) / 2 + 3) / 4;
         hipLaunchKernelGGL(unpack8_half_kernel, dim3((unsigned)(bpg * count)), dim3(256), 0, st, packed, sp, n, SB, sws,
@@ -784,7 +822,7 @@ __global__ __launch_bounds__(256) void y2_sb_kernel(const double *__restrict__ S
 // A K step covers 8 consecutive l of one (j,k) row: k/8 + 1 steps per row.
 template <int NT>
 __global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__ SB, const double *__restrict__ K3,
-                                                      int n, double *__restrict__ partial, int64_t sws) {
+                                                      int n, double *__restrict__ partial, int64_t sws, int pairs) {
     __shared__ double red[4][NT * 16][NT * 16 + 1];
     SB += (int64_t)blockIdx.y * sws;
     K3 += (int64_t)blockIdx.y * sws;
@@ -798,7 +836,9 @@ __global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__
     const int64_t per = (nsteps + nw - 1) / nw;
     const int64_t w = (int64_t)blockIdx.x * 4 + wave;
     const int64_t s0 = w * per, s1 = min(nsteps, s0 + per);
-    const bool even = (n & 1) == 0;  // every (i,j,k) row of SB starts 16-byte aligned
+    // pairs: SB is the dense (pair, pair) matrix SB[tri(i,j)][tri(k,l)] (rows are not 16-byte aligned)
+    const int npairs = n * (n + 1) / 2;
+    const bool even = (n & 1) == 0 && !pairs;  // every (i,j,k) row of SB starts 16-byte aligned
     d4 acc[NT][NT];
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
@@ -822,7 +862,8 @@ __global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__
             const bool iok = i < n;
             const int ii = iok ? i : 0;
             const int hi = ii > j ? ii : j, lo = ii > j ? j : ii;
-            const double *ap = SB + (((int64_t)hi * n + lo) * n + k) * n + l;
+            const double *ap = pairs ? SB + (int64_t)(hi * (hi + 1) / 2 + lo) * npairs + k * (k + 1) / 2 + l
+                                     : SB + (((int64_t)hi * n + lo) * n + k) * n + l;
             double2 af;
             if (even) af = (iok && v0) ? *reinterpret_cast<const double2 *>(ap) : make_double2(0.0, 0.0);
             else af = make_double2((iok && v0) ? ap[0] : 0.0, (iok && v1) ? ap[1] : 0.0);
@@ -854,14 +895,15 @@ __global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__
     }
 }
 
-int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
+int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, int pairs,
+                   hipStream_t st) {
     const int nt = (n + 15) / 16;
     const dim3 grid(kY2Slabs, (unsigned)count);
     switch (nt) {
-        case 1: hipLaunchKernelGGL(y2_fold_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
-        case 2: hipLaunchKernelGGL(y2_fold_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
-        case 3: hipLaunchKernelGGL(y2_fold_kernel<3>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
-        case 4: hipLaunchKernelGGL(y2_fold_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
+        case 1: hipLaunchKernelGGL(y2_fold_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
+        case 2: hipLaunchKernelGGL(y2_fold_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
+        case 3: hipLaunchKernelGGL(y2_fold_kernel<3>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
+        case 4: hipLaunchKernelGGL(y2_fold_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
         default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
     }
     EVC_LAUNCH_CHECK("y2_fold");
