@@ -79,9 +79,10 @@ def parse():
     p.add_argument("--shard", default="geometries", choices=["geometries", "pairs"],
                    help="what is distributed over the ranks when --gpus N > 1")
     p.add_argument("--no-second-mode", action="store_true", help="N > 1: skip the leg for the other --shard mode")
-    p.add_argument("--ip1", default="packed", choices=["packed", "full"],
-                   help="int2e_ip1 input of the sym8 legs: packed in its last two AO indices (PySCF aosym='s2kl', "
-                        "EVC_FLAG_IP1_S2KL) or the full (3,N,N,N,N) array; other layouts always take the full array")
+    p.add_argument("--integrals", default="packed", choices=["packed", "full"],
+                   help="two-electron AO integrals of the sym8 legs: packed as PySCF delivers them with aosym='s4' "
+                        "(int2e, EVC_FLAG_ERI_S4) and aosym='s2kl' (int2e_ip1, EVC_FLAG_IP1_S2KL), or the full "
+                        "(N,N,N,N) / (3,N,N,N,N) arrays; other layouts always take the full arrays")
     return p.parse_args()
 
 
@@ -251,9 +252,11 @@ def main():
     aos = geometries(seed * 1000 + (0 if pairs_first else rank * a.geoms))
     # what the sym8 legs are fed: the same integrals with int2e_ip1 packed in (r,s), gathered on the device here,
     # outside every timed region -- the form PySCF delivers with aosym="s2kl"
-    packed_ip1 = a.layout == "sym8" and a.ip1 == "packed" and n <= 32 and not a.energy_only
-    run_view = (lambda lst: [x.packed_ip1() for x in lst]) if packed_ip1 else (lambda lst: lst)
-    aos_run = run_view(aos)
+    packed_ip1 = a.layout == "sym8" and a.integrals == "packed" and n <= 32
+    # (pair sharding goes through the phase entry points, which take the full int2e)
+    run_view = ((lambda lst, phases=False: [x.packed_ip1(eri=not phases) for x in lst]) if packed_ip1
+                else (lambda lst, phases=False: lst))
+    aos_run = run_view(aos, pairs_first)
     m = measure(trd, aos_run, G, 1 if pairs_first else S, a.steps, a.warmup, pairs_first)
 
     out = None
@@ -293,7 +296,7 @@ def main():
             "config": {"workload": f"{a.workload}: N={n} orbitals, A={A} atoms, T={T} training states, "
                                    f"two-body t-RDM layout {a.layout} ({rows}x{cols} f64, "
                                    f"{rows * cols * 8 / 1e9:.3f} GB resident in HBM), int2e_ip1 "
-                                   f"{'packed in its last two AO indices (s2kl)' if packed_ip1 else 'full'}, "
+                                   f"{'and int2e packed as PySCF aosym s2kl / s4' if packed_ip1 else 'and int2e full'}, "
                                    f"{a.geoms} resident geometries "
                                    f"per GPU; step = {m['geometries_per_step']} {what} evaluations",
                        "parallelism": par,
@@ -316,7 +319,7 @@ def main():
         del aos
         # pair sharding needs identical geometries on all ranks, geometry sharding distinct ones
         aos2 = geometries(seed * 1000 + (0 if second_pairs else rank * a.geoms))
-        aos_run = run_view(aos2)
+        aos_run = run_view(aos2, second_pairs)
         m2 = measure(trd2, aos_run, G, 1 if second_pairs else S, a.steps, a.warmup, second_pairs)
         if rank == 0:
             out["pair_sharded" if second_pairs else "geometry_sharded"] = {
@@ -380,12 +383,13 @@ def main():
         # from the previous step (EVC_FLAG_WARM_START) as evcont_amd.MD_utils.get_scanner does
         from evcont_amd.evaluator import DeviceAO
         a0, a1 = aos_run[0], aos_run[1]
+        assert not a0.eri_s4 or a0.eri.dim() == 2
         nsteps = 40
         lerp = lambda x, y, t: torch.lerp(x, y, t)
         traj = [DeviceAO(S=lerp(a0.S, a1.S, t), hcore=lerp(a0.hcore, a1.hcore, t), eri=lerp(a0.eri, a1.eri, t),
                          enuc=(1 - t) * a0.enuc + t * a1.enuc, natm=a0.natm, ipovlp=lerp(a0.ipovlp, a1.ipovlp, t),
                          dhcore=lerp(a0.dhcore, a1.dhcore, t), eri_ip1=lerp(a0.eri_ip1, a1.eri_ip1, t),
-                         gnuc=lerp(a0.gnuc, a1.gnuc, t), aoslices=a0.aoslices, ip1_s2kl=a0.ip1_s2kl)
+                         gnuc=lerp(a0.gnuc, a1.gnuc, t), aoslices=a0.aoslices, ip1_s2kl=a0.ip1_s2kl, eri_s4=a0.eri_s4)
                 for t in (1e-3 * k for k in range(nsteps))]
         res = {}
         for name, warm in (("cold", False), ("warm", True)):

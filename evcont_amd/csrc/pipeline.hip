@@ -57,6 +57,7 @@ struct Geo {
     int64_t sS, sh, seri, sip, sdh, sip1, sgn;
     double enuc;             // used when enuc_dev == NULL
     const double *enuc_dev;  // [count]
+    int eri_s4;              // eri is the dense (pair, pair) matrix (EVC_FLAG_ERI_S4); set from the call's flags
 };
 struct Out {
     double *energy, *coeffs, *grad, *d_pred, *g_pred, *hmat;
@@ -215,9 +216,16 @@ static void replan(const evc_trdm_set *t, Ws &w, int count) {
 }
 
 // rows_out != NULL: the scaled two-body rows go to rows_out[g*srows_out + r] (r local) instead of the workspace.
-static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool reduce_rows, hipStream_t st,
+static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool reduce_rows, hipStream_t st,
                              double *rows_out = nullptr, int64_t srows_out = 0) {
-    const int n = t->n, cnt = g.count;
+    const int n = t->n, cnt = g_in.count;
+    Geo g = g_in;
+    if (g.eri_s4) {
+        EVC_REQUIRE(is_sym8(t->layout) && use_pair_transform(n),
+                    "EVC_FLAG_ERI_S4 needs the compressed layout (EVC_LAYOUT_SYM8) and N <= 32");
+        const int64_t npr = (int64_t)n * (n + 1) / 2;
+        if (cnt > 1) g.seri = npr * npr;
+    }
     const int64_t sw = w.stride;
     int rc;
     replan(t, w, cnt);
@@ -263,6 +271,7 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g, Ws &w, bool re
             // produces the q <= p half of its output and the second one reads the lower triangles
             // (in_lower: eri[p,q,r,s] = eri[p,q,s,r]; rs_lower: the next step's leading pairs are (r',s'), s' <= r')
             pa.lead_sym = pa.in_lower = pa.rs_lower = is_sym8(t->layout) ? 1 : 0;
+            pa.in_pairs = g.eri_s4;       // int2e handed over as the dense (pair, pair) matrix (EVC_FLAG_ERI_S4)
             pa.out_pairs = pa.lead_sym;   // the intermediate as a dense (pair, pair) matrix
             int pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
             if ((rc = launch_pair_transform(pa, cc, st))) return rc;
@@ -782,10 +791,12 @@ extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g
     const Out o = out_single(out);
     int rc;
     w.warm = (flags & EVC_FLAG_WARM_START) != 0;
-    if ((rc = phase_hamiltonian(t, geo, w, false, st))) return rc;
-    if ((rc = phase_solve(t, geo, nullptr, 0, o, nroots, w, st))) return rc;
+    Geo gg = geo;
+    gg.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
+    if ((rc = phase_hamiltonian(t, gg, w, false, st))) return rc;
+    if ((rc = phase_solve(t, gg, nullptr, 0, o, nroots, w, st))) return rc;
     if (energy_only) return 0;
-    return phase_gradient(t, geo, o, flags & ~EVC_FLAG_PARTIAL_RANK, w, st);
+    return phase_gradient(t, gg, o, flags & ~EVC_FLAG_PARTIAL_RANK, w, st);
 }
 
 // Shared argument checking / descriptor set-up of the batch entry points.
@@ -857,6 +868,7 @@ extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geome
     hipStream_t st = as_stream(stream);
     int rc;
     w.warm = (flags & EVC_FLAG_WARM_START) != 0;
+    g.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
     if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
     if ((rc = phase_solve(t, g, nullptr, 0, o, nroots, w, st))) return rc;
     if (energy_only) return 0;

@@ -247,20 +247,32 @@ class DeviceAO:
     gnuc: Optional[torch.Tensor] = None
     aoslices: Optional[torch.Tensor] = None
     ip1_s2kl: bool = False   # eri_ip1 is (3,N,N,N(N+1)/2): packed in its last two indices (EVC_FLAG_IP1_S2KL)
+    eri_s4: bool = False     # eri is (N(N+1)/2, N(N+1)/2): packed in both index pairs (EVC_FLAG_ERI_S4)
 
     @property
     def nao(self) -> int:
         return int(self.S.shape[0])
 
     @staticmethod
-    def from_arrays(ao, device=None, energy_only: bool = False, pack_ip1: bool = False) -> "DeviceAO":
+    def from_arrays(ao, device=None, energy_only: bool = False, pack_ip1: bool = False,
+                    pack_eri: bool = False) -> "DeviceAO":
         """From any object with the AOArrays fields (numpy).  ``pack_ip1``: upload ``eri_ip1`` packed in its last
         two AO indices (half the bytes; what ``mol.intor("int2e_ip1", aosym="s2kl")`` returns -- an ``eri_ip1`` that
-        already has that shape is taken as is); only for evaluators on the compressed ``sym8`` layout."""
+        already has that shape is taken as is); ``pack_eri``: upload ``eri`` packed in both index pairs (a quarter of
+        the bytes, ``aosym="s4"``; a 2-D ``eri`` of that shape is taken as is).  Both only for evaluators on the
+        compressed ``sym8`` layout."""
         d = _dev(device)
         up = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(d)
-        out = DeviceAO(S=up(ao.S), hcore=up(ao.hcore), eri=up(ao.eri), enuc=float(ao.enuc),
-                       natm=int(np.asarray(ao.aoslices).shape[0]))
+        n = int(np.asarray(ao.S).shape[0])
+        npr = n * (n + 1) // 2
+        eri = np.asarray(ao.eri)
+        s4 = eri.ndim == 2 and eri.shape == (npr, npr) and n > 1
+        if pack_eri and not s4:
+            iu, ju = np.tril_indices(n)
+            eri = eri.reshape(n, n, n, n)[iu, ju][:, iu, ju]
+            s4 = True
+        out = DeviceAO(S=up(ao.S), hcore=up(ao.hcore), eri=up(eri), enuc=float(ao.enuc),
+                       natm=int(np.asarray(ao.aoslices).shape[0]), eri_s4=s4)
         if not energy_only:
             ip1 = np.asarray(ao.eri_ip1)
             n = out.nao
@@ -275,17 +287,21 @@ class DeviceAO:
             out.aoslices = torch.from_numpy(np.ascontiguousarray(ao.aoslices, dtype=np.int64)).to(d)
         return out
 
-    def packed_ip1(self) -> "DeviceAO":
-        """A copy (sharing every other array) whose ``eri_ip1`` is packed in its last two indices, gathered on the
-        device from the full array."""
-        if self.ip1_s2kl or self.eri_ip1 is None:
-            return self
+    def packed_ip1(self, eri: bool = False) -> "DeviceAO":
+        """A copy (sharing every other array) whose ``eri_ip1`` is packed in its last two indices (and, with
+        ``eri=True``, whose ``eri`` is packed in both index pairs), gathered on the device from the full arrays."""
         n = self.nao
         iu, ju = np.tril_indices(n)
-        idx = torch.from_numpy((iu * n + ju).astype(np.int64)).to(self.eri_ip1.device)
-        ip1 = self.eri_ip1.reshape(3, n, n, n * n).index_select(3, idx).contiguous()
-        return DeviceAO(S=self.S, hcore=self.hcore, eri=self.eri, enuc=self.enuc, natm=self.natm, ipovlp=self.ipovlp,
-                        dhcore=self.dhcore, eri_ip1=ip1, gnuc=self.gnuc, aoslices=self.aoslices, ip1_s2kl=True)
+        idx = torch.from_numpy((iu * n + ju).astype(np.int64)).to(self.S.device)
+        ip1, s2kl = self.eri_ip1, self.ip1_s2kl
+        if ip1 is not None and not s2kl:
+            ip1, s2kl = ip1.reshape(3, n, n, n * n).index_select(3, idx).contiguous(), True
+        e, s4 = self.eri, self.eri_s4
+        if eri and not s4:
+            e, s4 = e.reshape(n * n, n * n).index_select(0, idx).index_select(1, idx).contiguous(), True
+        return DeviceAO(S=self.S, hcore=self.hcore, eri=e, enuc=self.enuc, natm=self.natm, ipovlp=self.ipovlp,
+                        dhcore=self.dhcore, eri_ip1=ip1, gnuc=self.gnuc, aoslices=self.aoslices, ip1_s2kl=s2kl,
+                        eri_s4=s4)
 
     def cstruct(self) -> Geometry:
         p = lambda t: (t.data_ptr() if t is not None else None)
@@ -309,6 +325,7 @@ class DeviceAOBatch:
     gnuc: Optional[torch.Tensor] = None      # (G,A,3)
     aoslices: Optional[torch.Tensor] = None  # (A,2) int64, shared
     ip1_s2kl: bool = False                   # eri_ip1 is (G,3,N,N,N(N+1)/2) (EVC_FLAG_IP1_S2KL)
+    eri_s4: bool = False                     # eri is (G,N(N+1)/2,N(N+1)/2) (EVC_FLAG_ERI_S4)
 
     @property
     def count(self) -> int:
@@ -322,18 +339,19 @@ class DeviceAOBatch:
     def stack(aos) -> "DeviceAOBatch":
         """Stack single-geometry ``DeviceAO`` objects (device-to-device copies)."""
         aos = list(aos)
-        assert len({bool(a.ip1_s2kl) for a in aos}) == 1, "mixed full / packed eri_ip1 in one batch"
+        assert len({(bool(a.ip1_s2kl), bool(a.eri_s4)) for a in aos}) == 1, "mixed full / packed integrals in one batch"
         d = aos[0].S.device
         st = lambda name: (torch.stack([getattr(a, name) for a in aos]).contiguous()
                            if getattr(aos[0], name) is not None else None)
         return DeviceAOBatch(S=st("S"), hcore=st("hcore"), eri=st("eri"),
                              enuc=torch.tensor([a.enuc for a in aos], dtype=F64, device=d), natm=aos[0].natm,
                              ipovlp=st("ipovlp"), dhcore=st("dhcore"), eri_ip1=st("eri_ip1"), gnuc=st("gnuc"),
-                             aoslices=aos[0].aoslices, ip1_s2kl=bool(aos[0].ip1_s2kl))
+                             aoslices=aos[0].aoslices, ip1_s2kl=bool(aos[0].ip1_s2kl), eri_s4=bool(aos[0].eri_s4))
 
     @staticmethod
-    def from_arrays(ao_list, device=None, energy_only: bool = False, pack_ip1: bool = False) -> "DeviceAOBatch":
-        return DeviceAOBatch.stack([DeviceAO.from_arrays(a, device, energy_only, pack_ip1) for a in ao_list])
+    def from_arrays(ao_list, device=None, energy_only: bool = False, pack_ip1: bool = False,
+                    pack_eri: bool = False) -> "DeviceAOBatch":
+        return DeviceAOBatch.stack([DeviceAO.from_arrays(a, device, energy_only, pack_ip1, pack_eri) for a in ao_list])
 
     def cstruct(self) -> "_lib.GeometryBatch":
         p = lambda t: (t.data_ptr() if t is not None else None)
@@ -343,13 +361,13 @@ class DeviceAOBatch:
 
 
 def _ip1_flag(trdms: "DeviceTRDMs", ao) -> int:
-    """EVC_FLAG_IP1_S2KL for geometries whose ``eri_ip1`` is packed in its last two indices."""
-    if not getattr(ao, "ip1_s2kl", False):
-        return 0
-    if trdms.layout != _lib.LAYOUT_SYM8 or trdms.n > 32:
-        raise _lib.EvcontHipError("a packed (s2kl) eri_ip1 needs training data in the compressed sym8 layout and "
-                                  "N <= 32 (DeviceAO.from_arrays(..., pack_ip1=False) otherwise)")
-    return _lib.FLAG_IP1_S2KL
+    """EVC_FLAG_IP1_S2KL / EVC_FLAG_ERI_S4 for geometries whose integrals are handed over packed."""
+    f = (_lib.FLAG_IP1_S2KL if getattr(ao, "ip1_s2kl", False) else 0) | \
+        (_lib.FLAG_ERI_S4 if getattr(ao, "eri_s4", False) else 0)
+    if f and (trdms.layout != _lib.LAYOUT_SYM8 or trdms.n > 32):
+        raise _lib.EvcontHipError("packed (s2kl / s4) integrals need training data in the compressed sym8 layout and "
+                                  "N <= 32 (DeviceAO.from_arrays(..., pack_ip1=False, pack_eri=False) otherwise)")
+    return f
 
 
 class BatchedEvaluator:
@@ -407,6 +425,8 @@ class BatchedEvaluator:
         """Scaled two-body rows of this rank's pairs -> ``rows_out[g, :rows_local]`` (row stride = rows_out.stride(0))."""
         assert rows_out.dtype == F64 and rows_out.dim() == 2 and rows_out.shape[0] == self.count
         assert rows_out.stride(1) == 1 and rows_out.shape[1] >= self.t.rows_local
+        if aob.eri_s4:
+            raise _lib.EvcontHipError("the phase entry points take the full eri (no EVC_FLAG_ERI_S4)")
         g = aob.cstruct()
         rc = self.lib.evc_phase_hamiltonian_batch(C.byref(self.t.cstruct), C.byref(g), rows_out.data_ptr(),
                                                   int(rows_out.stride(0)), self.ws.data_ptr(), self.ws_bytes, self._sp())
@@ -509,6 +529,8 @@ class ContinuationEvaluator:
     # -- phase API for the pair-sharded multi-GPU host (evcont_amd/distributed.py) -----------------
     def phase_hamiltonian(self, ao: DeviceAO) -> torch.Tensor:
         """Returns a view of this rank's scaled two-body rows (length rows_local) in the workspace."""
+        if ao.eri_s4:
+            raise _lib.EvcontHipError("the phase entry points take the full eri (no EVC_FLAG_ERI_S4)")
         g = ao.cstruct()
         p_rows, p_h1 = C.c_void_p(), C.c_void_p()
         rc = self.lib.evc_phase_hamiltonian(C.byref(self.t.cstruct), C.byref(g), self.ws.data_ptr(), self.ws_bytes,

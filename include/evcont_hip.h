@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define EVC_ABI_VERSION 4 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
-                             3: EVC_LAYOUT_SYM8; 4: evc_profile_stage, EVC_FLAG_IP1_S2KL */
+                             3: EVC_LAYOUT_SYM8; 4: evc_profile_stage/_select, EVC_FLAG_IP1_S2KL, EVC_FLAG_ERI_S4 */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
@@ -202,6 +202,10 @@ typedef struct evc_outputs {
                                    mol.intor("int2e_ip1", aosym="s2kl").  Half the bytes of the largest input; the
                                    contraction then streams dense rows.  Only with EVC_LAYOUT_SYM8 and N <= 32 (the
                                    path that uses the r <-> s symmetry of int2e_ip1 anyway). */
+#define EVC_FLAG_ERI_S4 16      /* geometry.eri is the dense (Ms,Ms) matrix, Ms = N(N+1)/2 [per geometry of a batch]: int2e
+                                   packed in both index pairs, element (p(p+1)/2+q, r(r+1)/2+s), p >= q, r >= s -- what PySCF
+                                   returns for mol.intor("int2e", aosym="s4").  A quarter of the bytes.  Fused entry points,
+                                   EVC_LAYOUT_SYM8 and N <= 32 only. */
 
 size_t evc_workspace_bytes(const evc_trdm_set *t, int natm);
 

@@ -249,6 +249,20 @@ def test_packed_ip1_input(n, T, A):
         Eo, go = orc.energy_with_grad(bundle(aos[k]), one, two_l, S)
         assert abs(Eb[k] - Eo) < 1e-9
         np.testing.assert_allclose(gb[k], go, rtol=0, atol=1e-8)
+    # int2e packed in both index pairs as well (aosym="s4"): host-packed and device-gathered, energy-only too
+    dao4 = DeviceAO.from_arrays(aos[0], dev, pack_ip1=True, pack_eri=True)
+    npr = n * (n + 1) // 2
+    assert dao4.eri_s4 and tuple(dao4.eri.shape) == (npr, npr)
+    assert torch.equal(DeviceAO.from_arrays(aos[0], dev).packed_ip1(eri=True).eri, dao4.eri)
+    E4, g4 = ev.energy_with_grad(dao4)
+    Eo, go = orc.energy_with_grad(bundle(aos[0]), one, two_l, S)
+    assert abs(E4 - Eo) < 1e-10
+    np.testing.assert_allclose(g4, go, rtol=0, atol=1e-9)
+    e4, _ = ev.energies(DeviceAO.from_arrays(aos[0], dev, energy_only=True, pack_eri=True), 1)
+    assert abs(e4[0] - Eo) < 1e-10
+    Eb4, gb4 = be.energies_with_grads(DeviceAOBatch.from_arrays(aos, dev, pack_ip1=True, pack_eri=True))
+    np.testing.assert_allclose(Eb4, Eb, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(gb4, gb, rtol=0, atol=1e-10)
     # the packed form is only understood by the symmetric pipeline of the compressed layout
     plain = ContinuationEvaluator(DeviceTRDMs(one, two_l, S, dev), A)
     from evcont_amd._lib import EvcontHipError
