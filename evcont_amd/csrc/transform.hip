@@ -239,8 +239,12 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
                         for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
                 if (a.k3) {
-                    // lead_sym: only K3[s'][p][q][:] with q <= p is written (its consumer folds the p <-> q symmetry)
+                    // lead_sym: only K3[s'][p][q][:] with q <= p is written (its consumer folds the p <-> q symmetry),
+                    // as K3[s'][tri(p,q)][:] times the multiplicity of (p,q)
                     double *K3 = a.k3 + g * a.sk3;
+                    const double km = (sym && p != q) ? 2.0 : 1.0;
+                    const int64_t kcol = sym ? (int64_t)(p * (p + 1) / 2 + q) * n : (int64_t)p * n2 + (int64_t)q * n;
+                    const int64_t krow = sym ? (int64_t)npairs * n : (int64_t)n * n2;
 #pragma unroll
                     for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
                             for (int reg = 0; reg < 4; ++reg) {
                                 const int r = rt * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
-                                if (r < n && s2 < n) K3[((int64_t)s2 * n + p) * n2 + (int64_t)q * n + r] = h[rt][st][reg];
+                                if (r < n && s2 < n) K3[s2 * krow + kcol + r] = h[rt][st][reg] * km;
                             }
                 }
                 // N = X^T H : B operand of k-step kk is register kk%4 of H's row tile kk/4
@@ -816,10 +820,11 @@ __global__ __launch_bounds__(256) void y2_sb_kernel(const double *__restrict__ S
     }
 }
 
-// Folded form for the symmetric pipeline: SB is only valid for i >= j, l <= k and K3[j][k][l][:] only for l <= k;
-// both are symmetric under i <-> j resp. k <-> l, so
-//   partial[slab][i][a] = sum_j sum_{l <= k} (l < k ? 2 : 1) SB[max(i,j)][min(i,j)][k][l] K3[j][k][l][a].
-// A K step covers 8 consecutive l of one (j,k) row: k/8 + 1 steps per row.
+// Folded form for the symmetric pipeline: SB is only valid for i >= j, l <= k and K3 is K3p[j][tri(k,l)][:] =
+// (l < k ? 2 : 1) K3[j][k][l][:]; both are symmetric under i <-> j resp. k <-> l, so
+//   partial[slab][i][a] = sum_j sum_{l <= k} SB[max(i,j)][min(i,j)][k][l] K3p[j][tri(k,l)][a].
+// A K step covers 8 consecutive l of one (j,k) row: k/8 + 1 steps per row.  (Variant for the N^4-addressed SB that
+// is written when the caller wants the unpacked 2-RDM; the usual case is y2_pairs_kernel below.)
 template <int NT>
 __global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__ SB, const double *__restrict__ K3,
                                                       int n, double *__restrict__ partial, int64_t sws, int pairs) {
@@ -853,8 +858,8 @@ __global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__
         const int k = 8 * b + rp / (b + 1), ls = rp % (b + 1);
         const int l = ls * 8 + 2 * l4;  // this lane's K slots: l, l + 1
         const bool v0 = l <= k, v1 = l + 1 <= k;
-        const double w0 = l < k ? 2.0 : 1.0, w1 = l + 1 < k ? 2.0 : 1.0;
-        const double *kb = K3 + (((int64_t)j * n + k) * n + l) * n;
+        // (the weight 2 of l < k is folded into K3 by the pair transform that wrote it)
+        const double *kb = K3 + ((int64_t)j * npairs + k * (k + 1) / 2 + l) * n;
         double a0[NT], a1[NT], b0[NT], b1[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -867,8 +872,72 @@ __global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__
             double2 af;
             if (even) af = (iok && v0) ? *reinterpret_cast<const double2 *>(ap) : make_double2(0.0, 0.0);
             else af = make_double2((iok && v0) ? ap[0] : 0.0, (iok && v1) ? ap[1] : 0.0);
-            a0[t] = (iok && v0) ? af.x * w0 : 0.0;
-            a1[t] = (iok && v1) ? af.y * w1 : 0.0;
+            a0[t] = (iok && v0) ? af.x : 0.0;
+            a1[t] = (iok && v1) ? af.y : 0.0;
+            b0[t] = (iok && v0) ? kb[i] : 0.0;
+            b1[t] = (iok && v1) ? kb[n + i] : 0.0;
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(a0[ti], b0[ta], acc[ti][ta]);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(a1[ti], b1[ta], acc[ti][ta]);
+    }
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
+    __syncthreads();
+    double *dst = partial + (int64_t)blockIdx.x * n * n;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, a = idx % n;
+        dst[idx] = (red[0][i][a] + red[1][i][a]) + (red[2][i][a] + red[3][i][a]);
+    }
+}
+
+// The usual case: SB dense (pair, pair), SB[tri(i,j)][v], and K3p[j][v][:]: for every j one contiguous K range
+// v = 0..n(n+1)/2-1, 8 consecutive v per step.
+template <int NT>
+__global__ __launch_bounds__(256) void y2_pairs_kernel(const double *__restrict__ SB, const double *__restrict__ K3,
+                                                       int n, double *__restrict__ partial, int64_t sws) {
+    __shared__ double red[4][NT * 16][NT * 16 + 1];
+    SB += (int64_t)blockIdx.y * sws;
+    K3 += (int64_t)blockIdx.y * sws;
+    partial += (int64_t)blockIdx.y * sws;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int npairs = n * (n + 1) / 2;
+    const int spj = (npairs + 7) / 8;  // steps per j
+    const int64_t nsteps = (int64_t)n * spj;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int64_t per = (nsteps + nw - 1) / nw;
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t s0 = w * per, s1 = min(nsteps, s0 + per);
+    d4 acc[NT][NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int64_t s = s0; s < s1; ++s) {
+        const int j = (int)(s / spj);
+        const int v = (int)(s - (int64_t)j * spj) * 8 + 2 * l4;   // this lane's K slots: v, v + 1
+        const bool v0 = v < npairs, v1 = v + 1 < npairs;
+        const double *kb = K3 + ((int64_t)j * npairs + v) * n;
+        double a0[NT], a1[NT], b0[NT], b1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int i = t * 16 + l15;
+            const bool iok = i < n;
+            const int ii = iok ? i : 0;
+            const int hi = ii > j ? ii : j, lo = ii > j ? j : ii;
+            const double *ap = SB + (int64_t)(hi * (hi + 1) / 2 + lo) * npairs + v;
+            a0[t] = (iok && v0) ? ap[0] : 0.0;
+            a1[t] = (iok && v1) ? ap[1] : 0.0;
             b0[t] = (iok && v0) ? kb[i] : 0.0;
             b1[t] = (iok && v1) ? kb[n + i] : 0.0;
         }
@@ -897,6 +966,18 @@ __global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__
 
 int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, int pairs,
                    hipStream_t st) {
+    if (pairs) {
+        const dim3 grid(kY2Slabs, (unsigned)count);
+        switch ((n + 15) / 16) {
+            case 1: hipLaunchKernelGGL(y2_pairs_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
+            case 2: hipLaunchKernelGGL(y2_pairs_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
+            case 3: hipLaunchKernelGGL(y2_pairs_kernel<3>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
+            case 4: hipLaunchKernelGGL(y2_pairs_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
+            default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
+        }
+        EVC_LAUNCH_CHECK("y2_pairs");
+        return 0;
+    }
     const int nt = (n + 15) / 16;
     const dim3 grid(kY2Slabs, (unsigned)count);
     switch (nt) {
