@@ -698,8 +698,7 @@ static int y2_slab_count() {
     }();
     return v;
 }
-#define kY2Slabs y2_slab_count()
-int y2_slabs(int) { return kY2Slabs; }
+int y2_slabs(int) { return y2_slab_count(); }
 
 template <int NT>
 __global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT, const double *__restrict__ K3,
@@ -967,7 +966,7 @@ __global__ __launch_bounds__(256) void y2_pairs_kernel(const double *__restrict_
 int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, int pairs,
                    hipStream_t st) {
     if (pairs) {
-        const dim3 grid(kY2Slabs, (unsigned)count);
+        const dim3 grid((unsigned)y2_slab_count(), (unsigned)count);
         switch ((n + 15) / 16) {
             case 1: hipLaunchKernelGGL(y2_pairs_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
             case 2: hipLaunchKernelGGL(y2_pairs_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
@@ -979,7 +978,7 @@ int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, i
         return 0;
     }
     const int nt = (n + 15) / 16;
-    const dim3 grid(kY2Slabs, (unsigned)count);
+    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count);
     switch (nt) {
         case 1: hipLaunchKernelGGL(y2_fold_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
         case 2: hipLaunchKernelGGL(y2_fold_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
@@ -994,7 +993,7 @@ int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, i
 int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
     const int64_t ktot = (int64_t)n * n * n;
     const int nt = (n + 15) / 16;
-    const dim3 grid(kY2Slabs, (unsigned)count);
+    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count);
     switch (nt) {
         case 1: hipLaunchKernelGGL(y2_sb_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
         case 2: hipLaunchKernelGGL(y2_sb_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
@@ -1009,7 +1008,7 @@ int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int
 int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
     const int64_t ktot = (int64_t)n * n * n;
     const int nt = (n + 15) / 16;
-    const dim3 grid(kY2Slabs, (unsigned)count);
+    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count);
     switch (nt) {
         case 1: hipLaunchKernelGGL(y2_kernel<1>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
         case 2: hipLaunchKernelGGL(y2_kernel<2>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
