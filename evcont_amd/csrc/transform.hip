@@ -1029,8 +1029,8 @@ int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64
 // the t2part workspace)
 static int ip1_per_thread() {
     static const int pt = [] {
-        const int v = getenv("EVC_IP1_PT") ? atoi(getenv("EVC_IP1_PT")) : 4;
-        return (v == 8 || v == 16) ? v : 4;
+        const int v = getenv("EVC_IP1_PT") ? atoi(getenv("EVC_IP1_PT")) : 8;
+        return (v == 4 || v == 16) ? v : 8;
     }();
     return pt;
 }
