@@ -422,6 +422,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         if (a.Hout) a.Hout += g * a.sH;
         if (a.w1) a.w1 += g * a.sw;
         if (a.w2) a.w2 += g * a.sw;
+        if (a.w2t) a.w2t += (g - g % kMaxBatchG) * a.sw;
         if (a.vstd) a.vstd += g * a.sw;
         if (a.e_shift_dev) a.e_shift = a.e_shift_dev[g];
     }
@@ -588,6 +589,8 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
                 w = c0[ia] * c0[g - (int64_t)ia * T];
             }
             a.w2[r] = w;
+            // transposed copy for the batched K8: [row][slot] in the workspace of the group's first geometry
+            if (a.w2t) a.w2t[r * kMaxBatchG + (int)(blockIdx.x % kMaxBatchG)] = w;
         }
     }
 }

@@ -399,12 +399,17 @@ __global__ __launch_bounds__(256, MINW) void gemv_cols_mfma_rs_kernel(GemvColsLa
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t rows = P.rows, cols = P.cols, ld = P.ld;
     const int64_t c0 = (int64_t)bid * 32;
-    // lanes whose geometry slot is >= G read geometry g0's weights; their output rows are discarded
+    // lanes whose geometry slot is >= G read geometry g0's weights; their output rows are discarded.
+    // With a transposed copy (P.wt: [row][kMaxBatchG] per group of geometries) the 16 geometries of a K step are
+    // 128 contiguous bytes per row instead of 16 separate 32-byte segments.
     const double *__restrict__ wg[GS];
+    const bool wtr = P.wt != nullptr;
+    const int64_t wrs = wtr ? kMaxBatchG : 1;   // stride between rows
 #pragma unroll
     for (int gs = 0; gs < GS; ++gs) {
-        const int slot = 16 * gs + l15;
-        wg[gs] = P.w + (int64_t)(g0 + (slot < G ? slot : 0)) * P.wstride;
+        const int slot = 16 * gs + l15, gg = g0 + (slot < G ? slot : 0);
+        wg[gs] = wtr ? P.wt + (int64_t)(gg - gg % kMaxBatchG) * P.wstride + gg % kMaxBatchG
+                     : P.w + (int64_t)gg * P.wstride;
     }
     d4 ae[GS], ao[GS];
 #pragma unroll
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256, MINW) void gemv_cols_mfma_rs_kernel(GemvColsLa
             const bool live = r < rows;   // rows beyond the matrix: zero weight, address clamped to a valid row
             const double *row = P.A + (live ? r : rows - 1) * ld;
 #pragma unroll
-            for (int gs = 0; gs < GS; ++gs) wf[ks][gs] = live ? wg[gs][r] : 0.0;
+            for (int gs = 0; gs < GS; ++gs) wf[ks][gs] = live ? wg[gs][r * wrs] : 0.0;
             if (inside) x[ks] = ld2(row + cl);
             else x[ks] = ld2_guard(row, cl, cols);
         }

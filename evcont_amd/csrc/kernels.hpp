@@ -30,6 +30,8 @@ struct GemvRowsLaunch {
 struct ColProblem {
     const double *A;  // (rows, ld)                        shared by the batch
     const double *w;  // (rows)             + g*wstride
+    const double *wt; // (rows, kMaxBatchG) + (g - g % kMaxBatchG)*wstride: the same weights of a group of geometries,
+                      // transposed (geometry g in column g % kMaxBatchG), or NULL
     double *out;      // (cols)             + g*ostride
     int64_t rows, cols, ld, wstride, ostride;
 };
@@ -147,6 +149,8 @@ struct SolveArgs {
     const double *e_shift_dev;  // [count] or NULL
     double *evals, *evecs, *Hout;  // + g*sev, + g*svec, + g*sH  (Hout may be NULL)
     double *w2, *w1;               // + g*sw
+    double *w2t;                   // (w2_count, kMaxBatchG) or NULL: w2 of the geometries of a group of kMaxBatchG,
+                                   // transposed, in the workspace of the group's first geometry (+ (g - g%32)*sw)
     int64_t sh1, sh2, sev, svec, sH, sw;
     int64_t w2_offset, w2_count;  // slice of the global weight vector to write (multi-GPU)
     double *vstd;                 // (m,m), m = T rounded up to even: standard-form eigenvectors, kept in the

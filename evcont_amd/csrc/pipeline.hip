@@ -71,7 +71,7 @@ struct Ws {
     double *B1, *B2, *K3, *G;
     double *vec2;  // ld2-long vector: packed h2 (phase A) / packed predicted 2-RDM (phase C)
     // t-RDM contraction
-    double *h2part, *h1part, *h2rows, *w2, *w1;
+    double *h2part, *h1part, *h2rows, *w2, *w1, *w2t;
     // gradient partials
     double *y2part, *y2, *t2part, *term3;
     // scratch outputs when the caller passes NULL
@@ -166,6 +166,7 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.h1part = take((size_t)T * T * w.rp1.nspans);
     w.h2rows = take((size_t)t->rows2_total);
     w.w2 = take((size_t)t->rows2 + 1);
+    w.w2t = take((size_t)t->rows2 * kMaxBatchG + 1);
     w.w1 = take(T * T);
     w.y2part = take((size_t)y2_slabs((int)n) * n2);
     w.y2 = take(n2);
@@ -381,6 +382,7 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
     a.Hout = out.hmat;
     a.sH = out.sH;
     a.w2 = w.w2;
+    a.w2t = g.count > 1 ? w.w2t : nullptr;
     a.w1 = w.w1;
     a.sw = sw;
     a.w2_offset = t->row_offset;
@@ -589,6 +591,7 @@ static int phase_gradient(const evc_trdm_set *t, const Geo &g_in, const Out &out
     ColProblem c2{}, c1{};
     c2.A = t->two_rdm;
     c2.w = w.w2;
+    c2.wt = cnt > 1 ? w.w2t : nullptr;
     c2.wstride = sw;
     c2.rows = t->rows2;
     c2.cols = t->cols2;
