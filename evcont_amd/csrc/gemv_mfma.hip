@@ -208,6 +208,11 @@ __global__ __launch_bounds__(256, MINW) void gemv_rows_mfma_pipe_kernel(GemvRows
         if constexpr (PIPE) rows_pipe_body<NT_, MAXT, GS>(P, row_base, cbeg, cend, vr, l15, l4, wave, acc); \
         else rows_lean_body<NT_, MAXT, GS>(P, row_base, cbeg, cend, vr, l15, l4, wave, acc);        \
     }
+    if constexpr (MAXT >= 7) {
+        if (ntile == 7) EVC_ROWS_BODY(7)  // wave-uniform
+        if (ntile == 6) EVC_ROWS_BODY(6)
+        if (ntile == 5) EVC_ROWS_BODY(5)
+    }
     if constexpr (MAXT >= 4) {
         if (ntile == 4) EVC_ROWS_BODY(4)  // wave-uniform
     }
@@ -246,9 +251,13 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, h
     // shape code = 100*MAXT + 10*MINW + PIPE (EVC_ROWS_SHAPE / EVC_ROWS_SHAPE2 for one / two geometry sets)
     static const int sh1 = getenv("EVC_ROWS_SHAPE") ? atoi(getenv("EVC_ROWS_SHAPE")) : 421;
     static const int sh2 = getenv("EVC_ROWS_SHAPE2") ? atoi(getenv("EVC_ROWS_SHAPE2")) : 321;
-    const int shape = gs == 2 ? sh2 : sh1;
+    // narrow matrices (the 8-fold compressed layout, < 200 000 columns): the vectors of the 32 geometries weigh as
+    // much as the matrix itself when five row groups re-read them; two groups of seven tiles on ONE wave per SIMD
+    // (512 registers) read them twice: 66 against 76 us at 108 345 columns -- and 270 against 222 us at 405 450
+    static const int sh2n = getenv("EVC_ROWS_SHAPE2_NARROW") ? atoi(getenv("EVC_ROWS_SHAPE2_NARROW")) : 711;
+    const int shape = gs == 2 ? (Lin.p[0].cols <= 200000 ? sh2n : sh2) : sh1;
     const int kernel_maxt = shape / 100;
-    int max_tiles = tiles <= 0 ? (kernel_maxt >= 3 ? 3 : kernel_maxt) : tiles;   // see the measurements above
+    int max_tiles = tiles <= 0 ? (kernel_maxt >= 7 ? 7 : kernel_maxt >= 3 ? 3 : kernel_maxt) : tiles;   // see the measurements above
     if (max_tiles > kernel_maxt) max_tiles = kernel_maxt;
     for (int k = 0; k < 2; ++k) {
         // balanced row groups of at most max_tiles tiles
@@ -269,8 +278,8 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, h
         break;
     if (gs == 2) {
         switch (shape) {
-            // in situ, G=32: pipelined 321 -> 226 us; lean 330 -> 238, 230 -> 247, 240 -> 259, 150 -> 300
-            EVC_ROWS_CASE(2, 3, 2, 1) EVC_ROWS_CASE(2, 3, 3, 0) EVC_ROWS_CASE(2, 2, 4, 0)
+            // in situ, G=32: pipelined 321 -> 226 us; lean 330 -> 238, 230 -> 247, 240 -> 259, 150 -> 300; 711 -> 270
+            EVC_ROWS_CASE(2, 3, 2, 1) EVC_ROWS_CASE(2, 3, 3, 0) EVC_ROWS_CASE(2, 2, 4, 0) EVC_ROWS_CASE(2, 7, 1, 1)
             default: set_error("gemv_rows_mfma: unknown EVC_ROWS_SHAPE2=%d", shape); return -1;
         }
     } else {
