@@ -127,14 +127,31 @@ def cpu_baseline(workload, layout_nd, trd, aos, samples):
                       f"(layout ndim {layout_nd}) by oracle/evcont_oracle.py (numpy/OpenBLAS), median, after 1 warm-up"}
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as fresh child processes through
+    torch.distributed.run -- nothing in THIS process has touched the GPU yet (torch is imported, no device call) --
+    stream their output through and return the launcher's exit code.  Never exec: a child per rank."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // ngpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # EVC_BENCH_BACKEND=gloo lets several ranks share one card (rehearsal on a one-GPU box); RCCL needs a card per rank
@@ -229,8 +246,12 @@ def main():
         runners[0].enqueue(inputs[0], 1, a.energy_only)
         fence()
         e_check = float(evs[0].energy.reshape(-1)[0].item())
+        per_rank = [steps * G / dt]          # this rank's own rate (its G geometries per step over ITS wall time)
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(every, tt)
+            per_rank = [steps * G / float(x.item()) for x in every]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         gl = min(G, MAX_G_PER_LAUNCH)                  # geometries per launch of the streaming kernels
@@ -246,7 +267,7 @@ def main():
                 "k5_ms": k5, "k8_ms": k8, "bytes_per_launch": nbytes, "launches": rows_n.value * lps,
                 "geometries_per_launch": gl, "k5_GBs": nbytes / (k5 * 1e-3) / 1e9,
                 "k8_GBs": (nbytes / (k8 * 1e-3) / 1e9) if k8 else None, "last_energy": e_last, "check_energy": e_check,
-                "stages": stages,
+                "stages": stages, "per_rank": per_rank,
                 "geometries_per_step": job_g}
 
     G, S = max(1, a.batch), max(1, a.streams)
@@ -314,6 +335,12 @@ def main():
                          "launches": m["launches"], "geometries_per_launch": m["geometries_per_launch"]},
             "kernels": {"k5_rows_ms": m["k5_ms"], "k8_cols_ms": m["k8_ms"], "k8_cols_GBs": m["k8_GBs"]},
             "last_energy": m["last_energy"],
+            # what the collectives library itself reports, and what each rank delivered on its own clock: in the
+            # geometry-sharded job a rank's figure is directly comparable with the N=1 run of the same command
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else None),
+            "visible_devices": ndev,
+            "per_rank_value": m["per_rank"],
         }
     if world > 1 and not a.no_second_mode:
         # the other way of using the node, same batch size, reported next to the headline

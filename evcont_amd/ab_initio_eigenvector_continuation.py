@@ -16,12 +16,6 @@ from .evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator, _dev
 from .integrals import ao_arrays, energy_nuc, is_array_mol
 
 
-def _nonhermitian_unsupported():
-    raise NotImplementedError(
-        "hermitian=False is not supported for the energy+gradient path: the reference's eig branch (:76-78) "
-        "returns 2-norm-normalised vectors, which mis-scale its own predicted RDMs; every script uses hermitian=True")
-
-
 def _eig_nonhermitian(H: np.ndarray, S: np.ndarray, layout: int):
     """The reference's non-Hermitian branch (:50-51,67-68,76-81) on the subspace matrix assembled by the
     device: pair layouts carry the two-body part in the lower triangle only, so the upper one is filled

@@ -7,7 +7,7 @@ import torch
 
 from . import gradients as G
 from . import ops
-from .ab_initio_eigenvector_continuation import _evaluator, _nonhermitian_unsupported, approximate_ground_state  # noqa: F401
+from .ab_initio_eigenvector_continuation import _evaluator, approximate_ground_state  # noqa: F401
 from .electron_integral_utils import get_loewdin_trafo, restore_electron_exchange_symmetry  # noqa: F401
 from .evaluator import DeviceAO, _dev
 from .integrals import ao_arrays, grad_nuc, is_array_mol
@@ -89,9 +89,13 @@ def get_energy_with_grad(mol, one_RDM, two_RDM, S, hermitian=True, return_densit
 
     The t-RDMs are uploaded once (``evcont_amd.cache``) and stay resident; each call ships only
     the AO integrals of the new geometry and enqueues one fused device pipeline."""
-    if not hermitian:
-        _nonhermitian_unsupported()
     ao = ao_arrays(mol, need_grad=True)
-    ev = _evaluator(one_RDM, two_RDM, S, int(np.asarray(ao.aoslices).shape[0]))
+    natm = int(np.asarray(ao.aoslices).shape[0])
+    if not hermitian:
+        # the eig branch works on the subspace matrix of the layout the caller passed (no sym8 compression)
+        ev = _evaluator(one_RDM, two_RDM, S, natm, compress=None)
+        return ev.energy_with_grad_nonhermitian(DeviceAO.from_arrays(ao, ev.t.device),
+                                                return_density_matrices=return_density_matrices)
+    ev = _evaluator(one_RDM, two_RDM, S, natm)
     dao = DeviceAO.from_arrays(ao, ev.t.device)
     return ev.energy_with_grad(dao, return_density_matrices=return_density_matrices)

@@ -5,7 +5,10 @@ The reference API passes the (possibly multi-GB) t-RDM arrays to every call
 ``MD_utils.py:43-50``).  The device path must not re-upload them each time, so the host
 arrays are fingerprinted (address, shape, strides, dtype + a strided content sample) and
 the corresponding ``DeviceTRDMs``/``ContinuationEvaluator`` are kept in a small LRU.
-Callers that mutate an array in place between calls should call :func:`clear`.
+Callers that mutate an array in place between calls should call :func:`clear` (the containers do so on
+``append_to_rdms`` / ``prune_datapoints``); ``EVCONT_AMD_CACHE_STRICT=1`` fingerprints the WHOLE array on every
+call instead of a sample (what the reference effectively does by re-reading it: exact, but a 2.6 GB t-RDM then costs
+a full host pass per call).
 """
 from __future__ import annotations
 
@@ -16,6 +19,7 @@ from typing import Tuple
 import numpy as np
 
 _MAX = int(os.environ.get("EVCONT_AMD_CACHE_ENTRIES", "4"))
+_STRICT = os.environ.get("EVCONT_AMD_CACHE_STRICT", "0") not in ("", "0")
 _cache: "OrderedDict[tuple, object]" = OrderedDict()
 
 
@@ -25,7 +29,7 @@ def _fingerprint(a: np.ndarray) -> tuple:
     if flat_len == 0:
         return (a.shape, a.dtype.str)
     # ~4096 samples spread over the array + both ends; cheap even for a 2.6 GB array
-    step = max(1, flat_len // 4096)
+    step = 1 if _STRICT else max(1, flat_len // 4096)
     if a.flags.c_contiguous:
         sample = a.reshape(-1)[::step]
     else:

@@ -59,6 +59,7 @@ class TRDMContainer:
     def _append_state(self, ovlp_row, one_rows, two_rows) -> None:
         self.overlap, self.one_rdm, self.two_rdm = grow_trdms(self.overlap, self.one_rdm, self.two_rdm,
                                                               ovlp_row, one_rows, two_rows)
+        self._invalidate()
 
     def _prune_arrays(self, keep_ids: Sequence[int]) -> None:
         keep_ids = list(keep_ids)
@@ -68,6 +69,14 @@ class TRDMContainer:
             self.one_rdm = self.one_rdm[np.ix_(keep_ids, keep_ids)]
         if self.two_rdm is not None:
             self.two_rdm = self.two_rdm[np.ix_(keep_ids, keep_ids)]
+        self._invalidate()
+
+    def _invalidate(self) -> None:
+        """The training set changed: drop the device copies made from the old arrays (this container's and the
+        upload cache of the mol-level API, which is keyed on a fingerprint of the arrays it was given)."""
+        from . import cache
+        self._device, self._device_key = None, None
+        cache.clear()
 
     def prune_datapoints(self, keep_ids) -> None:
         self._prune_arrays(keep_ids)

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "../../include/evcont_hip.h"
 
 namespace evc {
@@ -31,6 +33,29 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
             return (int)e_;                                                         \
         }                                                                           \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: one process may drive several
+// devices through this library, so the "already raised" flag is kept per device (bit d of `done`; devices >= 64 set
+// the attribute on every call).  Returns 0 or the hipError_t of the failed call (error string set).
+struct LdsAttr {
+    std::atomic<uint64_t> done{0};
+};
+template <typename K>
+inline int allow_dynamic_lds(K kernel, LdsAttr &st, int bytes, const char *name) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) {
+        const bool tracked = dev >= 0 && dev < 64;
+        if (tracked && (st.done.load(std::memory_order_acquire) >> dev & 1u)) return 0;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) {
+            if (tracked) st.done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+            return 0;
+        }
+    }
+    set_error("%s: cannot raise the dynamic LDS limit to %d bytes: %s", name, bytes, hipGetErrorString(e));
+    return (int)e;
+}
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

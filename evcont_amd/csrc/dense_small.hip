@@ -390,20 +390,11 @@ static size_t jacobi_aux_bytes(int m) {
            (m <= kJwMax ? sizeof(double) * kJwMax * kJwPitch + 16 : 0);
 }
 
-template <typename K>
-static void allow_big_lds(K kernel, bool &done) {
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        done = true;
-    }
-}
-
 int launch_loewdin(const LoewdinArgs &a, int count, hipStream_t st) {
     const int m = (a.n + 1) & ~1;
     const size_t lds = sizeof(double) * (size_t)3 * m * m + jacobi_aux_bytes(m);
-    static bool attr_set = false;
-    allow_big_lds(loewdin_kernel, attr_set);
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(loewdin_kernel, attr, 160 * 1024, "loewdin")) return rc;
     hipLaunchKernelGGL(loewdin_kernel, dim3(count), dim3(kThreads), lds, st, a);
     EVC_LAUNCH_CHECK("loewdin");
     return 0;
@@ -598,10 +589,44 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
 int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st) {
     const int m = (a.T + 1) & ~1;
     const size_t lds = sizeof(double) * (size_t)4 * m * m + sizeof(int) * m + jacobi_aux_bytes(m);
-    static bool attr_set = false;
-    allow_big_lds(subspace_kernel, attr_set);
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(subspace_kernel, attr, 160 * 1024, "subspace_solve")) return rc;
     hipLaunchKernelGGL(subspace_kernel, dim3(count), dim3(kThreads), lds, st, a);
     EVC_LAUNCH_CHECK("subspace_solve");
+    return 0;
+}
+
+// Row weights from a coefficient vector the caller supplies (the non-Hermitian branch: the T x T pencil is solved
+// with scipy.linalg.eig on the host, as the reference does, and its eigenvector comes back here).
+__global__ __launch_bounds__(256) void pair_weights_kernel(const double *__restrict__ c, int T, int pairs,
+                                                           double *__restrict__ w1, double *__restrict__ w2,
+                                                           int64_t w2_offset, int64_t w2_count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w1 && i < (int64_t)T * T) {
+        const int ia = (int)(i / T);
+        w1[i] = c[ia] * c[i - (int64_t)ia * T];
+    }
+    if (w2 && i < w2_count) {
+        const int64_t g = i + w2_offset;
+        double w;
+        if (pairs) {
+            const int ia = (int)tri_row(g), ib = (int)(g - (int64_t)ia * (ia + 1) / 2);
+            w = (ia == ib) ? c[ia] * c[ia] : 2.0 * c[ia] * c[ib];
+        } else {
+            const int ia = (int)(g / T);
+            w = c[ia] * c[g - (int64_t)ia * T];
+        }
+        w2[i] = w;
+    }
+}
+
+int launch_pair_weights(const double *c, int T, int layout, double *w1, double *w2, int64_t w2_offset,
+                        int64_t w2_count, hipStream_t st) {
+    const int pairs = (layout == EVC_LAYOUT_PAIR5 || layout == EVC_LAYOUT_PACK2 || layout == EVC_LAYOUT_SYM8) ? 1 : 0;
+    const int64_t nmax = (int64_t)T * T > w2_count ? (int64_t)T * T : w2_count;
+    hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)ceil_div(nmax, 256)), dim3(256), 0, st, c, T, pairs, w1, w2,
+                       w2_offset, w2_count);
+    EVC_LAUNCH_CHECK("pair_weights");
     return 0;
 }
 
@@ -642,8 +667,8 @@ __global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) {
 
 int launch_grad_prep(const GradPrepArgs &a, int count, hipStream_t st) {
     const size_t lds = sizeof(double) * (size_t)4 * a.n * a.n;
-    static bool attr_set = false;
-    allow_big_lds(grad_prep_kernel, attr_set);
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(grad_prep_kernel, attr, 160 * 1024, "grad_prep")) return rc;
     hipLaunchKernelGGL(grad_prep_kernel, dim3(count), dim3(kThreads), lds, st, a);
     EVC_LAUNCH_CHECK("grad_prep");
     return 0;
@@ -781,8 +806,8 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
 int launch_grad_final(const GradFinalArgs &a, int count, hipStream_t st) {
     const size_t lds = sizeof(double) * ((size_t)4 * a.n * a.n + 6 * a.n + 3 * (size_t)a.natm) +
                        sizeof(int) * 2 * (size_t)a.natm + 16;
-    static bool attr_set = false;
-    allow_big_lds(grad_final_kernel, attr_set);
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(grad_final_kernel, attr, 160 * 1024, "grad_final")) return rc;
     hipLaunchKernelGGL(grad_final_kernel, dim3(count), dim3(kThreads), lds, st, a);
     EVC_LAUNCH_CHECK("grad_final");
     return 0;

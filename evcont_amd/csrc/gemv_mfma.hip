@@ -484,21 +484,19 @@ static void cols_mfma_rs_launch(GemvColsLaunch L, int g0, int G, hipStream_t st)
 }
 
 template <int CT, int KSN, int MINW, int GS>
-static void cols_mfma_launch(GemvColsLaunch L, int g0, int G, hipStream_t st) {
+static int cols_mfma_launch(GemvColsLaunch L, int g0, int G, hipStream_t st) {
     const int64_t per = 4 * 32 * CT;
     L.nblk0 = (int)ceil_div(L.p[0].cols, per);
     const int total = L.nblk0 + (int)ceil_div(L.p[1].cols, per);
     int64_t rmax = L.p[0].rows > L.p[1].rows ? L.p[0].rows : L.p[1].rows;
     if (rmax > kRowTile) rmax = kRowTile;
     const size_t lds = sizeof(double) * 16 * GS * (size_t)((rmax + 3) & ~3);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemv_cols_mfma_kernel<CT, KSN, MINW, GS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kRowTile * 16 * GS * (int)sizeof(double));
-        attr = true;
-    }
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(gemv_cols_mfma_kernel<CT, KSN, MINW, GS>, attr,
+                                   kRowTile * 16 * GS * (int)sizeof(double), "gemv_cols_mfma"))
+        return rc;
     hipLaunchKernelGGL((gemv_cols_mfma_kernel<CT, KSN, MINW, GS>), dim3(total), dim3(256), lds, st, L, g0, G);
+    return 0;
 }
 
 int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
@@ -510,7 +508,9 @@ int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
     static const int sh1 = getenv("EVC_COLS_SHAPE") ? atoi(getenv("EVC_COLS_SHAPE")) : 126;
     static const int sh2 = getenv("EVC_COLS_SHAPE2") ? atoi(getenv("EVC_COLS_SHAPE2")) : 224;
 #define EVC_COLS_CASE(CT_, KSN_, MINW_, GS_) \
-    case 100 * CT_ + 10 * KSN_ + MINW_: cols_mfma_launch<CT_, KSN_, MINW_, GS_>(L, g0, G, st); break;
+    case 100 * CT_ + 10 * KSN_ + MINW_:                                                        \
+        if (int rc_ = cols_mfma_launch<CT_, KSN_, MINW_, GS_>(L, g0, G, st)) return rc_;       \
+        break;
     // shape code 1000 + 10*KSN + MINW = the row-split kernel; it is the default below kRsMaxCols columns
 #define EVC_COLS_RS_CASE(KSN_, MINW_, GS_) \
     case 1000 + 10 * KSN_ + MINW_: cols_mfma_rs_launch<KSN_, MINW_, GS_>(L, g0, G, st); break;

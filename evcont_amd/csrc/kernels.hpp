@@ -158,6 +158,11 @@ struct SolveArgs {
     int warm;                     // start the Jacobi sweeps from vstd
 };
 int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st);
+// Weights of the t-RDM rows for the predicted RDMs of a GIVEN coefficient vector c[T] (gradients_loewdin.py:343-356):
+// w1[a*T+b] = c_a c_b; w2 = the slice [w2_offset, +w2_count) of the two-body row weights (pairs: 2 c_a c_b, c_a^2 on
+// the diagonal; otherwise c_a c_b).
+int launch_pair_weights(const double *c, int T, int layout, double *w1, double *w2, int64_t w2_offset,
+                        int64_t w2_count, hipStream_t st);
 struct GradPrepArgs {
     int n;
     const double *X;      // + g*sws

@@ -8,6 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -28,7 +31,7 @@ void set_error(const char *fmt, ...) {
 constexpr int kProfStages = 8;
 constexpr int kProfPerSample = 16;   // event pairs one evaluation can record
 struct Prof {
-    bool on = false;
+    std::atomic<bool> on{false};
     int cap = 0, n = 0;          // records: capacity, used
     hipEvent_t *ev = nullptr;    // [cap][2]: start, stop
     int *stage = nullptr;        // [cap]
@@ -37,8 +40,11 @@ struct Prof {
     unsigned mask = (1u << EVC_PROF_ROWS) | (1u << EVC_PROF_COLS);   // stages that are timed (evc_profile_select)
 };
 static Prof g_prof;
+static std::mutex g_prof_mu;   // record allocation and begin/end/select: host threads may share the hook
 // start of a timed launch: returns the record index or -1
 static int prof_start(int stage, hipStream_t st) {
+    if (!g_prof.on) return -1;   // the common case: no lock taken
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof.on || !(g_prof.mask >> stage & 1u) || g_prof.n >= g_prof.cap) return -1;
     const int i = g_prof.n++;
     g_prof.stage[i] = stage;
@@ -673,6 +679,7 @@ extern "C" int evc_abi_version(void) { return EVC_ABI_VERSION; }
 extern "C" const char *evc_last_error(void) { return g_err; }
 
 extern "C" int evc_profile_begin(int max_samples) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     EVC_REQUIRE(!g_prof.on, "evc_profile_begin: already profiling");
     EVC_REQUIRE(max_samples > 0 && max_samples <= 1 << 16, "evc_profile_begin: max_samples=%d", max_samples);
     const int cap = max_samples * kProfPerSample;
@@ -692,6 +699,7 @@ extern "C" int evc_profile_begin(int max_samples) {
 }
 
 extern "C" int evc_profile_end(double *rows_ms, int *rows_n, double *cols_ms, int *cols_n) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     EVC_REQUIRE(g_prof.on, "evc_profile_end: not profiling");
     for (int k = 0; k < kProfStages; ++k) {
         g_prof.ms[k] = 0.0;
@@ -720,12 +728,14 @@ extern "C" int evc_profile_end(double *rows_ms, int *rows_n, double *cols_ms, in
 }
 
 extern "C" int evc_profile_select(unsigned stage_mask) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     EVC_REQUIRE(!g_prof.on, "evc_profile_select: not while profiling");
     g_prof.mask = stage_mask & ((1u << kProfStages) - 1u);
     return 0;
 }
 
 extern "C" int evc_profile_stage(int stage, double *ms, int *launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     EVC_REQUIRE(stage >= 0 && stage < kProfStages, "evc_profile_stage: stage=%d", stage);
     EVC_REQUIRE(!g_prof.on, "evc_profile_stage: call evc_profile_end first");
     if (ms) *ms = g_prof.ms[stage];
@@ -773,6 +783,17 @@ extern "C" int evc_phase_solve(const evc_trdm_set *t, const evc_geometry *g, con
     EVC_SETUP(false);
     EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
     return phase_solve(t, geo, h2rows_all ? h2rows_all : w.h2rows, 0, out_single(out), nroots, w, st);
+}
+
+extern "C" int evc_phase_set_coeffs(const evc_trdm_set *t, const double *coeffs, int natm, void *ws, size_t ws_bytes,
+                                    void *stream) {
+    if (check_set(t)) return -1;
+    EVC_REQUIRE(coeffs, "evc_phase_set_coeffs: coeffs is NULL");
+    EVC_REQUIRE(ws && aligned16(ws), "workspace NULL or misaligned");
+    Ws w;
+    carve(t, natm, static_cast<char *>(ws), w);
+    EVC_REQUIRE(ws_bytes >= w.bytes, "workspace too small: %zu < %zu", ws_bytes, w.bytes);
+    return launch_pair_weights(coeffs, t->ntrain, t->layout, w.w1, w.w2, t->row_offset, t->rows2, as_stream(stream));
 }
 
 extern "C" int evc_phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,

@@ -162,15 +162,6 @@ __global__ __launch_bounds__(kT) void contract_kernel(const double *__restrict__
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
-template <typename K>
-static void big_lds(K kernel, bool &done) {
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        done = true;
-    }
-}
-
 }  // namespace evc
 
 using namespace evc;
@@ -188,8 +179,8 @@ extern "C" int evc_loewdin_trafo_grad(const double *S, int n, double *LG, double
     la.n = n;
     int rc = launch_loewdin(la, 1, st);
     if (rc) return rc;
-    static bool a = false;
-    big_lds(loewdin_trafo_grad_kernel, a);
+    static LdsAttr attr;
+    if (int rca = allow_dynamic_lds(loewdin_trafo_grad_kernel, attr, 160 * 1024, "loewdin_trafo_grad")) return rca;
     hipLaunchKernelGGL(loewdin_trafo_grad_kernel, dim3(n), dim3(kT), sizeof(double) * 3 * n * n, st, U, s, n, LG);
     EVC_LAUNCH_CHECK("loewdin_trafo_grad");
     return 0;
@@ -209,8 +200,8 @@ extern "C" int evc_derivative_ao_mo_trafo(const double *S, const double *ipovlp,
     la.n = n;
     int rc = launch_loewdin(la, 1, st);
     if (rc) return rc;
-    static bool a = false;
-    big_lds(dx_tensor_kernel, a);
+    static LdsAttr attr;
+    if (int rca = allow_dynamic_lds(dx_tensor_kernel, attr, 160 * 1024, "dx_tensor")) return rca;
     hipLaunchKernelGGL(dx_tensor_kernel, dim3(natm * 3), dim3(kT), sizeof(double) * (3 * n * n + n), st, U, s, ipovlp,
                        aoslices, n, natm, dX);
     EVC_LAUNCH_CHECK("dx_tensor");
@@ -221,8 +212,8 @@ extern "C" int evc_one_el_grad(const double *X, const double *hcore, const doubl
                                int natm, double *out, void *stream) {
     EVC_REQUIRE(X && hcore && dhcore && dX && out, "evc_one_el_grad: null pointer");
     EVC_REQUIRE(n >= 1 && n <= 60 && natm >= 1, "evc_one_el_grad: n=%d natm=%d out of range (n<=60)", n, natm);
-    static bool a = false;
-    big_lds(one_el_grad_kernel, a);
+    static LdsAttr attr;
+    if (int rca = allow_dynamic_lds(one_el_grad_kernel, attr, 160 * 1024, "one_el_grad")) return rca;
     hipLaunchKernelGGL(one_el_grad_kernel, dim3(natm * 3), dim3(kT), sizeof(double) * 5 * n * n, as_stream(stream), X,
                        hcore, dhcore, dX, n, natm, out);
     EVC_LAUNCH_CHECK("one_el_grad");

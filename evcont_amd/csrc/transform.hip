@@ -385,12 +385,8 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
         hipLaunchKernelGGL(pt_kernel<16>, grid, dim3(256), lds, st, a);
     } else if (npad == 32) {
         const size_t lds = sizeof(double) * ((size_t)32 * 48 + stage_rows * 9);
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pt_kernel<32>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
+        static LdsAttr attr;
+        if (int rc = allow_dynamic_lds(pt_kernel<32>, attr, 160 * 1024, "pair_transform")) return rc;
         hipLaunchKernelGGL(pt_kernel<32>, grid, dim3(256), lds, st, a);
     } else {
         set_error("pair_transform: n=%d not supported (1..32)", n);

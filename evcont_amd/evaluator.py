@@ -546,6 +546,45 @@ class ContinuationEvaluator:
                                       int(nroots), self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_phase_solve")
 
+    def phase_set_coeffs(self, coeffs: torch.Tensor) -> None:
+        """Row weights of the predicted RDMs from a caller-supplied coefficient vector (``evc_phase_set_coeffs``)."""
+        assert coeffs.dtype == F64 and coeffs.numel() == self.t.T and coeffs.is_contiguous()
+        rc = self.lib.evc_phase_set_coeffs(C.byref(self.t.cstruct), coeffs.data_ptr(), self.natm, self.ws.data_ptr(),
+                                           self.ws_bytes, self._sp())
+        check(rc, "evc_phase_set_coeffs")
+
+    def energy_with_grad_nonhermitian(self, ao: DeviceAO, return_density_matrices: bool = False):
+        """``get_energy_with_grad(..., hermitian=False)`` (``ab_initio_gradients_loewdin.py:341-379`` with the ``eig``
+        branch of ``ab_initio_eigenvector_continuation.py:76-88``): the device assembles H(R) as for the Hermitian
+        branch; the T x T non-symmetric pencil goes to ``scipy.linalg.eig`` on the host, as in the reference (pair
+        layouts: upper triangle filled from the lower one, ``|Im| < 1e-5`` filter, ``argmin``), and ITS 2-norm
+        eigenvector -- real part, as the reference takes it -- defines the predicted RDMs and the gradient."""
+        import scipy.linalg
+        if self.t.layout == _lib.LAYOUT_SYM8:
+            raise _lib.EvcontHipError("hermitian=False needs the training data in the layout the caller holds, not sym8")
+        if (self.t.row_offset, self.t.rows_local) != (0, self.t.rows_total):
+            raise _lib.EvcontHipError("hermitian=False needs the complete t-RDM on this device")
+        rows = self.phase_hamiltonian(ao)
+        self.phase_solve(ao, rows, 1)
+        self.synchronize()
+        H = self.hmat.cpu().numpy().copy()
+        if self.t.layout in (5, 2):
+            iu = np.triu_indices(self.t.T)
+            H[iu] = H.T[iu]
+        vals, vecs = scipy.linalg.eig(H, self.t.S.cpu().numpy())
+        valid = np.abs(vals.imag) < 1.0e-5
+        k = int(np.argmin(vals[valid].real))
+        e = float(vals[valid][k].real)
+        vec = np.ascontiguousarray(vecs[:, valid][:, k].real, dtype=np.float64)
+        self.phase_set_coeffs(torch.from_numpy(vec).to(self.t.device))
+        self.phase_gradient(ao, False)
+        self.synchronize()
+        self._primed = False      # the workspace no longer holds a converged Hermitian solve
+        g = self.grad[: self.natm].cpu().numpy().copy()
+        if return_density_matrices:
+            return e + ao.enuc, g, self.d_pred.cpu().numpy().copy(), self.g_pred.cpu().numpy().copy()
+        return e + ao.enuc, g
+
     def phase_gradient(self, ao: DeviceAO, partial_rank: bool) -> None:
         g = ao.cstruct()
         rc = self.lib.evc_phase_gradient(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out),

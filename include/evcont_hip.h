@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 4 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
-                             3: EVC_LAYOUT_SYM8; 4: evc_profile_stage/_select, EVC_FLAG_IP1_S2KL, EVC_FLAG_ERI_S4 */
+#define EVC_ABI_VERSION 5 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
+                             3: EVC_LAYOUT_SYM8; 4: evc_profile_stage/_select, EVC_FLAG_IP1_S2KL, EVC_FLAG_ERI_S4;
+                             5: evc_phase_set_coeffs */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
@@ -220,6 +221,13 @@ int evc_phase_solve(const evc_trdm_set *t, const evc_geometry *g, const double *
 /* Phase C: predicted RDMs of root 0 + Loewdin-response nuclear gradient. */
 int evc_phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
                        int flags, void *ws, size_t ws_bytes, void *stream);
+/* Between B and C, optional: replace the row weights phase B left in the workspace by those of a coefficient vector
+ * the CALLER supplies (coeffs[T], device): w1 = c c^T, two-body rows 2 c_a c_b / c_a^2 (pair layouts) or c_a c_b
+ * (ab_initio_gradients_loewdin.py:343-356).  This is how hermitian=False is served: the T x T pencil (outputs.hmat of
+ * phase B) is solved by scipy.linalg.eig on the host, exactly as the reference does (:76-88), and phase C then builds
+ * the predicted RDMs and the gradient from ITS eigenvector.  `natm` as passed to evc_workspace_bytes. */
+int evc_phase_set_coeffs(const evc_trdm_set *t, const double *coeffs, int natm, void *ws, size_t ws_bytes,
+                         void *stream);
 /* A+B(+C) back to back on one device. */
 int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
                          int nroots, int flags, void *ws, size_t ws_bytes, void *stream);

@@ -124,8 +124,22 @@ def test_get_energy_with_grad(case, lname, load_golden):
     assert E2 == E
     np.testing.assert_allclose(D, g[f"ewg_D_{lname}"], rtol=0, atol=1e-10)
     np.testing.assert_allclose(G, g[f"ewg_G_{lname}"], rtol=0, atol=1e-10)
-    with pytest.raises(NotImplementedError):
-        gl.get_energy_with_grad(mol, g["one_RDM"], two, g["S_train"], hermitian=False)
+    # hermitian=False (reference :341-356 with the eig vector): host eig on the device-assembled H, device gradient
+    En, gradn, Dn, Gn = gl.get_energy_with_grad(mol, g["one_RDM"], two, g["S_train"], hermitian=False,
+                                                return_density_matrices=True)
+    from oracle import evcont_oracle as orc
+    from conftest import bundle_from_golden
+    Eo, go, Do, Go = orc.energy_with_grad(bundle_from_golden(g), g["one_RDM"], two, g["S_train"], False, True)
+    assert abs(En - Eo) < 1e-10
+    np.testing.assert_allclose(gradn, go, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Dn, Do, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Gn, np.asarray(Go).reshape(Gn.shape), rtol=0, atol=1e-10)
+    if lname == "full6" and "ewg_E_full6_nh" in g:
+        # the reference's own output for this branch (tests/golden/make_golden.py)
+        assert abs(En - float(g["ewg_E_full6_nh"])) < 1e-10
+        np.testing.assert_allclose(gradn, g["ewg_grad_full6_nh"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(Dn, g["ewg_D_full6_nh"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(Gn, g["ewg_G_full6_nh"], rtol=0, atol=1e-10)
 
 
 def test_sliced_views_and_cache(load_golden):
