@@ -8,6 +8,8 @@
 // These kernels are latency bound (one CU): every global operand is staged into LDS with
 // coalesced loads first, inner loops carry no integer division, and the 256 threads are
 // used as a 16x16 grid (tj = row group, tk = column group).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -88,7 +90,7 @@ __device__ __forceinline__ void jacobi_rotation(double app, double aqq, double a
 }
 
 // init_v = false: V already holds an orthogonal matrix and A the matrix in THAT basis (warm start).
-__device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double *red, bool init_v = true) {
+__device__ __forceinline__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double *red, bool init_v = true) {
     const int tid = threadIdx.x;
     const int tk = tid & 15, tj = tid >> 4;
     const int half = m >> 1;
@@ -170,19 +172,48 @@ __device__ void jacobi_eigh_lds(double *A, double *V, int m, double *rot, double
 constexpr int kJwPitch = 34;
 constexpr int kJwMax = 32;
 
-__device__ __forceinline__ double quad_sum(double v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
+// Sum over the four lanes of a quad, every lane gets the total.  DPP quad_perm moves (one v_mov_b32_dpp per
+// 32-bit half), not __shfl_xor: that lowers to ds_bpermute_b32, an LDS-pipeline round trip per half and level.
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kQuadXor1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int kQuadXor2 = 0x4E;   // quad_perm [2,3,0,1]
+template <typename T>
+__device__ __forceinline__ T quad_sum(T v) {
+    v += dpp_quad<kQuadXor1>(v);
+    v += dpp_quad<kQuadXor2>(v);
     return v;
 }
 
-__device__ void jacobi_onesided_wave(double *Gc, int m) {
+__device__ long long g_dbg_stamp[64];   // wall_clock64() (100 MHz) stamps of workgroup 0 (debug, evc_debug_read)
+__device__ double g_dbg_val[64];
+#define EVC_STAMP(i_)                                                                   \
+    do {                                                                                \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_stamp[i_] = wall_clock64();      \
+    } while (0)
+#define EVC_DBGVAL(i_, v_)                                                              \
+    do {                                                                                \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_val[i_] = (double)(v_);          \
+    } while (0)
+__device__ int g_dbg_max_sweeps = 0;   // > 0: cap on the sweeps of the wave solvers (EVC_DBG_MAX_SWEEPS, timing experiments)
+
+__device__ __forceinline__ void jacobi_onesided_wave(double *Gc, int m) {
     const int lane = threadIdx.x & 63;
     const int k = lane >> 2, sub = lane & 3;
     const int half = m >> 1;
     const bool active = k < half;
     const int row0 = sub * 8;
-    for (int sweep = 0; sweep < 40; ++sweep) {
+    const int cap = g_dbg_max_sweeps > 0 ? g_dbg_max_sweeps : 40;
+    for (int sweep = 0; sweep < cap; ++sweep) {
         bool bad = false;
         for (int step = 0; step < m - 1; ++step) {
             int p = 0, q = 1;
@@ -251,7 +282,7 @@ __device__ void jacobi_onesided_wave(double *Gc, int m) {
 // through the rotations (its orthogonality is that of the columns of G, which is the convergence criterion).
 // init_v = false: V holds an orthogonal start matrix and A the matrix in THAT basis (warm start), G0 = V (A + shift I).
 // Gc: kJwMax x kJwPitch doubles of LDS.
-__device__ void jacobi_eigh_wave(double *A, double *V, int m, double shift, bool init_v, double *Gc, double *lam) {
+__device__ __forceinline__ void jacobi_eigh_wave(double *A, double *V, int m, double shift, bool init_v, double *Gc, double *lam) {
     const int tid = threadIdx.x;
     for (int idx = tid; idx < kJwMax * kJwPitch; idx += kThreads) {
         const int j = idx / kJwPitch, i = idx - j * kJwPitch;
@@ -286,11 +317,330 @@ __device__ void jacobi_eigh_wave(double *A, double *V, int m, double shift, bool
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ FP32 Jacobi + FP64 refinement (m <= 32)
+// The FP64 wave Jacobi above is a chain of ~8 sweeps x (m-1) steps of ~1200 cycles each (f64 rsq/rcp seeds with
+// Newton steps, twice the LDS bytes), and its last sweeps only square an error that is already tiny.  Two stages
+// instead:
+//  (1) the same one-sided Jacobi in FP32 (hardware v_sqrt/v_rcp/v_rsq_f32 without refinement, half the LDS traffic,
+//      ~2.5x shorter steps), run until every column pair is orthogonal to 1e-5 before its rotation: eigenvectors to
+//      ~1e-6;
+//  (2) Ogita-Aishima refinement in FP64 (Japan J. Indust. Appl. Math. 35 (2018) 1007): with R = I - Z^T Z,
+//      S = Z^T A Z, l_i = S_ii / (1 - R_ii),  E_ij = (S_ij + l_j R_ij) / (l_j - l_i)  (R_ij / 2 on the diagonal and
+//      inside a cluster |l_i - l_j| <= delta),  Z <- Z + Z E  squares the error per pass: four small products on the
+//      whole workgroup, one or two passes.
+// Everything downstream (X = V f(s) V^T, the divided-difference response, the generalised eigenvectors) is a smooth
+// function of invariant subspaces, so the arbitrary basis the cluster rule leaves inside a degenerate eigenspace is
+// harmless -- as it is for LAPACK.  Returns false (A untouched) when the refinement does not contract: the caller
+// falls back to the FP64 Jacobi.
+constexpr int kJfPitch = 36;   // floats per column (16-byte aligned columns)
+
+__device__ __forceinline__ void jacobi_onesided_wave_f32(float *Gf, int m) {
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 2, sub = lane & 3;
+    const int half = m >> 1;
+    const bool active = k < half;
+    const int row0 = sub * 8;
+    const int cap = g_dbg_max_sweeps > 0 ? g_dbg_max_sweeps : 30;
+    for (int sweep = 0; sweep < cap; ++sweep) {
+        bool bad = false;
+        for (int step = 0; step < m - 1; ++step) {
+            int p = 0, q = 1;
+            if (active) pair_of(step, k, m, p, q);
+            float *gp = Gf + p * kJfPitch + row0, *gq = Gf + q * kJfPitch + row0;
+            float4 x0 = *reinterpret_cast<const float4 *>(gp), x1 = *reinterpret_cast<const float4 *>(gp + 4);
+            float4 y0 = *reinterpret_cast<const float4 *>(gq), y1 = *reinterpret_cast<const float4 *>(gq + 4);
+            float al = x0.x * x0.x, be = y0.x * y0.x, ga = x0.x * y0.x;
+#define EVC_ACC(X_, Y_)          \
+    al = fmaf(X_, X_, al);      \
+    be = fmaf(Y_, Y_, be);      \
+    ga = fmaf(X_, Y_, ga);
+            EVC_ACC(x0.y, y0.y) EVC_ACC(x0.z, y0.z) EVC_ACC(x0.w, y0.w)
+            EVC_ACC(x1.x, y1.x) EVC_ACC(x1.y, y1.y) EVC_ACC(x1.z, y1.z) EVC_ACC(x1.w, y1.w)
+#undef EVC_ACC
+            al = quad_sum(al);
+            be = quad_sum(be);
+            ga = quad_sum(ga);
+            const float ab = al * be, g2 = ga * ga;
+            const bool rot = active && (g2 > 1.0e-14f * ab);
+            bad = bad || (active && g2 > 1.0e-10f * ab);
+            if (rot) {
+                const float d = be - al, b = 2.0f * ga;
+                const float den = fabsf(d) + __builtin_sqrtf(fmaf(d, d, b * b));
+                const float t = copysignf(b, d * b == 0.0f ? b : d * b) * __builtin_amdgcn_rcpf(den);
+                const float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f)), s = t * c;
+                float4 a0, a1, b0, b1;
+#define EVC_ROT(F_)                         \
+    a0.F_ = c * x0.F_ - s * y0.F_;          \
+    b0.F_ = s * x0.F_ + c * y0.F_;          \
+    a1.F_ = c * x1.F_ - s * y1.F_;          \
+    b1.F_ = s * x1.F_ + c * y1.F_;
+                EVC_ROT(x) EVC_ROT(y) EVC_ROT(z) EVC_ROT(w)
+#undef EVC_ROT
+                *reinterpret_cast<float4 *>(gp) = a0;
+                *reinterpret_cast<float4 *>(gp + 4) = a1;
+                *reinterpret_cast<float4 *>(gq) = b0;
+                *reinterpret_cast<float4 *>(gq + 4) = b1;
+            }
+        }
+        if (lane == 0 && blockIdx.x == 0) g_dbg_val[20] = sweep + 1;
+        if (__ballot(bad) == 0) break;
+    }
+}
+
+// max over the workgroup (NaN-propagating: a NaN input yields a NaN result); red: 4 doubles of LDS.
+// Wave stage on DPP moves (quad xor 1, xor 2, row_half_mirror, row_mirror) + four readlanes, no LDS round trips.
+__device__ __forceinline__ double nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_max_nan(double v) {
+    v = nanmax(v, dpp_quad<kQuadXor1>(v));
+    v = nanmax(v, dpp_quad<kQuadXor2>(v));
+    v = nanmax(v, dpp_quad<0x141>(v));   // row_half_mirror
+    v = nanmax(v, dpp_quad<0x140>(v));   // row_mirror: every lane holds the maximum of its row of 16
+    return nanmax(nanmax(readlane_f64(v, 0), readlane_f64(v, 16)), nanmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+__device__ __forceinline__ double block_max_nan(double v, double *red) {
+    v = wave_max_nan(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    const double t = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
+    __syncthreads();
+    return t;
+}
+
+// ---- refinement on the whole workgroup: matrices of up to 32 x 32 in LDS with row pitch kRp ------------------
+// C[i][j] = sum_k P[i][k] Q[j][k] ("row . row": both operands are read along contiguous rows with 16-byte LDS loads;
+// 16 consecutive rows at pitch 34 doubles fall on 16 different 4-bank groups).  Thread (tj,tk) of the 16 x 16 grid owns
+// i in {tj, tj+16}, j in {tk, tk+16}; rows >= m are read as row 0 and their results dropped by the caller's store.
+constexpr int kRp = 34;
+constexpr int kRsz = 32 * kRp;   // doubles per matrix
+
+template <typename Store>
+__device__ __forceinline__ void mm_rowrow(int m, const double *__restrict__ P, const double *__restrict__ Q, Store store) {
+    const int tk = threadIdx.x & 15, tj = threadIdx.x >> 4;
+    const int ia = tj, ib = tj + 16, ja = tk, jb = tk + 16;
+    const double *pa = P + (ia < m ? ia : 0) * kRp, *pb = P + (ib < m ? ib : 0) * kRp;
+    const double *qa = Q + (ja < m ? ja : 0) * kRp, *qb = Q + (jb < m ? jb : 0) * kRp;
+    double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    const int m2 = (m + 1) & ~1;   // columns m..m2-1 are zero padding
+#pragma unroll 4
+    for (int k = 0; k < m2; k += 2) {
+        const double2 a0 = *reinterpret_cast<const double2 *>(pa + k), a1 = *reinterpret_cast<const double2 *>(pb + k);
+        const double2 b0 = *reinterpret_cast<const double2 *>(qa + k), b1 = *reinterpret_cast<const double2 *>(qb + k);
+        c00 = fma(a0.x, b0.x, c00); c00 = fma(a0.y, b0.y, c00);
+        c01 = fma(a0.x, b1.x, c01); c01 = fma(a0.y, b1.y, c01);
+        c10 = fma(a1.x, b0.x, c10); c10 = fma(a1.y, b0.y, c10);
+        c11 = fma(a1.x, b1.x, c11); c11 = fma(a1.y, b1.y, c11);
+    }
+    if (ia < m && ja < m) store(ia, ja, c00);
+    if (ia < m && jb < m) store(ia, jb, c01);
+    if (ib < m && ja < m) store(ib, ja, c10);
+    if (ib < m && jb < m) store(ib, jb, c11);
+}
+
+// Ogita-Aishima refinement of approximate eigenvectors of the symmetric matrix Ap (pitch kRp).  On entry Z holds the
+// start vectors as columns and Zt = Z^T (both pitch kRp, padding zero); B1, B2, B3: scratch matrices.  On success
+// (the error contracted to rounding) returns true with Z / Zt pointing at the refined pair (two of the five buffers)
+// and lam = eigenvalues; false when a pass does not contract (garbage, NaN or an unresolved cluster structure).
+__device__ __forceinline__ bool oa_refine(int m, const double *Ap, double *&Z, double *&Zt, double *B1, double *B2,
+                                          double *B3, double *lam, double *red, int max_pass) {
+    const int tid = threadIdx.x;
+    bool ok = false;
+    double prev = 1.0e300;
+    for (int pass = 0; pass < max_pass; ++pass) {
+        // Wt = Zt A  (A symmetric: Wt[j][i] = sum_k Zt[j][k] A[i][k])
+        mm_rowrow(m, Zt, Ap, [&](int j, int i, double v) { B1[j * kRp + i] = v; });
+        __syncthreads();
+        // S = Z^T W -> B2,  R = I - Z^T Z -> B3, in one pass over the rows of Zt
+        {
+            const int tk = tid & 15, tj = tid >> 4;
+            const int ia = tj, ib = tj + 16, ja = tk, jb = tk + 16;
+            const double *pa = Zt + (ia < m ? ia : 0) * kRp, *pb = Zt + (ib < m ? ib : 0) * kRp;
+            const double *za = Zt + (ja < m ? ja : 0) * kRp, *zb = Zt + (jb < m ? jb : 0) * kRp;
+            const double *wa = B1 + (ja < m ? ja : 0) * kRp, *wb = B1 + (jb < m ? jb : 0) * kRp;
+            double s00 = 0, s01 = 0, s10 = 0, s11 = 0, r00 = 0, r01 = 0, r10 = 0, r11 = 0;
+            const int m2 = (m + 1) & ~1;
+#pragma unroll 2
+            for (int k = 0; k < m2; k += 2) {
+                const double2 a0 = *reinterpret_cast<const double2 *>(pa + k), a1 = *reinterpret_cast<const double2 *>(pb + k);
+                const double2 y0 = *reinterpret_cast<const double2 *>(za + k), y1 = *reinterpret_cast<const double2 *>(zb + k);
+                const double2 w0 = *reinterpret_cast<const double2 *>(wa + k), w1 = *reinterpret_cast<const double2 *>(wb + k);
+                s00 = fma(a0.x, w0.x, s00); s00 = fma(a0.y, w0.y, s00);
+                s01 = fma(a0.x, w1.x, s01); s01 = fma(a0.y, w1.y, s01);
+                s10 = fma(a1.x, w0.x, s10); s10 = fma(a1.y, w0.y, s10);
+                s11 = fma(a1.x, w1.x, s11); s11 = fma(a1.y, w1.y, s11);
+                r00 = fma(a0.x, y0.x, r00); r00 = fma(a0.y, y0.y, r00);
+                r01 = fma(a0.x, y1.x, r01); r01 = fma(a0.y, y1.y, r01);
+                r10 = fma(a1.x, y0.x, r10); r10 = fma(a1.y, y0.y, r10);
+                r11 = fma(a1.x, y1.x, r11); r11 = fma(a1.y, y1.y, r11);
+            }
+            if (ia < m && ja < m) { B2[ia * kRp + ja] = s00; B3[ia * kRp + ja] = (ia == ja ? 1.0 : 0.0) - r00; }
+            if (ia < m && jb < m) { B2[ia * kRp + jb] = s01; B3[ia * kRp + jb] = -r01; }
+            if (ib < m && ja < m) { B2[ib * kRp + ja] = s10; B3[ib * kRp + ja] = -r10; }
+            if (ib < m && jb < m) { B2[ib * kRp + jb] = s11; B3[ib * kRp + jb] = (ib == jb ? 1.0 : 0.0) - r11; }
+        }
+        __syncthreads();
+        const double *S = B2, *R = B3;
+        double lm = 0.0;
+        if (tid < m) {
+            lm = S[tid * kRp + tid] / (1.0 - R[tid * kRp + tid]);
+            lam[tid] = lm;
+            lm = fabs(lm);
+        }
+        const double lmax = block_max_nan(lm, red);   // (its barriers also publish lam)
+        // E^T -> B1 (Wt is consumed).  E = R/2 + a, a antisymmetric: a_ij = sh / (l_j - l_i) to first order with
+        // sh = S_ij + (l_i + l_j)/2 R_ij; evaluated as the tangent of the Jacobi angle of the 2 x 2 problem
+        // [[l_i, sh], [sh, l_j]], which is the same number for well separated pairs and stays bounded (|a| <= 1) for
+        // close ones -- no cluster threshold.  Elements below the rounding floor are not rotated (an exactly
+        // degenerate eigenspace keeps whatever orthonormal basis it has).  Convergence measure: the rotation, but
+        // never more than |sh| relative to 1e-8 max|l| (a large rotation inside a numerically degenerate pair moves
+        // nothing that any smooth function of A can see), and the symmetric part.
+        const double floor_s = 1.5e-14 * lmax, inv_tol = 1.0e8 / (lmax > 0.0 ? lmax : 1.0);
+        double emax = 0.0;
+        for (int idx = tid; idx < m * 32; idx += kThreads) {
+            const int i = idx >> 5, j = idx & 31;
+            if (j < m) {
+                const double rv = R[i * kRp + j];
+                double e = 0.5 * rv, meas = fabs(e);
+                if (i != j) {
+                    const int lo = i < j ? i : j, hi = i < j ? j : i;
+                    const double d = lam[hi] - lam[lo];
+                    const double sh = S[i * kRp + j] + 0.5 * (lam[i] + lam[j]) * rv;
+                    double t = 0.0;
+                    if (fabs(sh) > floor_s || sh != sh) {
+                        const double hd = 0.5 * d, rt = sqrt(fma(hd, hd, sh * sh));
+                        t = sh / (hd + (hd < 0.0 ? -rt : rt));
+                    }
+                    e += (i < j) ? t : -t;
+                    const double mt = fmin(fabs(t), fabs(sh) * inv_tol);
+                    meas = nanmax(meas, (t != t) ? t : mt);
+                }
+                B1[j * kRp + i] = e;
+                emax = nanmax(emax, meas);
+            }
+        }
+        emax = block_max_nan(emax, red);
+        EVC_STAMP(3 + pass);
+        EVC_DBGVAL(pass, emax);
+        if (!(emax < 0.5) || (pass >= 2 && !(emax < prev))) break;   // NaN / no contraction: give up
+        // Zt' = Zt + E^T Z^T: Zt'[j][i] = Zt[j][i] + sum_k Et[j][k] Z[i][k]; stored both ways (S and R are consumed)
+        mm_rowrow(m, B1, Z, [&](int j, int i, double v) {
+            const double z = Zt[j * kRp + i] + v;
+            B2[j * kRp + i] = z;
+            B3[i * kRp + j] = z;
+        });
+        __syncthreads();
+        double *t = Zt;
+        Zt = B2;
+        B2 = t;
+        t = Z;
+        Z = B3;
+        B3 = t;
+        prev = emax;
+        if (emax < 3.0e-8) {   // the pass just applied leaves an error of ~emax^2
+            ok = true;
+            break;
+        }
+    }
+    return ok;
+}
+
+// Eigen-decomposition of the symmetric m x m matrix A (LDS, pitch m, both triangles; m <= 32, m even, a trailing
+// decoupled dummy dimension allowed): on return diag(A) = eigenvalues, V (pitch m) = eigenvectors as columns.
+//   warm: V holds the eigenvectors of a nearby problem (any garbage is detected): refinement starts from them;
+//   otherwise, or when that does not contract: FP32 Jacobi start; when that fails as well: FP64 Jacobi.
+// A + shift I must be positive definite.  Scratch R6: six matrices of kRsz doubles; Gc: kJwMax x kJwPitch doubles
+// (also serves as the FP32 column buffer); lam: m; red: 8 doubles.
+__device__ __forceinline__ void eigh_small(double *A, double *V, int m, double shift, bool warm, bool fast, double *R6,
+                                           double *Gc, double *lam, double *red) {
+    const int tid = threadIdx.x;
+    bool ok = false;
+    if (fast) {
+        double *Ap = R6, *Z = R6 + kRsz, *Zt = R6 + 2 * kRsz, *B1 = R6 + 3 * kRsz, *B2 = R6 + 4 * kRsz, *B3 = R6 + 5 * kRsz;
+        float *Gf = reinterpret_cast<float *>(Gc);
+        EVC_STAMP(0);
+        for (int idx = tid; idx < kRsz; idx += kThreads) {
+            const int i = idx / kRp, j = idx - i * kRp;
+            Ap[idx] = (i < m && j < m) ? A[i * m + j] : 0.0;
+        }
+        if (warm) {
+            for (int idx = tid; idx < kRsz; idx += kThreads) {
+                const int i = idx / kRp, j = idx - i * kRp;
+                const bool in = i < m && j < m;
+                Z[idx] = in ? V[i * m + j] : 0.0;
+                Zt[idx] = in ? V[j * m + i] : 0.0;
+            }
+            __syncthreads();
+            ok = oa_refine(m, Ap, Z, Zt, B1, B2, B3, lam, red, 6);
+            if (!ok) {   // the buffers may have been permuted: re-establish the roles
+                Z = R6 + kRsz; Zt = R6 + 2 * kRsz; B1 = R6 + 3 * kRsz; B2 = R6 + 4 * kRsz; B3 = R6 + 5 * kRsz;
+            }
+        }
+        if (!ok) {
+            // FP32 stage: G0 = (A + shift I) / max|.|, column-major with pitch kJfPitch
+            double amax = 0.0;
+            for (int idx = tid; idx < m * m; idx += kThreads) {
+                const int i = idx / m, j = idx - i * m;
+                const double v = fabs(A[idx] + (i == j ? shift : 0.0));
+                amax = (v > amax || v != v) ? v : amax;
+            }
+            amax = block_max_nan(amax, red);
+            if (amax > 0.0 && amax < 1.0e300) {   // (zero, NaN or Inf input: left to the FP64 path)
+                const double sc = 1.0 / amax;
+                for (int idx = tid; idx < kJwMax * kJfPitch; idx += kThreads) {
+                    const int j = idx / kJfPitch, i = idx - j * kJfPitch;
+                    Gf[idx] = (i < m && j < m) ? (float)((A[i * m + j] + (i == j ? shift : 0.0)) * sc) : 0.0f;
+                }
+                __syncthreads();
+                EVC_STAMP(1);
+                if (tid < 64) jacobi_onesided_wave_f32(Gf, m);
+                __syncthreads();
+                EVC_STAMP(2);
+                // Z0 = normalised columns (a zero column = the decoupled dummy dimension keeps its unit vector)
+                if (tid < m) {
+                    double nn = 0.0;
+                    for (int i = 0; i < m; ++i) nn = fma((double)Gf[tid * kJfPitch + i], (double)Gf[tid * kJfPitch + i], nn);
+                    lam[tid] = nn > 1.0e-60 ? 1.0 / sqrt(nn) : 0.0;
+                }
+                __syncthreads();
+                for (int idx = tid; idx < kRsz; idx += kThreads) {
+                    const int i = idx / kRp, j = idx - i * kRp;   // Zt[i][j] = Z[j][i] = component j of eigenvector i
+                    double v = 0.0;
+                    if (i < m && j < m) v = lam[i] > 0.0 ? (double)Gf[i * kJfPitch + j] * lam[i] : (i == j ? 1.0 : 0.0);
+                    Zt[idx] = v;
+                }
+                __syncthreads();
+                for (int idx = tid; idx < kRsz; idx += kThreads) {
+                    const int i = idx / kRp, j = idx - i * kRp;
+                    Z[idx] = (i < m && j < m) ? Zt[j * kRp + i] : 0.0;
+                }
+                __syncthreads();
+                ok = oa_refine(m, Ap, Z, Zt, B1, B2, B3, lam, red, 6);
+            }
+        }
+        EVC_STAMP(10);
+        if (ok) {
+            for (int idx = tid; idx < m * m; idx += kThreads) {
+                const int i = idx / m, j = idx - i * m;
+                V[idx] = Z[i * kRp + j];
+            }
+            if (tid < m) A[tid * m + tid] = lam[tid];
+            __syncthreads();
+        }
+    }
+    if (!ok) jacobi_eigh_wave(A, V, m, shift, true, Gc, lam);
+}
+
 // Warm start (EVC_FLAG_WARM_START): `prev` holds the eigenvectors of the previous, nearby problem.  If they
 // are orthonormal to 1e-8 (a stale or never-written buffer is not), V <- prev (padded with the identity) and
 // A <- V^T A V, which is nearly diagonal, so the sweeps that follow are two or three instead of seven or eight.
 // Returns whether the rotation was applied (uniform over the workgroup).  Tmp: n*n doubles of LDS.
-__device__ bool warm_start_rotate(double *A, double *V, double *Tmp, int n, int m, const double *__restrict__ prev,
+__device__ __forceinline__ bool warm_start_rotate(double *A, double *V, double *Tmp, int n, int m, const double *__restrict__ prev,
                                   int ldp, double *red) {
     const int tid = threadIdx.x;
     for (int idx = tid; idx < m * m; idx += kThreads) {
@@ -341,7 +691,8 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     double *rot = Xs + m * m;    // m
     double *red = rot + m;       // 8
     double *f = red + 8;         // m
-    double *Gc = f + m;          // kJwMax x kJwPitch (only carved for m <= kJwMax)
+    double *Gc = f + m;          // kJwMax x kJwPitch (only carved for m <= kJwMax), then the refinement's six matrices
+    double *R6 = Gc + kJwMax * kJwPitch;
     const int tid = threadIdx.x, tk = tid & 15, tj = tid >> 4;
     // LAPACK's eigh reads one triangle; numpy.linalg.eigh uses the lower one.
     for (int idx = tid; idx < m * m; idx += kThreads) A[idx] = 0.0;
@@ -356,9 +707,20 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     }
     __syncthreads();
     // warm start from the eigenvectors the previous call left in U (same workspace, nearby geometry)
-    const bool warm = a.warm && warm_start_rotate(A, V, Xs, n, m, U, n, red);
-    if (m <= kJwMax) jacobi_eigh_wave(A, V, m, 0.0, !warm, Gc, f);
-    else jacobi_eigh_lds(A, V, m, rot, red, !warm);
+    if (m <= kJwMax && a.fast) {
+        if (a.warm) {   // refinement straight from U (a stale or never-written buffer makes it fall back)
+            for (int idx = tid; idx < m * m; idx += kThreads) {
+                const int i = idx / m, j = idx - i * m;
+                V[idx] = (i < n && j < n) ? U[i * n + j] : (i == j ? 1.0 : 0.0);
+            }
+            __syncthreads();
+        }
+        eigh_small(A, V, m, 0.0, a.warm != 0, true, R6, Gc, f, red);
+    } else {
+        const bool warm = a.warm && warm_start_rotate(A, V, Xs, n, m, U, n, red);
+        if (m <= kJwMax) jacobi_eigh_wave(A, V, m, 0.0, !warm, Gc, f);
+        else jacobi_eigh_lds(A, V, m, rot, red, !warm);
+    }
     if (tid < m) {
         const double s = A[tid * m + tid];
         f[tid] = (tid < n && s > 1.0e-15) ? 1.0 / sqrt(s) : 0.0;
@@ -387,10 +749,25 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
 
 static size_t jacobi_aux_bytes(int m) {
     return sizeof(double) * (size_t)(2 * m + 8) + 32 +
-           (m <= kJwMax ? sizeof(double) * kJwMax * kJwPitch + 16 : 0);
+           (m <= kJwMax ? sizeof(double) * ((size_t)kJwMax * kJwPitch + (size_t)6 * kRsz) + 16 : 0);
 }
 
-int launch_loewdin(const LoewdinArgs &a, int count, hipStream_t st) {
+static bool eigh_fast_enabled() {
+    static const bool on = !(getenv("EVC_EIGH_F32") && atoi(getenv("EVC_EIGH_F32")) == 0);
+    static bool dbg_done = false;
+    if (!dbg_done) {
+        dbg_done = true;
+        if (const char *e = getenv("EVC_DBG_MAX_SWEEPS")) {
+            const int v = atoi(e);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_max_sweeps), &v, sizeof(int));
+        }
+    }
+    return on;
+}
+
+int launch_loewdin(const LoewdinArgs &a_in, int count, hipStream_t st) {
+    LoewdinArgs a = a_in;
+    a.fast = eigh_fast_enabled() ? 1 : 0;
     const int m = (a.n + 1) & ~1;
     const size_t lds = sizeof(double) * (size_t)3 * m * m + jacobi_aux_bytes(m);
     static LdsAttr attr;
@@ -427,8 +804,10 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     double *red = rot + m;      // 8
     double *ev = red + 8;       // m
     int *order = reinterpret_cast<int *>(ev + m);                              // m
-    // kJwMax x kJwPitch doubles for the single-wave eigensolver (only carved for m <= kJwMax), 16-byte aligned
+    // kJwMax x kJwPitch doubles for the single-wave eigensolver (only carved for m <= kJwMax), 16-byte aligned,
+    // followed by the refinement's six matrices
     double *Gc = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(order + m) + 15) & ~(uintptr_t)15);
+    double *R6 = Gc + kJwMax * kJwPitch;
     const int tid = threadIdx.x;
     const int64_t P = (int64_t)T * (T + 1) / 2;
     const bool pairs = (a.layout == EVC_LAYOUT_PAIR5 || a.layout == EVC_LAYOUT_PACK2 || a.layout == EVC_LAYOUT_SYM8);
@@ -519,7 +898,6 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     }
     __syncthreads();
     // warm start from the standard-form eigenvectors of the previous call (H is free as scratch here)
-    const bool warm = a.warm && a.vstd && warm_start_rotate(Cm, V, H, T, m, a.vstd, m, red);
     if (m <= kJwMax) {
         // the standard-form matrix is indefinite: shift it by a Gershgorin bound (the eigenvectors do not change)
         if (tid < m) {
@@ -532,8 +910,19 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         for (int j = 0; j < m; ++j) shift = fmax(shift, ev[j]);
         shift = 2.0 * shift + 1.0e-300;   // eigenvalues of the shifted matrix within [1, 3] x the bound
         __syncthreads();
-        jacobi_eigh_wave(Cm, V, m, shift, !warm, Gc, ev);
+        if (a.fast) {
+            const bool warm = a.warm && a.vstd;
+            if (warm) {   // refinement straight from the previous eigenvectors (garbage makes it fall back)
+                for (int idx = tid; idx < m * m; idx += kThreads) V[idx] = a.vstd[idx];
+                __syncthreads();
+            }
+            eigh_small(Cm, V, m, shift, warm, true, R6, Gc, ev, red);
+        } else {
+            const bool warm = a.warm && a.vstd && warm_start_rotate(Cm, V, H, T, m, a.vstd, m, red);
+            jacobi_eigh_wave(Cm, V, m, shift, !warm, Gc, ev);
+        }
     } else {
+        const bool warm = a.warm && a.vstd && warm_start_rotate(Cm, V, H, T, m, a.vstd, m, red);
         jacobi_eigh_lds(Cm, V, m, rot, red, !warm);
     }
     if (a.vstd)
@@ -586,7 +975,9 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     }
 }
 
-int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st) {
+int launch_subspace_solve(const SolveArgs &a_in, int count, hipStream_t st) {
+    SolveArgs a = a_in;
+    a.fast = eigh_fast_enabled() ? 1 : 0;
     const int m = (a.T + 1) & ~1;
     const size_t lds = sizeof(double) * (size_t)4 * m * m + sizeof(int) * m + jacobi_aux_bytes(m);
     static LdsAttr attr;
@@ -832,4 +1223,12 @@ extern "C" int evc_loewdin(const double *S, const double *hcore, int n, double *
     a.h1 = h1;
     a.n = n;
     return launch_loewdin(a, 1, as_stream(stream));
+}
+
+// Debug: stamps / values written by workgroup 0 of the last eigen-kernel (timing experiments).
+extern "C" int evc_debug_read(long long *stamps, double *vals, int n) {
+    if (n > 64) n = 64;
+    hipError_t e = hipMemcpyFromSymbol(stamps, HIP_SYMBOL(evc::g_dbg_stamp), sizeof(long long) * n);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(vals, HIP_SYMBOL(evc::g_dbg_val), sizeof(double) * n);
+    return (int)e;
 }

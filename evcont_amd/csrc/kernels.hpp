@@ -133,6 +133,7 @@ struct LoewdinArgs {
     int64_t sS, sh, sws;
     int n;
     int warm;  // U holds the eigenvectors of a previous, nearby S: start the Jacobi sweeps from them
+    int fast;  // set by launch_loewdin: FP32 Jacobi + FP64 refinement for n <= 32 (EVC_EIGH_F32=0: FP64 Jacobi)
 };
 int launch_loewdin(const LoewdinArgs &a, int count, hipStream_t st);
 struct SolveArgs {
@@ -156,6 +157,7 @@ struct SolveArgs {
     double *vstd;                 // (m,m), m = T rounded up to even: standard-form eigenvectors, kept in the
                                   // workspace from call to call (+ g*sw); may be NULL
     int warm;                     // start the Jacobi sweeps from vstd
+    int fast;                     // set by launch_subspace_solve: FP32 Jacobi + FP64 refinement for T <= 32
 };
 int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st);
 // Weights of the t-RDM rows for the predicted RDMs of a GIVEN coefficient vector c[T] (gradients_loewdin.py:343-356):

@@ -138,7 +138,14 @@ int launch_quarter_transform(const double *in, int64_t sin, const double *C, int
 // independent flags: lead_sym (in[p][q] = in[q][p]: only the n(n+1)/2 pairs q <= p are computed), in_lower
 // (M = M^T: only its lower triangle is read) and rs_lower (only N[r'][s'], s' <= r', is wanted: 3 of 4
 // result tiles, half the stage, half the output rows / the 8-fold compressed packed vector).
-template <int NPAD>
+// ROWBUF (operand = dense (pair, pair) matrix, in_pairs): a leading pair's matrix is ONE contiguous row of n(n+1)/2
+// doubles.  The wave fetches it with coalesced 16-byte loads (4-5 instructions of 1 KiB instead of 16 eight-byte
+// gathers that touch 64 cache lines each), parks it in a wave-private LDS row and reads its MFMA fragments from there
+// at lane-constant offsets tri(max(r,s), min(r,s)): triangular numbers of 16 consecutive r fall on 16 different banks.
+constexpr int kPtRawMax = (kPairTransformMaxN * (kPairTransformMaxN + 1) / 2 + 1 + 127) / 128;   // double2 per lane: 5
+constexpr int kPtRowLen = kPtRawMax * 128 + 4;   // + two zero slots (padding fragments), 16-byte multiple
+
+template <int NPAD, bool ROWBUF>
 __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     constexpr int LDX = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;
     constexpr int KS = NPAD / 4;
@@ -199,11 +206,63 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             }
     };
 
+    // ROWBUF: wave-private LDS row behind the stage; raw[] = the row in flight (lane i holds doubles 128 u + 2 i, +1 of
+    // the 16-byte aligned window that starts `dlt` doubles before the row)
+    const int stage_rows = rsl ? npairs : n * n;
+    double *mrow = stage + (((int64_t)stage_rows * QP + 1) & ~(int64_t)1) + wave * kPtRowLen;
+    const int nraw = ROWBUF ? (npairs + 1 + 127) / 128 : 0;   // wave-uniform
+    double2 raw[ROWBUF ? kPtRawMax : 1];
+    int dlt = 0, dlt_next = 0;
+    int foff[ROWBUF ? NT : 1][ROWBUF ? KS : 1];
+    if constexpr (ROWBUF) {
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int r = rt * 16 + l15, s = 4 * kk + l4;
+                const int hi = s > r ? s : r, lo = s > r ? r : s;
+                foff[rt][kk] = (r < n && s < n) ? hi * (hi + 1) / 2 + lo : kPtRawMax * 128;   // else: a zero slot
+            }
+        if (lane < 4) mrow[kPtRawMax * 128 + lane] = 0.0;
+    }
+    auto fetch_row = [&](bool ok, int p_, int q_, int &d_) {
+        if constexpr (ROWBUF) {
+            const double *row = in + (int64_t)(ok ? p_ * (p_ + 1) / 2 + q_ : 0) * npairs;
+            d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
+            const double *w0 = row - d_;          // 16-byte aligned window
+            const int lim = npairs + d_;          // valid doubles of the window
+#pragma unroll
+            for (int u = 0; u < kPtRawMax; ++u) {
+                if (u < nraw) {
+                    const int j = 128 * u + 2 * lane;
+                    double2 v = make_double2(0.0, 0.0);
+                    if (ok) {
+                        if (j + 1 < lim) v = *reinterpret_cast<const double2 *>(w0 + j);
+                        else if (j < lim) v.x = w0[j];
+                    }
+                    raw[u] = v;
+                }
+            }
+        }
+    };
+    auto row_to_fragments = [&](double (&m)[NT][KS], int d_) {
+        if constexpr (ROWBUF) {
+#pragma unroll
+            for (int u = 0; u < kPtRawMax; ++u)
+                if (u < nraw) *reinterpret_cast<double2 *>(mrow + 128 * u + 2 * lane) = raw[u];
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) m[rt][kk] = mrow[foff[rt][kk] + d_];
+        }
+    };
+
     // first matrix of this wave: operand loads issued before the LDS fill of X
     double mf[NT][KS];
     int p = 0, q = 0;
     bool have = pair_of(t_begin, wave, p, q);
-    load_matrix(mf, have, p, q);
+    if constexpr (ROWBUF) fetch_row(have, p, q, dlt);
+    else load_matrix(mf, have, p, q);
     for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += 256) {
         const int d = idx / NPAD, c = idx % NPAD;
         double v = 0.0;
@@ -216,14 +275,16 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
         for (int t = 0; t < NT; ++t) xf[kk][t] = Xs[(4 * kk + l4) * LDX + t * 16 + l15];
+    if constexpr (ROWBUF) row_to_fragments(mf, dlt);
 
     for (int t = t_begin; t < t_end; ++t) {
         for (int ql = wave; ql < QT; ql += 4) {
             // prefetch the wave's next matrix: slot ql + 4 of this tile, else its first slot of the next tile
-            double mn[NT][KS];
+            double mn[ROWBUF ? 1 : NT][ROWBUF ? 1 : KS];
             int pn = 0, qn = 0;
             const bool have_next = (ql + 4 < QT) ? pair_of(t, ql + 4, pn, qn) : (t + 1 < t_end && pair_of(t + 1, wave, pn, qn));
-            load_matrix(mn, have_next, pn, qn);
+            if constexpr (ROWBUF) fetch_row(have_next, pn, qn, dlt_next);
+            else load_matrix(mn, have_next, pn, qn);
             if (have) {  // wave-uniform
                 // H = M X
                 // (a dependent f64 MFMA costs ~3x the issue interval: the NT*NT tile chains are interleaved)
@@ -281,10 +342,14 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
                             }
                         }
             }
+            if constexpr (ROWBUF) {
+                row_to_fragments(mf, dlt_next);   // (the fragments of the current matrix are consumed: same wave, in order)
+            } else {
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
+                for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = mn[rt][kk];
+                    for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = mn[rt][kk];
+            }
             have = have_next;
             p = pn;
             q = qn;
@@ -380,14 +445,25 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     const int ntiles = a.lead_sym ? (n * (n + 1) / 2 + 7) / 8 : n * ntq;
     const dim3 grid((unsigned)((ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
     const size_t stage_rows = a.rs_lower ? (size_t)n * (n + 1) / 2 : (size_t)n * n;
+    // dense (pair, pair) operand: coalesced row fetch through a wave-private LDS row (EVC_PT_ROWBUF=0: gather)
+    static const bool rowbuf_on = !(getenv("EVC_PT_ROWBUF") && atoi(getenv("EVC_PT_ROWBUF")) == 0);
+    const bool rowbuf = rowbuf_on && a.in_pairs;
+    const size_t rowbuf_doubles = rowbuf ? (size_t)4 * kPtRowLen + 2 : 0;
     if (npad == 16) {
-        const size_t lds = sizeof(double) * ((size_t)16 * 16 + stage_rows * 9);
-        hipLaunchKernelGGL(pt_kernel<16>, grid, dim3(256), lds, st, a);
+        const size_t lds = sizeof(double) * ((size_t)16 * 16 + stage_rows * 9 + rowbuf_doubles);
+        if (rowbuf) hipLaunchKernelGGL((pt_kernel<16, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((pt_kernel<16, false>), grid, dim3(256), lds, st, a);
     } else if (npad == 32) {
-        const size_t lds = sizeof(double) * ((size_t)32 * 48 + stage_rows * 9);
-        static LdsAttr attr;
-        if (int rc = allow_dynamic_lds(pt_kernel<32>, attr, 160 * 1024, "pair_transform")) return rc;
-        hipLaunchKernelGGL(pt_kernel<32>, grid, dim3(256), lds, st, a);
+        const size_t lds = sizeof(double) * ((size_t)32 * 48 + stage_rows * 9 + rowbuf_doubles);
+        if (rowbuf) {
+            static LdsAttr attr;
+            if (int rc = allow_dynamic_lds(pt_kernel<32, true>, attr, 160 * 1024, "pair_transform")) return rc;
+            hipLaunchKernelGGL((pt_kernel<32, true>), grid, dim3(256), lds, st, a);
+        } else {
+            static LdsAttr attr;
+            if (int rc = allow_dynamic_lds(pt_kernel<32, false>, attr, 160 * 1024, "pair_transform")) return rc;
+            hipLaunchKernelGGL((pt_kernel<32, false>), grid, dim3(256), lds, st, a);
+        }
     } else {
         set_error("pair_transform: n=%d not supported (1..32)", n);
         return -1;

@@ -1,0 +1,40 @@
+"""Timing of the two single-workgroup eigen-kernels alone (one geometry): python tools/micro/loewdin_time.py [n] [T]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from evcont_amd import ops
+from evcont_amd.synthetic import make_ao_arrays, make_trdms
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device("cuda:0")
+ao = make_ao_arrays(n, 3, 1)
+S = torch.from_numpy(ao.S).to(dev); h = torch.from_numpy(ao.hcore).to(dev)
+def timeit(f, reps=50):
+    for _ in range(5): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+import ctypes as C
+from evcont_amd import _lib
+lib = _lib.load()
+def dbg(tag):
+    st = (C.c_longlong * 64)(); va = (C.c_double * 64)()
+    fn = lib.evc_debug_read; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    fn(st, va, 64)
+    t = [ (st[i] - st[0]) / 100.0 for i in range(11)]
+    print(tag, "stamps(us)", [round(x, 1) for x in t], "sweeps", va[20], "emax", [va[i] for i in range(4)], "delta", [va[8+i] for i in range(3)])
+print("loewdin n=%d: %.1f us" % (n, timeit(lambda: ops.loewdin(S, h))))
+dbg("loewdin")
+St, one, two = make_trdms(4, T, 3)
+rng = np.random.default_rng(5)
+H = rng.standard_normal((T, T)); H = 0.5 * (H + H.T)
+P = T * (T + 1) // 2
+a, b = np.tril_indices(T)
+rows1 = torch.from_numpy(np.zeros(T * T)).to(dev)
+rows2 = torch.from_numpy(np.ascontiguousarray(H[a, b])).to(dev)
+Sd = torch.from_numpy(St).to(dev)
+print("subspace T=%d: %.1f us" % (T, timeit(lambda: ops.subspace_solve(rows1, rows2, Sd, 2, 1))))
+dbg("subspace")
