@@ -413,6 +413,231 @@ __device__ __forceinline__ double block_max_nan(double v, double *red) {
     return t;
 }
 
+// ------------------------------------------------------------------ FP32 tridiagonal eigensolver on ONE wave
+// Start vectors for the refinement below, as LAPACK's xSYEVX would compute them, in single precision: Householder
+// tridiagonalisation, eigenvalues by multisection on the Sturm count, eigenvectors of the tridiagonal matrix by
+// twisted factorisation, back-transformation with the reflectors.  ~20 us for m = 30 where the Jacobi sweeps take
+// 80.  Nothing here has to be accurate (the refinement squares the error and checks itself; vectors that come out
+// parallel -- eigenvalues closer than single precision resolves -- make it give up, and the caller falls back to the
+// Jacobi start), so there is no reorthogonalisation inside clusters and no safeguard beyond keeping pivots finite.
+// Lane map: j = lane & 31 (row of the matrix, eigenvalue, eigenvector), h = lane >> 5 (column half / direction).
+constexpr int kTp = 36;    // floats per row of the matrix being reduced (16-byte aligned rows)
+constexpr int kZfp = 33;   // floats per eigenvector row of the result (lane-private rows, conflict-free)
+
+__device__ __forceinline__ float half32_sum(float v) {   // sum over the 32 lanes j (both halves hold the same values)
+    v += dpp_quad<kQuadXor1>(v);
+    v += dpp_quad<kQuadXor2>(v);
+    v += dpp_quad<0x141>(v);
+    v += dpp_quad<0x140>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// Af: m x m matrix (pitch kTp, rows/columns >= m zero), destroyed.  Zf[j*kZfp + i] = component i of eigenvector j
+// (unnormalised), zn[j] = 1 / its norm.  scr: 32*32*5 + 5*32 floats; cntbuf: [2][8][32] ints (Sturm counts of a
+// multisection round).  Called by the whole workgroup (it
+// contains barriers): the reduction and the eigenvectors are chains on wave 0, the multisection runs one abscissa
+// per lane on all four waves.
+__device__ __forceinline__ void tridiag_eig_wg_f32(float *Af, int m, float *Zf, float *zn, float *scr, int *cntbuf) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    float *Vh = scr;                    // [k][r] reflector k
+    float *fD = Vh + 32 * 32;           // [i][j][h] pivots of the forward / backward factorisation of lane pair j
+    float *fF = fD + 2 * 32 * 32;       // [i][j][h] multipliers
+    float *vv = fF + 2 * 32 * 32;       // v of the current step
+    float *ww = vv + 32;                // w
+    float *dd = ww + 32, *ee = dd + 32, *bb = ee + 32;   // diagonal, off-diagonal, 2 / v^T v
+    const int c0 = h * 16;
+    // ---- Householder reduction: A <- H_k A H_k, H_k = I - beta v v^T, v zero up to row k
+    for (int k = 0; wave == 0 && k + 2 < m; ++k) {
+        const float x = (j > k && j < m) ? Af[j * kTp + k] : 0.0f;
+        const float sig = half32_sum(x * x);
+        const float xk1 = readlane_f32(x, k + 1);
+        const float rest = sig - xk1 * xk1;            // what the reflector has to remove
+        float alpha = xk1, beta = 0.0f, v = 0.0f;
+        if (rest > 1.0e-30f) {
+            alpha = -copysignf(__builtin_sqrtf(sig), xk1);
+            beta = __builtin_amdgcn_rcpf(sig - xk1 * alpha);
+            v = (j == k + 1) ? xk1 - alpha : x;
+        }
+        if (h == 0) {
+            vv[j] = v;
+            Vh[k * 32 + j] = v;
+            if (j == 0) {
+                dd[k] = Af[k * kTp + k];
+                ee[k] = alpha;
+                bb[k] = beta;
+            }
+        }
+        float a[16], vc[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 t = *reinterpret_cast<const float4 *>(Af + j * kTp + c0 + 4 * u);
+            const float4 q = *reinterpret_cast<const float4 *>(vv + c0 + 4 * u);
+            a[4 * u] = t.x; a[4 * u + 1] = t.y; a[4 * u + 2] = t.z; a[4 * u + 3] = t.w;
+            vc[4 * u] = q.x; vc[4 * u + 1] = q.y; vc[4 * u + 2] = q.z; vc[4 * u + 3] = q.w;
+        }
+        float part = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) part = fmaf(a[c], vc[c], part);
+        float pr = (part + __shfl_xor(part, 32)) * beta;          // p = beta A v
+        const float K = 0.5f * beta * half32_sum(pr * v);
+        const float w = pr - K * v;                               // (rows <= k: v = 0, and p is not used there)
+        if (h == 0) ww[j] = (j > k) ? w : 0.0f;
+        const float wr = (j > k) ? w : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 q = *reinterpret_cast<const float4 *>(ww + c0 + 4 * u);
+            float4 t;
+            t.x = a[4 * u] - (v * q.x + wr * vc[4 * u]);
+            t.y = a[4 * u + 1] - (v * q.y + wr * vc[4 * u + 1]);
+            t.z = a[4 * u + 2] - (v * q.z + wr * vc[4 * u + 2]);
+            t.w = a[4 * u + 3] - (v * q.w + wr * vc[4 * u + 3]);
+            *reinterpret_cast<float4 *>(Af + j * kTp + c0 + 4 * u) = t;
+        }
+    }
+    EVC_STAMP(11);
+    if (threadIdx.x == 0) {
+        dd[m - 2] = Af[(m - 2) * kTp + m - 2];
+        dd[m - 1] = Af[(m - 1) * kTp + m - 1];
+        ee[m - 2] = Af[(m - 1) * kTp + m - 2];
+        ee[m - 1] = 0.0f;
+    }
+    __syncthreads();
+    // ---- eigenvalue j by multisection: one abscissa per lane, 8 per eigenvalue (4 waves x 2 halves) -> 9 sub-intervals
+    //      per round; the Sturm counts of a round are exchanged through LDS (double-buffered: one barrier per round)
+    float dr[32], e2[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        dr[i] = i < m ? dd[i] : 0.0f;
+        const float e = (i + 1 < m) ? ee[i] : 0.0f;
+        e2[i] = e * e;
+    }
+    float glo, ghi, emx = 0.0f;
+    {
+        const float ea = (j > 0 && j < m) ? fabsf(ee[j - 1]) : 0.0f, eb = (j + 1 < m) ? fabsf(ee[j]) : 0.0f;
+        const float dj = j < m ? dd[j] : 0.0f;
+        float lo = j < m ? dj - ea - eb : 3.0e38f, hi = j < m ? dj + ea + eb : -3.0e38f, em = fmaxf(ea, eb);
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            lo = fminf(lo, __shfl_xor(lo, off));
+            hi = fmaxf(hi, __shfl_xor(hi, off));
+            em = fmaxf(em, __shfl_xor(em, off));
+        }
+        const float pad = 1.0e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1.0e-30f;
+        glo = lo - pad;
+        ghi = hi + pad;
+        emx = em;
+    }
+    const float pivmin = 1.0e-30f + 1.0e-14f * emx * emx;
+    // (the Sturm recurrence runs unguarded: a zero pivot gives q = -inf, which counts as negative and is followed by
+    //  q = d - x, as IEEE arithmetic has it; e^2 is kept away from zero so that 0 * inf cannot occur)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) e2[i] = fmaxf(e2[i], 1.0e-36f);
+    float lo = glo, hi = ghi;
+    const int slot = 2 * wave + h;   // 0..7; this lane evaluates abscissae 2 slot + 1, 2 slot + 2 of 16
+    for (int it = 0; it < 6; ++it) {
+        const float wd = (hi - lo) * (1.0f / 17.0f);
+        const float xa = lo + wd * (float)(2 * slot + 1), xb = lo + wd * (float)(2 * slot + 2);
+        float qa = dr[0] - xa, qb = dr[0] - xb;
+        int ca = qa < 0.0f ? 1 : 0, cb2 = qb < 0.0f ? 1 : 0;
+#pragma unroll
+        for (int i = 1; i < 32; ++i) {
+            if (i < m) {   // uniform
+                qa = (dr[i] - xa) - e2[i - 1] * __builtin_amdgcn_rcpf(qa);
+                qb = (dr[i] - xb) - e2[i - 1] * __builtin_amdgcn_rcpf(qb);
+                ca += qa < 0.0f ? 1 : 0;
+                cb2 += qb < 0.0f ? 1 : 0;
+            }
+        }
+        int *cb = cntbuf + (it & 1) * 256;
+        // eigenvalue j (ascending, 0-based) is >= x  <=>  count(x) <= j
+        cb[slot * 32 + j] = (ca <= j ? 1 : 0) + (cb2 <= j ? 1 : 0);
+        __syncthreads();
+        int below = 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) below += cb[p * 32 + j];
+        lo = lo + wd * (float)below;
+        hi = lo + wd;
+    }
+    if (wave != 0) return;
+    const float lam = 0.5f * (lo + hi);
+    EVC_STAMP(12);
+    // ---- eigenvector of the tridiagonal matrix: twisted factorisation (h = 0: from the top, h = 1: from the bottom)
+    {
+        auto at = [&](int ii) { return h ? m - 1 - ii : ii; };
+        float D = dd[at(0)] - lam;
+        for (int ii = 0; ii + 1 < m; ++ii) {
+            const int pos = at(ii), nxt = at(ii + 1), ei = pos < nxt ? pos : nxt;
+            if (fabsf(D) < pivmin) D = -pivmin;
+            const float e = ee[ei], F = e * __builtin_amdgcn_rcpf(D);
+            fD[(pos * 32 + j) * 2 + h] = D;
+            fF[(ei * 32 + j) * 2 + h] = F;
+            D = (dd[nxt] - lam) - F * e;
+        }
+        fD[(at(m - 1) * 32 + j) * 2 + h] = D;
+    }
+    int kt = 0;
+    {
+        float best = 3.0e38f;
+        for (int i = 0; i < m; ++i) {
+            const float g = fabsf(fD[(i * 32 + j) * 2] + fD[(i * 32 + j) * 2 + 1] - (dd[i] - lam));
+            if (g < best) {
+                best = g;
+                kt = i;
+            }
+        }
+    }
+    float nrm = h ? 0.0f : 1.0f;
+    {
+        // h = 0: z_i = -L_i z_{i+1} downwards from the twist; h = 1: z_{i+1} = -U_i z_i upwards
+        float z = 1.0f;
+        if (j < m) {
+            if (h == 0) {
+                Zf[j * kZfp + kt] = 1.0f;
+                for (int i = kt - 1; i >= 0; --i) {
+                    z = -fF[(i * 32 + j) * 2] * z;
+                    Zf[j * kZfp + i] = z;
+                    nrm = fmaf(z, z, nrm);
+                }
+            } else {
+                for (int i = kt; i + 1 < m; ++i) {
+                    z = -fF[(i * 32 + j) * 2 + 1] * z;
+                    Zf[j * kZfp + i + 1] = z;
+                    nrm = fmaf(z, z, nrm);
+                }
+            }
+        }
+    }
+    nrm += __shfl_xor(nrm, 32);
+    EVC_STAMP(13);
+    if (h == 0 && j < m) zn[j] = __builtin_amdgcn_rsqf(nrm);
+    // ---- back-transformation z <- H_0 H_1 ... H_{m-3} z: rows c0 .. c0+15 of eigenvector j in registers
+    float z[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) z[c] = (j < m && c0 + c < m) ? Zf[j * kZfp + c0 + c] : 0.0f;
+    for (int k = m - 3; k >= 0; --k) {
+        float vk[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 t = *reinterpret_cast<const float4 *>(Vh + k * 32 + c0 + 4 * u);
+            vk[4 * u] = t.x; vk[4 * u + 1] = t.y; vk[4 * u + 2] = t.z; vk[4 * u + 3] = t.w;
+        }
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dot = fmaf(vk[c], z[c], dot);
+        dot = (dot + __shfl_xor(dot, 32)) * bb[k];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) z[c] = fmaf(-dot, vk[c], z[c]);
+    }
+    if (j < m)
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c0 + c < m) Zf[j * kZfp + c0 + c] = z[c];
+}
+
 // ---- refinement on the whole workgroup: matrices of up to 32 x 32 in LDS with row pitch kRp ------------------
 // C[i][j] = sum_k P[i][k] Q[j][k] ("row . row": both operands are read along contiguous rows with 16-byte LDS loads;
 // 16 consecutive rows at pitch 34 doubles fall on 16 different 4-bank groups).  Thread (tj,tk) of the 16 x 16 grid owns
@@ -553,13 +778,15 @@ __device__ __forceinline__ bool oa_refine(int m, const double *Ap, double *&Z, d
 // Eigen-decomposition of the symmetric m x m matrix A (LDS, pitch m, both triangles; m <= 32, m even, a trailing
 // decoupled dummy dimension allowed): on return diag(A) = eigenvalues, V (pitch m) = eigenvectors as columns.
 //   warm: V holds the eigenvectors of a nearby problem (any garbage is detected): refinement starts from them;
-//   otherwise, or when that does not contract: FP32 Jacobi start; when that fails as well: FP64 Jacobi.
+//   otherwise, or when that does not contract: FP32 tridiagonal start, then FP32 Jacobi start, then FP64 Jacobi.
+//   nreal: rows/columns nreal..m-1 are the decoupled dummy dimension of an odd problem.
 // A + shift I must be positive definite.  Scratch R6: six matrices of kRsz doubles; Gc: kJwMax x kJwPitch doubles
 // (also serves as the FP32 column buffer); lam: m; red: 8 doubles.
-__device__ __forceinline__ void eigh_small(double *A, double *V, int m, double shift, bool warm, bool fast, double *R6,
-                                           double *Gc, double *lam, double *red) {
+__device__ __forceinline__ void eigh_small(double *A, double *V, int m, int nreal, double shift, bool warm, int fast,
+                                           double *R6, double *Gc, double *lam, double *red) {
     const int tid = threadIdx.x;
     bool ok = false;
+    const bool tri = fast > 1;   // fast: 0 FP64 Jacobi, 1 FP32 Jacobi + refinement, 2 FP32 tridiagonal start first
     if (fast) {
         double *Ap = R6, *Z = R6 + kRsz, *Zt = R6 + 2 * kRsz, *B1 = R6 + 3 * kRsz, *B2 = R6 + 4 * kRsz, *B3 = R6 + 5 * kRsz;
         float *Gf = reinterpret_cast<float *>(Gc);
@@ -581,26 +808,59 @@ __device__ __forceinline__ void eigh_small(double *A, double *V, int m, double s
                 Z = R6 + kRsz; Zt = R6 + 2 * kRsz; B1 = R6 + 3 * kRsz; B2 = R6 + 4 * kRsz; B3 = R6 + 5 * kRsz;
             }
         }
+        double amax = 0.0;
         if (!ok) {
-            // FP32 stage: G0 = (A + shift I) / max|.|, column-major with pitch kJfPitch
-            double amax = 0.0;
             for (int idx = tid; idx < m * m; idx += kThreads) {
                 const int i = idx / m, j = idx - i * m;
-                const double v = fabs(A[idx] + (i == j ? shift : 0.0));
-                amax = (v > amax || v != v) ? v : amax;
+                amax = nanmax(amax, fabs(A[idx] + (i == j ? shift : 0.0)));
             }
             amax = block_max_nan(amax, red);
-            if (amax > 0.0 && amax < 1.0e300) {   // (zero, NaN or Inf input: left to the FP64 path)
+        }
+        const bool sane = amax > 0.0 && amax < 1.0e300;   // (zero, NaN or Inf input: left to the FP64 path)
+        if (!ok && sane && tri) {
+            // FP32 start 1: tridiagonalisation + multisection + twisted factorisation (scratch: the B buffers)
+            float *Af = reinterpret_cast<float *>(B1), *scr = Af + 32 * kTp, *zn = scr + 32 * 32 * 5 + 5 * 32;
+            float *Zf = Gf;
+            const double sc = 1.0 / amax;
+            for (int idx = tid; idx < 32 * kTp; idx += kThreads) {
+                const int i = idx / kTp, j = idx - i * kTp;
+                float v = 0.0f;
+                if (i < nreal && j < nreal) v = (float)(A[i * m + j] * sc);
+                else if (i == j && i < m) v = 40.0f;   // decoupled dummy dimension: an eigenvalue outside the spectrum
+                Af[idx] = v;
+            }
+            __syncthreads();
+            EVC_STAMP(1);
+            tridiag_eig_wg_f32(Af, m, Zf, zn, scr, reinterpret_cast<int *>(Gf + 34 * 32));
+            __syncthreads();
+            EVC_STAMP(2);
+            for (int idx = tid; idx < kRsz; idx += kThreads) {
+                const int i = idx / kRp, j = idx - i * kRp;   // Zt[i][j] = component j of eigenvector i
+                Zt[idx] = (i < m && j < m) ? (double)Zf[i * kZfp + j] * (double)zn[i] : 0.0;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < kRsz; idx += kThreads) {
+                const int i = idx / kRp, j = idx - i * kRp;
+                Z[idx] = (i < m && j < m) ? Zt[j * kRp + i] : 0.0;
+            }
+            __syncthreads();
+            ok = oa_refine(m, Ap, Z, Zt, B1, B2, B3, lam, red, 6);
+            EVC_DBGVAL(21, ok ? 1.0 : 0.0);
+            if (!ok) {
+                Z = R6 + kRsz; Zt = R6 + 2 * kRsz; B1 = R6 + 3 * kRsz; B2 = R6 + 4 * kRsz; B3 = R6 + 5 * kRsz;
+            }
+        }
+        if (!ok && sane) {
+            // FP32 start 2: one-sided Jacobi on G0 = (A + shift I) / max|.|, column-major with pitch kJfPitch
+            {
                 const double sc = 1.0 / amax;
                 for (int idx = tid; idx < kJwMax * kJfPitch; idx += kThreads) {
                     const int j = idx / kJfPitch, i = idx - j * kJfPitch;
                     Gf[idx] = (i < m && j < m) ? (float)((A[i * m + j] + (i == j ? shift : 0.0)) * sc) : 0.0f;
                 }
                 __syncthreads();
-                EVC_STAMP(1);
                 if (tid < 64) jacobi_onesided_wave_f32(Gf, m);
                 __syncthreads();
-                EVC_STAMP(2);
                 // Z0 = normalised columns (a zero column = the decoupled dummy dimension keeps its unit vector)
                 if (tid < m) {
                     double nn = 0.0;
@@ -715,7 +975,7 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
             }
             __syncthreads();
         }
-        eigh_small(A, V, m, 0.0, a.warm != 0, true, R6, Gc, f, red);
+        eigh_small(A, V, m, n, 0.0, a.warm != 0, a.fast, R6, Gc, f, red);
     } else {
         const bool warm = a.warm && warm_start_rotate(A, V, Xs, n, m, U, n, red);
         if (m <= kJwMax) jacobi_eigh_wave(A, V, m, 0.0, !warm, Gc, f);
@@ -727,6 +987,38 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
         if (tid < n) sv[tid] = s;
     }
     __syncthreads();
+    if (m <= kJwMax && a.fast) {
+        // X = V diag(f) V^T and h1 = X^T h X as row.row products at pitch kRp (the refinement's buffers are free)
+        double *Vf = R6, *Vp = R6 + kRsz, *Xp = R6 + 2 * kRsz, *hp = R6 + 3 * kRsz, *Tt = R6 + 4 * kRsz;
+        for (int idx = tid; idx < kRsz; idx += kThreads) {
+            const int i = idx / kRp, j = idx - i * kRp;
+            const bool in = i < n && j < n;
+            const double v = in ? V[i * m + j] : 0.0;
+            Vp[idx] = v;
+            Vf[idx] = in ? v * f[j] : 0.0;
+            hp[idx] = (in && h) ? h[i * n + j] : 0.0;
+            Xp[idx] = 0.0;
+            Tt[idx] = 0.0;
+            if (in) U[i * n + j] = v;
+        }
+        __syncthreads();
+        mm_rowrow(m, Vf, Vp, [&](int i, int j, double v) {
+            if (i < n && j < n) {
+                Xp[i * kRp + j] = v;
+                X[i * n + j] = v;
+            }
+        });
+        if (h && h1) {
+            __syncthreads();
+            // Tt[j][i] = (h X)[i][j] = sum_k X[j][k] h[i][k]  (X symmetric);  h1[i][j] = sum_k X[i][k] Tt[j][k]
+            mm_rowrow(m, Xp, hp, [&](int j, int i, double v) { Tt[j * kRp + i] = v; });
+            __syncthreads();
+            mm_rowrow(m, Xp, Tt, [&](int i, int j, double v) {
+                if (i < n && j < n) h1[i * n + j] = v;
+            });
+        }
+        return;
+    }
     // X = V diag(f) V^T  (a dummy column, if any, has f = 0)
     mm16(n, [&](int i, int k) { return V[i * m + k] * f[k]; }, [&](int k, int j) { return V[j * m + k]; },
          [&](int i, int j, double v) {
@@ -752,8 +1044,9 @@ static size_t jacobi_aux_bytes(int m) {
            (m <= kJwMax ? sizeof(double) * ((size_t)kJwMax * kJwPitch + (size_t)6 * kRsz) + 16 : 0);
 }
 
-static bool eigh_fast_enabled() {
-    static const bool on = !(getenv("EVC_EIGH_F32") && atoi(getenv("EVC_EIGH_F32")) == 0);
+// EVC_EIGH_F32: 0 = FP64 Jacobi, 1 = FP32 Jacobi + refinement, 2 (default) = FP32 tridiagonal start + refinement
+static int eigh_fast_enabled() {
+    static const int on = getenv("EVC_EIGH_F32") ? atoi(getenv("EVC_EIGH_F32")) : 2;
     static bool dbg_done = false;
     if (!dbg_done) {
         dbg_done = true;
@@ -767,7 +1060,7 @@ static bool eigh_fast_enabled() {
 
 int launch_loewdin(const LoewdinArgs &a_in, int count, hipStream_t st) {
     LoewdinArgs a = a_in;
-    a.fast = eigh_fast_enabled() ? 1 : 0;
+    a.fast = eigh_fast_enabled();
     const int m = (a.n + 1) & ~1;
     const size_t lds = sizeof(double) * (size_t)3 * m * m + jacobi_aux_bytes(m);
     static LdsAttr attr;
@@ -775,6 +1068,56 @@ int launch_loewdin(const LoewdinArgs &a_in, int count, hipStream_t st) {
     hipLaunchKernelGGL(loewdin_kernel, dim3(count), dim3(kThreads), lds, st, a);
     EVC_LAUNCH_CHECK("loewdin");
     return 0;
+}
+
+// Cholesky factor of the symmetric positive definite T x T matrix S (lower triangle of Ssrc, pitch T) and its
+// inverse B = L^-1, on ONE wave with everything in registers: lane i holds row i of L; the pivot and the column
+// entries a step needs from other lanes travel through v_readlane (uniform operands), so the 2 T dependent steps
+// carry no LDS round trip and no barrier.  Writes B (lower triangular) to Bi at pitch kRp; a matrix that is not
+// positive definite yields NaNs.  T <= 32.  Called by wave 0 only.
+__device__ __forceinline__ void chol_inverse_wave(const double *Ssrc, int T, double *Bi) {
+    const int i = threadIdx.x & 31;
+    double a[32], rinv[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        a[k] = (i < T && k < T) ? (k <= i ? Ssrc[i * T + k] : 0.0) : (k == i ? 1.0 : 0.0);
+        rinv[k] = 1.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        if (j < T) {   // uniform
+            const double d = readlane_f64(a[j], j);
+            double rs = __builtin_amdgcn_rsq(d);
+            rs = rs * fma(-0.5 * d * rs, rs, 1.5);
+            rs = rs * fma(-0.5 * d * rs, rs, 1.5);
+            const double lij = a[j] * rs;   // lane j: sqrt(d)
+            a[j] = lij;
+            rinv[j] = rs;                   // 1 / L_jj (uniform)
+#pragma unroll
+            for (int k = j + 1; k < 32; ++k)
+                if (k < T) a[k] = fma(-lij, readlane_f64(lij, k), a[k]);
+        }
+    }
+    double b[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        b[r] = 0.0;
+        if (r < T) {   // uniform
+            double acc = (r == i) ? 1.0 : 0.0, acc2 = 0.0;
+#pragma unroll
+            for (int k = 0; k + 1 < r; k += 2) {
+                acc = fma(-readlane_f64(a[k], r), b[k], acc);
+                acc2 = fma(-readlane_f64(a[k + 1], r), b[k + 1], acc2);
+            }
+            if (r & 1) acc = fma(-readlane_f64(a[r - 1], r), b[r - 1], acc);
+            b[r] = (acc + acc2) * rinv[r];
+        }
+    }
+    if (threadIdx.x < 32 && i < T) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r)
+            if (r < T) Bi[r * kRp + i] = b[r];
+    }
 }
 
 // ------------------------------------------------------------------ subspace solve
@@ -794,6 +1137,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         if (a.vstd) a.vstd += g * a.sw;
         if (a.e_shift_dev) a.e_shift = a.e_shift_dev[g];
     }
+    EVC_STAMP(30);
     const int T = a.T;
     const int m = (T + 1) & ~1;
     double *H = sm;             // T*T  assembled H; later the coefficient vectors
@@ -850,46 +1194,76 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     __syncthreads();
     if (a.Hout)
         for (int idx = tid; idx < T * T; idx += kThreads) a.Hout[idx] = H[idx];
+    const bool fastbase = a.fast && m <= kJwMax;   // workgroup-parallel factorisation (T <= 32)
+    EVC_STAMP(31);
+    if (fastbase) {
+        // (3') Cholesky S = L L^T and B = L^-1 in the registers of one wave (chol_inverse_wave); (4') C = B Hsym B^T as
+        //      two row.row products on the workgroup, matrices at pitch kRp in the refinement's buffers (free until the
+        //      eigensolver starts).  The left-looking thread-per-row loops of the general path below are chains of
+        //      ~T^2/2 dependent LDS reads each.
+        double *Bi = R6 + kRsz, *Hs = R6 + 2 * kRsz, *Wt = R6 + 3 * kRsz;
+        for (int idx = tid; idx < kRsz; idx += kThreads) {
+            const int i = idx / kRp, j = idx - i * kRp;
+            const bool in = i < T && j < T;
+            Hs[idx] = in ? (i >= j ? H[i * T + j] : H[j * T + i]) : 0.0;
+            Bi[idx] = 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) chol_inverse_wave(L, T, Bi);
+        __syncthreads();
+        EVC_STAMP(33);
+        // Wt[j][k] = sum_l B[j][l] Hs[k][l];  C[i][j] = sum_k B[i][k] Wt[j][k]  (rows >= T are zero: decoupled dummy)
+        mm_rowrow(m, Bi, Hs, [&](int j, int k, double v) { Wt[j * kRp + k] = v; });
+        __syncthreads();
+        mm_rowrow(m, Bi, Wt, [&](int i, int j, double v) { V[i * m + j] = v; });
+        // keep B = L^-1 (pitch m) where the left-looking path keeps L: the back-transformation is c = B^T y
+        for (int idx = tid; idx < m * m; idx += kThreads) {
+            const int i = idx / m, j = idx - i * m;
+            L[idx] = Bi[i * kRp + j];
+        }
+        __syncthreads();
+    } else {
     // (3) Cholesky of S (lower triangle, as dpotrf('L')), left-looking: thread i owns row i and
-    //     recomputes the pivot itself, so the column needs no barrier between pivot and scaling.
-    for (int j = 0; j < T; ++j) {
-        const int i = tid;
-        double v = 0.0, d = 0.0;
-        if (i >= j && i < T) {
-            v = L[i * T + j];
-            d = L[j * T + j];
-            for (int k = 0; k < j; ++k) {
-                const double ljk = L[j * T + k];
-                v = fma(-L[i * T + k], ljk, v);
-                d = fma(-ljk, ljk, d);
-            }
-            d = sqrt(d);
-        }
-        __syncthreads();
-        if (i >= j && i < T) L[i * T + j] = (i == j) ? d : v / d;
-        __syncthreads();
-    }
-    // (4) C = L^-1 Hsym L^-T, Hsym from the LOWER triangle of H (dsygst).
-    //     thread j solves L z = Hsym[:,j]; result in Cm[:,j]
-    if (tid < T) {
-        const int j = tid;
-        for (int i = 0; i < T; ++i) {
-            double v = (i >= j) ? H[i * T + j] : H[j * T + i];
-            for (int k = 0; k < i; ++k) v = fma(-L[i * T + k], Cm[k * m + j], v);
-            Cm[i * m + j] = v / L[i * T + i];
-        }
-    }
-    __syncthreads();
-    //     thread i solves L w = Z[i,:]^T; result is row i of C, kept in V[i,:]
-    if (tid < T) {
-        const int i = tid;
+        //     recomputes the pivot itself, so the column needs no barrier between pivot and scaling.
         for (int j = 0; j < T; ++j) {
-            double v = Cm[i * m + j];
-            for (int k = 0; k < j; ++k) v = fma(-L[j * T + k], V[i * m + k], v);
-            V[i * m + j] = v / L[j * T + j];
+            const int i = tid;
+            double v = 0.0, d = 0.0;
+            if (i >= j && i < T) {
+                v = L[i * T + j];
+                d = L[j * T + j];
+                for (int k = 0; k < j; ++k) {
+                    const double ljk = L[j * T + k];
+                    v = fma(-L[i * T + k], ljk, v);
+                    d = fma(-ljk, ljk, d);
+                }
+                d = sqrt(d);
+            }
+            __syncthreads();
+            if (i >= j && i < T) L[i * T + j] = (i == j) ? d : v / d;
+            __syncthreads();
         }
+        // (4) C = L^-1 Hsym L^-T, Hsym from the LOWER triangle of H (dsygst).
+        //     thread j solves L z = Hsym[:,j]; result in Cm[:,j]
+        if (tid < T) {
+            const int j = tid;
+            for (int i = 0; i < T; ++i) {
+                double v = (i >= j) ? H[i * T + j] : H[j * T + i];
+                for (int k = 0; k < i; ++k) v = fma(-L[i * T + k], Cm[k * m + j], v);
+                Cm[i * m + j] = v / L[i * T + i];
+            }
+        }
+        __syncthreads();
+        //     thread i solves L w = Z[i,:]^T; result is row i of C, kept in V[i,:]
+        if (tid < T) {
+            const int i = tid;
+            for (int j = 0; j < T; ++j) {
+                double v = Cm[i * m + j];
+                for (int k = 0; k < j; ++k) v = fma(-L[j * T + k], V[i * m + k], v);
+                V[i * m + j] = v / L[j * T + j];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int idx = tid; idx < m * m; idx += kThreads) {
         const int i = idx / m, j = idx - i * m;
         double v = 0.0;
@@ -897,6 +1271,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         Cm[idx] = v;  // the dummy dimension (odd T) stays decoupled and is skipped below
     }
     __syncthreads();
+    EVC_STAMP(34);
     // warm start from the standard-form eigenvectors of the previous call (H is free as scratch here)
     if (m <= kJwMax) {
         // the standard-form matrix is indefinite: shift it by a Gershgorin bound (the eigenvectors do not change)
@@ -916,7 +1291,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
                 for (int idx = tid; idx < m * m; idx += kThreads) V[idx] = a.vstd[idx];
                 __syncthreads();
             }
-            eigh_small(Cm, V, m, shift, warm, true, R6, Gc, ev, red);
+            eigh_small(Cm, V, m, T, shift, warm, a.fast, R6, Gc, ev, red);
         } else {
             const bool warm = a.warm && a.vstd && warm_start_rotate(Cm, V, H, T, m, a.vstd, m, red);
             jacobi_eigh_wave(Cm, V, m, shift, !warm, Gc, ev);
@@ -927,6 +1302,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     }
     if (a.vstd)
         for (int idx = tid; idx < m * m; idx += kThreads) a.vstd[idx] = V[idx];
+    EVC_STAMP(35);
     // (5) ascending order
     if (tid < T) ev[tid] = Cm[tid * m + tid];
     __syncthreads();
@@ -937,8 +1313,17 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         order[rank] = tid;
     }
     __syncthreads();
-    // (6) back-transform c = L^-T y for the requested roots (thread per root); store into H region
-    if (tid < a.nroots) {
+    // (6) back-transform c = L^-T y for the requested roots; store into H region
+    if (fastbase) {
+        // c_i = sum_{k >= i} B[k][i] y_k with B = L^-1 kept in `L` (pitch m): one thread per (root, i)
+        for (int idx = tid; idx < a.nroots * T; idx += kThreads) {
+            const int root = idx / T, i = idx - root * T, col = order[root];
+            double c = 0.0;
+            for (int k = i; k < T; ++k) c = fma(L[k * m + i], V[k * m + col], c);
+            H[idx] = c;
+        }
+        if (tid < a.nroots) a.evals[tid] = ev[order[tid]] + a.e_shift;
+    } else if (tid < a.nroots) {
         const int col = order[tid];
         double *c = H + tid * T;
         for (int i = T - 1; i >= 0; --i) {
@@ -950,6 +1335,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     }
     __syncthreads();
     for (int idx = tid; idx < a.nroots * T; idx += kThreads) a.evecs[idx] = H[idx];
+    EVC_STAMP(36);
     // (7) weights of root 0 for the predicted RDMs
     const double *c0 = H;
     if (a.w1)
@@ -977,7 +1363,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
 
 int launch_subspace_solve(const SolveArgs &a_in, int count, hipStream_t st) {
     SolveArgs a = a_in;
-    a.fast = eigh_fast_enabled() ? 1 : 0;
+    a.fast = eigh_fast_enabled();
     const int m = (a.T + 1) & ~1;
     const size_t lds = sizeof(double) * (size_t)4 * m * m + sizeof(int) * m + jacobi_aux_bytes(m);
     static LdsAttr attr;

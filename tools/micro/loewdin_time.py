@@ -24,8 +24,8 @@ def dbg(tag):
     st = (C.c_longlong * 64)(); va = (C.c_double * 64)()
     fn = lib.evc_debug_read; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     fn(st, va, 64)
-    t = [ (st[i] - st[0]) / 100.0 for i in range(11)]
-    print(tag, "stamps(us)", [round(x, 1) for x in t], "sweeps", va[20], "emax", [va[i] for i in range(4)], "delta", [va[8+i] for i in range(3)])
+    t = [ (st[i] - st[0]) / 100.0 for i in range(14)]
+    print(tag, "kernel phases", [round((st[i]-st[30])/100.0,1) for i in range(30,37)]); print(tag, "stamps(us)", [round(x, 1) for x in t], "sweeps", va[20], "emax", [va[i] for i in range(4)], "delta", [va[8+i] for i in range(3)])
 print("loewdin n=%d: %.1f us" % (n, timeit(lambda: ops.loewdin(S, h))))
 dbg("loewdin")
 St, one, two = make_trdms(4, T, 3)
