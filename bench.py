@@ -270,6 +270,24 @@ def main():
                 "stages": stages, "per_rank": per_rank,
                 "geometries_per_step": job_g}
 
+    def step_roofline(ms_per_step, geoms):
+        """Whole step against the two rooflines at once: ALGORITHMIC bytes (the resident t-RDMs twice, the AO inputs
+        of every geometry once, the results) at the HBM peak PLUS the FP64 matrix work of the four-index rotations and
+        the two batched contractions at the MFMA peak, over the measured time of a step on ONE GPU."""
+        packed_in = a.layout == "sym8" and a.integrals == "packed" and n <= 32
+        npr = n * (n + 1) // 2
+        ao = (npr * npr + 3 * n * n * npr if packed_in else 4 * n ** 4) + (2 + 3 + 3 * A) * n * n + 3 * A
+        passes = 1 if a.energy_only else 2
+        launches = -(-geoms // MAX_G_PER_LAUNCH)
+        nbytes = 8.0 * (passes * launches * (rows * cols + T * T * n * n) + geoms * ao + geoms * (3 * A + T))
+        lead = npr if a.layout == "sym8" else n * n
+        flops = geoms * (2 if a.energy_only else 4) * lead * 4.0 * n ** 3 + passes * 2.0 * rows * cols * geoms
+        t_min = nbytes / (HBM_PEAK_GBS * 1e9) + flops / (MFMA_F64_PEAK_TFLOPS * 1e12)
+        return {"frac": t_min / (ms_per_step * 1e-3), "bytes_per_step": nbytes, "flops_per_step": flops,
+                "ms_at_peaks": t_min * 1e3, "ms_per_step": ms_per_step,
+                "note": "bytes / 8 TB/s + flops / 78.6 TFLOP/s over the measured step (per GPU); FP64 MFMA sustains "
+                        "47 TFLOP/s on this part (profiles/mfma_f64_peak.txt)"}
+
     G, S = max(1, a.batch), max(1, a.streams)
     pairs_first = world > 1 and a.shard == "pairs"
     full_range, my_range = (0, rows), shard_rows(rows, world, rank)
@@ -287,14 +305,25 @@ def main():
 
     out = None
     if rank == 0:
-        traffic = None
+        # HBM traffic of one K5 launch: PMC counters cannot be read from inside this process, so the figure comes from
+        # the committed rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json) -- and only while the
+        # streaming-kernel sources are byte-identical to the profiled ones; otherwise null
+        traffic, traffic_note = None, "no PMC record for this configuration"
         tj = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
+                import hashlib
                 rec = json.load(open(tj))
+                hh = hashlib.sha256()
+                for f_ in ("gemv_mfma.hip", "gemv_stream.hip"):
+                    hh.update(open(os.path.join(REPO, "evcont_amd", "csrc", f_), "rb").read())
                 key = f"{a.workload}/{a.layout}/batch{G}/k5"
                 if key in rec and not pairs_first:
-                    traffic = rec[key]["hbm_bytes_per_launch"]
+                    if rec.get("_source_sha256") == hh.hexdigest():
+                        traffic = rec[key]["hbm_bytes_per_launch"]
+                        traffic_note = f"profiles/pmc_traffic.json, kernel {rec[key]['kernel']}, same kernel sources"
+                    else:
+                        traffic_note = "profiles/pmc_traffic.json was collected with other kernel sources: not quoted"
             except Exception:
                 traffic = None
         what = "energy" if a.energy_only else "energy+force"
@@ -330,11 +359,14 @@ def main():
             "roofline": {"bound": "hbm",
                          "kernel": "K5: H_ab = Gamma . h2 (gemv_rows_*_kernel, the 2-RDM x ERI contraction), rank 0",
                          "achieved": m["k5_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": m["k5_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": m["k5_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "region": f"the timed region `value` is measured in ({m['streams']} stream(s); other batches' "
+                                   f"kernels share the chip when > 1)",
                          "bytes_per_launch": m["bytes_per_launch"], "ms_per_launch": m["k5_ms"],
                          "launches": m["launches"], "geometries_per_launch": m["geometries_per_launch"]},
             "kernels": {"k5_rows_ms": m["k5_ms"], "k8_cols_ms": m["k8_ms"], "k8_cols_GBs": m["k8_GBs"]},
             "last_energy": m["last_energy"],
+            "roofline_step": step_roofline(m["ms_per_step"], m["geometries_per_step"] if world == 1 else G),
             # what the collectives library itself reports, and what each rank delivered on its own clock: in the
             # geometry-sharded job a rank's figure is directly comparable with the N=1 run of the same command
             "ranks_seen": dist.get_world_size() if world > 1 else 1,
@@ -371,15 +403,11 @@ def main():
                                     "k5_rows_ms": one["k5_ms"], "k5_GBs": one["k5_GBs"],
                                     "k5_frac": one["k5_GBs"] / HBM_PEAK_GBS, "k8_cols_ms": one["k8_ms"],
                                     "k8_GBs": one["k8_GBs"], "k8_frac": one["k8_GBs"] / HBM_PEAK_GBS}
-            # the roofline of a kernel is a statement about the kernel: quote it where K5 has the device to
-            # itself, and keep its figure inside the multi-stream headline region beside it
-            r = out["roofline"]
-            r["contended"] = {"achieved": r["achieved"], "frac": r["frac"], "ms_per_launch": r["ms_per_launch"],
-                              "note": f"same kernel inside the {S}-stream headline region, other batches' kernels "
-                                      f"running beside it"}
-            r.update(achieved=one["k5_GBs"], frac=one["k5_GBs"] / HBM_PEAK_GBS, ms_per_launch=one["k5_ms"],
-                     launches=one["launches"],
-                     region="single_stream leg (HIP events on the launch stream, same batches, one stream)")
+            # `roofline` describes K5 inside the headline region; the same kernel with the device to itself:
+            out["roofline"]["uncontended"] = {
+                "achieved": one["k5_GBs"], "frac": one["k5_GBs"] / HBM_PEAK_GBS, "ms_per_launch": one["k5_ms"],
+                "launches": one["launches"],
+                "region": "single_stream leg (HIP events on the launch stream, same batches, one stream)"}
             # the other multi-workgroup stages of the same leg, against their own rooflines
             st = one["stages"]
             out["single_stream"]["stages_ms_per_launch"] = st
@@ -409,6 +437,39 @@ def main():
                                 "note": "one geometry per step on one stream (no batching, no overlap)",
                                 "k5_rows_ms": md["k5_ms"], "k5_GBs": md["k5_GBs"], "k5_frac": md["k5_GBs"] / HBM_PEAK_GBS,
                                 "k8_cols_ms": md["k8_ms"], "k8_GBs": md["k8_GBs"]}
+    if world == 1 and not a.no_md_regime and not a.energy_only:
+        # the same one-geometry-per-step regime with the integrals arriving from the HOST every step, as in an MD run
+        # driven by PySCF (MD_utils.py:40-55): pinned staging buffers -> H2D inside the timed region -> one HIP graph
+        # per step (evcont_amd/hosted.py).  Four evaluators with four different staged geometries are cycled, cold
+        # start (comparable with md_regime); the host-side production of the integrals is not part of the path.
+        from evcont_amd.hosted import HostedEvaluator
+        hevs = []
+        for k in range(4):
+            src = aos[k]
+            hv = HostedEvaluator(trd, A, src.aoslices.cpu().numpy(), warm_start=False)
+            run = src.packed_ip1(eri=True) if hv.packed else src
+            st_ = hv.staging()
+            for name in ("S", "hcore", "ipovlp", "dhcore", "gnuc", "eri", "eri_ip1"):
+                np.copyto(st_[name], getattr(run, name).cpu().numpy().reshape(st_[name].shape))
+            st_["enuc"][0] = src.enuc
+            for _ in range(3):
+                hv.run()               # two eager calls, then the capture
+            hevs.append(hv)
+        fence()
+        nst = max(20, min(a.steps * 2, 200))
+        t0 = time.perf_counter()
+        for k in range(nst):
+            e_h, _ = hevs[k % 4].run()
+        fence()
+        dt_h = time.perf_counter() - t0
+        up_bytes = sum(v.numel() * 8 for v in hevs[0].host.values())
+        if rank == 0:
+            out["md_hosted"] = {"value": nst / dt_h, "unit": "geometries/s", "ms_per_step": 1e3 * dt_h / nst,
+                                "h2d_bytes_per_step": up_bytes, "graph": hevs[0].graph is not None,
+                                "note": "one geometry per step, AO integrals in pinned HOST memory, uploaded inside the "
+                                        "timed region; whole step = one HIP graph (uploads, 15 kernels, downloads); "
+                                        "cold start; PCIe-inclusive, never `value`"}
+        del hevs
     if world == 1 and not a.no_md_regime and not a.energy_only:
         # an MD-like sequence: geometries that change slowly from step to step (linear blend of two of the
         # synthetic geometries in 0.1 % steps), one per step on one stream, the eigensolvers warm-started

@@ -14,7 +14,8 @@ from .ab_initio_eigenvector_continuation import (approximate_ground_state_OAO, _
                                                  get_trdm_compression)
 from .electron_integral_utils import get_basis, get_integrals  # noqa: F401 (re-export)
 from .evaluator import ContinuationEvaluator, DeviceAO
-from .integrals import ao_arrays, energy_nuc, grad_nuc
+from .hosted import HostedEvaluator
+from .integrals import ao_arrays, energy_nuc, grad_nuc, stage_mol
 
 
 def _grad_scanner_base():
@@ -25,50 +26,92 @@ def _grad_scanner_base():
         return object
 
 
-def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="default"):
+def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="default", device_trdms=None):
     """Fake PySCF gradient scanner driven by the continuation (reference :20-57): ``scanner(mol)``
     returns ``(E_tot, grad)`` and stores the predicted RDMs on ``scanner.base``.
 
     ``compress``: storage of the resident training data, ``None``, ``"sym8"`` or ``"default"``
-    (= ``set_trdm_compression``); with ``"sym8"`` the stored predicted 2-RDM is the 8-fold symmetrised one."""
+    (= ``set_trdm_compression``); with ``"sym8"`` the stored predicted 2-RDM is the 8-fold symmetrised one.
+    ``device_trdms``: training data already resident on the device (``trdm_io.load_pair_directories`` /
+    ``load_checkpoint``, a container's ``device_trdms()``): used instead of uploading the host arrays."""
     if compress == "default":
         compress = get_trdm_compression()
 
+    have_data = device_trdms is not None or (one_rdm is not None and two_rdm is not None and overlap is not None)
+
     class Base:
+        """``scanner.base`` of the reference (:26-32).  The predicted RDMs are fetched from the device when they are
+        read: integrator callbacks use ``predicted_one_rdm`` (``04_Zundel_continuation_MD.py:145``); nothing in the
+        reference reads the N^4 ``predicted_two_rdm`` during a run, so it is produced on first access (a second
+        evaluation of the current geometry with the unpacked 2-RDM as an output) instead of being shipped every step."""
         converged = True
         ovlp = overlap
         one_trdm = one_rdm
         two_trdm = two_rdm
-        predicted_one_rdm = None
-        predicted_two_rdm = None
+
+        def __init__(self, owner):
+            self._owner = owner
+
+        @property
+        def predicted_one_rdm(self):
+            return self._owner._one()
+
+        @property
+        def predicted_two_rdm(self):
+            return self._owner._two()
 
     class Scanner(_grad_scanner_base()):
         def __init__(self):
             self.mol = mol
-            self.base = Base()
-            self._ev = None
+            self.base = Base(self)
+            self._hev = None          # HostedEvaluator (Hermitian path)
+            self._full = None         # ContinuationEvaluator with every output (lazy 2-RDM, hermitian=False)
+            self._last = None         # (mol, D, G) of the last call as far as known
+
+        # -- lazily fetched outputs -----------------------------------------------------------------
+        def _one(self):
+            if self._last is None:
+                return None
+            if self._last[1] is None and self._hev is not None:
+                self._last[1] = self._hev.predicted_one_rdm()
+            return self._last[1]
+
+        def _two(self):
+            if self._last is None:
+                return None
+            if self._last[2] is None:
+                self._last[2] = self._full_eval(self._last[0])[3]
+            return self._last[2]
+
+        def _full_eval(self, m):
+            ao = ao_arrays(m, need_grad=True)
+            if self._full is None:
+                t = device_trdms if device_trdms is not None else _trdms(one_rdm, two_rdm, overlap, compress)
+                self._full = ContinuationEvaluator(t, int(np.asarray(ao.aoslices).shape[0]))
+            return self._full.energy_with_grad(DeviceAO.from_arrays(ao, self._full.t.device), True)
 
         def __call__(self, mol):
             self.mol = mol
-            if one_rdm is not None and two_rdm is not None and overlap is not None:
-                if not hermitian:
-                    en, grad, rdm_o, rdm_t = get_energy_with_grad(
-                        mol, one_rdm, two_rdm, overlap, hermitian=hermitian, return_density_matrices=True)
-                else:
-                    # the scanner is called once per MD step on slowly moving geometries: it owns an evaluator
-                    # whose eigensolvers start from the previous step's eigenvectors (EVC_FLAG_WARM_START)
-                    ao = ao_arrays(mol, need_grad=True)
-                    if self._ev is None:
-                        self._ev = ContinuationEvaluator(_trdms(one_rdm, two_rdm, overlap, compress),
-                                                         int(np.asarray(ao.aoslices).shape[0]), warm_start=True)
-                    # (compressed layout: int2e_ip1 travels packed in its last two AO indices, half the upload)
-                    pack = self._ev.t.layout == 8 and self._ev.t.n <= 32
-                    en, grad, rdm_o, rdm_t = self._ev.energy_with_grad(
-                        DeviceAO.from_arrays(ao, self._ev.t.device, pack_ip1=pack), return_density_matrices=True)
-                self.base.predicted_one_rdm = rdm_o
-                self.base.predicted_two_rdm = rdm_t
+            if not have_data:
+                return energy_nuc(mol), grad_nuc(mol)
+            if not hermitian:
+                en, grad, rdm_o, rdm_t = get_energy_with_grad(
+                    mol, one_rdm, two_rdm, overlap, hermitian=hermitian, return_density_matrices=True)
+                self._last = [mol, rdm_o, rdm_t]
                 return en, grad
-            return energy_nuc(mol), grad_nuc(mol)
+            # called once per MD step on slowly moving geometries: the scanner owns a hosted evaluator (pinned
+            # staging, one HIP graph per step, eigensolvers warm-started from the previous step; with the compressed
+            # layout the two large integral arrays are requested / staged packed: 12 instead of 26.6 MB at H30)
+            if self._hev is None:
+                t = device_trdms if device_trdms is not None else _trdms(one_rdm, two_rdm, overlap, compress)
+                ao0 = ao_arrays(mol, need_grad=True)
+                self._hev = HostedEvaluator(t, int(np.asarray(ao0.aoslices).shape[0]), ao0.aoslices, warm_start=True)
+                self._hev.stage(ao0)
+            else:
+                stage_mol(mol, self._hev)
+            en, grad = self._hev.run()
+            self._last = [mol, None, None]
+            return en, grad
 
     return Scanner()
 
@@ -98,12 +141,19 @@ def get_trajectory(init_mol, overlap, one_rdm, two_rdm, dt=10.0, steps=10, init_
 AMU2AU = 1822.888486209      # atomic mass unit in electron masses (CODATA 2018)
 
 
+KB_HARTREE = 3.166811563e-6   # Boltzmann constant in Hartree / K
+
+
 def nve_velocity_verlet(scanner, init_mol, dt=10.0, steps=10, veloc=None, trajectory_output=None,
-                        energy_output=None):
+                        energy_output=None, callback=None, thermostat=None):
     """Velocity-Verlet NVE propagation of an array-level molecule with ``scanner(mol) -> (E, grad)``.
     Returns one frame per step: ``{"coord", "veloc", "epot", "ekin", "time"}`` (frame 0 = initial geometry);
     the force of a step's end point is reused as the next step's start, so there is exactly one
-    energy+force evaluation per step."""
+    energy+force evaluation per step.
+
+    ``callback(locals())`` is called after every frame with ``mol`` and ``scanner`` among the keys, as PySCF's
+    integrators do (``04_Zundel_continuation_MD.py:140-177`` reads ``locals["scanner"].base.predicted_one_rdm``);
+    ``thermostat=(T_kelvin, taut)`` rescales the velocities after every step like ``md.integrators.NVTBerendson``."""
     R = np.array(init_mol.atom_coords(), dtype=np.float64)
     m = (np.asarray(init_mol.atom_mass_list(), dtype=np.float64) * AMU2AU)[:, None]
     v = np.zeros_like(R) if veloc is None else np.array(veloc, dtype=np.float64)
@@ -115,6 +165,9 @@ def nve_velocity_verlet(scanner, init_mol, dt=10.0, steps=10, veloc=None, trajec
     for k in range(steps):
         ekin = 0.5 * float(np.sum(m * v * v))
         frames.append({"coord": R.copy(), "veloc": v.copy(), "epot": float(e), "ekin": ekin, "time": k * dt})
+        if callable(callback):
+            frame, iteration = frames[-1], k   # noqa: F841 (exposed to the callback through locals())
+            callback(locals())
         if fe is not None:
             fe.write(f"{k * dt:14.6f} {e:18.10f} {ekin:18.10f} {e + ekin:18.10f}\n")
         if ft is not None:
@@ -128,6 +181,11 @@ def nve_velocity_verlet(scanner, init_mol, dt=10.0, steps=10, veloc=None, trajec
         mol = init_mol.with_coords(R)
         e, g = scanner(mol)
         v = v + 0.5 * dt * (a - np.asarray(g) / m)
+        if thermostat is not None:
+            T_target, taut = thermostat
+            T_now = float(np.sum(m * v * v)) / (3 * R.shape[0] * KB_HARTREE)
+            if T_now > 0.0:
+                v = v * np.sqrt(1.0 + (T_target / T_now - 1.0) * dt / taut)
     for f, given in ((fe, energy_output), (ft, trajectory_output)):
         if f is not None and isinstance(given, str):
             f.close()

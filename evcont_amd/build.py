@@ -14,6 +14,8 @@ LIB = os.path.join(HERE, "libevcont_hip.so")
 SOURCES = ["gemv_stream.hip", "gemv_mfma.hip", "transform.hip", "dense_small.hip", "response.hip", "pipeline.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "evcont_hip.h")]
 ARCH = "gfx950"
+# EVC_DEBUG_STAMPS=1 builds the eigen-kernels with their phase stamps (tools/micro/loewdin_time.py); never shipped
+EXTRA = ["-DEVC_DEBUG_STAMPS"] if os.environ.get("EVC_DEBUG_STAMPS") else []
 
 
 def _hipcc() -> str:
@@ -41,7 +43,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-                   "-Wall", "-Wno-unused-function", "-c", s, "-o", o]
+                   "-Wall", "-Wno-unused-function"] + EXTRA + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -194,7 +194,11 @@ __device__ __forceinline__ T quad_sum(T v) {
     return v;
 }
 
-__device__ long long g_dbg_stamp[64];   // wall_clock64() (100 MHz) stamps of workgroup 0 (debug, evc_debug_read)
+// Timing experiments (tools/micro/loewdin_time.py; build with EVC_DEBUG_STAMPS=1): workgroup 0 stamps the phases of
+// the eigen-kernels with the 100 MHz wall clock and a cap on the sweeps of the wave solvers can be set.  Compiled out
+// of the product library.
+#ifdef EVC_DEBUG_STAMPS
+__device__ long long g_dbg_stamp[64];
 __device__ double g_dbg_val[64];
 #define EVC_STAMP(i_)                                                                   \
     do {                                                                                \
@@ -204,7 +208,15 @@ __device__ double g_dbg_val[64];
     do {                                                                                \
         if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_val[i_] = (double)(v_);          \
     } while (0)
-__device__ int g_dbg_max_sweeps = 0;   // > 0: cap on the sweeps of the wave solvers (EVC_DBG_MAX_SWEEPS, timing experiments)
+#else
+#define EVC_STAMP(i_) do { } while (0)
+#define EVC_DBGVAL(i_, v_) do { } while (0)
+#endif
+#ifdef EVC_DEBUG_STAMPS
+__device__ int g_dbg_max_sweeps = 0;   // > 0: cap on the sweeps of the wave solvers (EVC_DBG_MAX_SWEEPS)
+#else
+constexpr int g_dbg_max_sweeps = 0;
+#endif
 
 __device__ __forceinline__ void jacobi_onesided_wave(double *Gc, int m) {
     const int lane = threadIdx.x & 63;
@@ -382,7 +394,7 @@ __device__ __forceinline__ void jacobi_onesided_wave_f32(float *Gf, int m) {
                 *reinterpret_cast<float4 *>(gq + 4) = b1;
             }
         }
-        if (lane == 0 && blockIdx.x == 0) g_dbg_val[20] = sweep + 1;
+        if (lane == 0) EVC_DBGVAL(20, sweep + 1);
         if (__ballot(bad) == 0) break;
     }
 }
@@ -1047,6 +1059,7 @@ static size_t jacobi_aux_bytes(int m) {
 // EVC_EIGH_F32: 0 = FP64 Jacobi, 1 = FP32 Jacobi + refinement, 2 (default) = FP32 tridiagonal start + refinement
 static int eigh_fast_enabled() {
     static const int on = getenv("EVC_EIGH_F32") ? atoi(getenv("EVC_EIGH_F32")) : 2;
+#ifdef EVC_DEBUG_STAMPS
     static bool dbg_done = false;
     if (!dbg_done) {
         dbg_done = true;
@@ -1055,6 +1068,7 @@ static int eigh_fast_enabled() {
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_max_sweeps), &v, sizeof(int));
         }
     }
+#endif
     return on;
 }
 
@@ -1611,6 +1625,7 @@ extern "C" int evc_loewdin(const double *S, const double *hcore, int n, double *
     return launch_loewdin(a, 1, as_stream(stream));
 }
 
+#ifdef EVC_DEBUG_STAMPS
 // Debug: stamps / values written by workgroup 0 of the last eigen-kernel (timing experiments).
 extern "C" int evc_debug_read(long long *stamps, double *vals, int n) {
     if (n > 64) n = 64;
@@ -1618,3 +1633,4 @@ extern "C" int evc_debug_read(long long *stamps, double *vals, int n) {
     if (e == hipSuccess) e = hipMemcpyFromSymbol(vals, HIP_SYMBOL(evc::g_dbg_val), sizeof(double) * n);
     return (int)e;
 }
+#endif

@@ -376,8 +376,12 @@ class BatchedEvaluator:
     ``energy (G,T)``, ``coeffs (G,T,T)``, ``grad (G,A,3)``."""
 
     def __init__(self, trdms: DeviceTRDMs, natm: int, count: int, stream: Optional["torch.cuda.Stream"] = None,
-                 keep_density_matrices: bool = False, keep_hmat: bool = False):
+                 keep_density_matrices: bool = False, keep_hmat: bool = False, warm_start: bool = False,
+                 keep_one_rdm: bool = False):
+        """``warm_start``: consecutive calls hold, slot by slot, nearby geometries (steps of ``count`` trajectories):
+        from the second call on the eigensolvers start from the previous call's eigenvectors (EVC_FLAG_WARM_START)."""
         self.t, self.natm, self.count, self.stream = trdms, int(natm), int(count), stream
+        self.warm_start, self._primed = bool(warm_start), False
         self.lib = _lib.load()
         d, n, T = trdms.device, trdms.n, trdms.T
         nbytes = self.lib.evc_workspace_bytes_batch(C.byref(trdms.cstruct), self.natm, self.count)
@@ -389,7 +393,7 @@ class BatchedEvaluator:
         self.energy = torch.zeros((G, T), dtype=F64, device=d)
         self.coeffs = torch.zeros((G, T, T), dtype=F64, device=d)
         self.grad = torch.zeros((G, max(self.natm, 1), 3), dtype=F64, device=d)
-        self.d_pred = torch.zeros((G, n, n), dtype=F64, device=d) if keep_density_matrices else None
+        self.d_pred = torch.zeros((G, n, n), dtype=F64, device=d) if (keep_density_matrices or keep_one_rdm) else None
         self.g_pred = torch.zeros((G, n, n, n, n), dtype=F64, device=d) if keep_density_matrices else None
         # the subspace Hamiltonians H(R) (lower triangles as handed to the eigensolver), for subset re-solves
         self.hmat = torch.zeros((G, T, T), dtype=F64, device=d) if keep_hmat else None
@@ -407,9 +411,12 @@ class BatchedEvaluator:
         assert aob.count == self.count, "batch size is fixed at construction"
         g = aob.cstruct()
         flags = (_lib.FLAG_ENERGY_ONLY if energy_only else 0) | _ip1_flag(self.t, aob)
+        if self.warm_start and self._primed:
+            flags |= _lib.FLAG_WARM_START
         rc = self.lib.evc_energy_with_grad_batch(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out), int(nroots),
                                                  flags, self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_energy_with_grad_batch")
+        self._primed = True
 
     def energies_with_grads(self, aob: DeviceAOBatch):
         """(E[G], grad[G,A,3]) as numpy arrays."""

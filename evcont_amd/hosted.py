@@ -1,0 +1,136 @@
+"""Host-resident geometries, one per call: the MD loop of the reference (``MD_utils.py:40-55``), where PySCF
+produces the AO integrals of every step on the host and the continuation consumes them once.
+
+``HostedEvaluator`` keeps, for one molecule size,
+
+* PINNED host staging buffers in the shapes the device path consumes -- with the compressed ``sym8`` training set the
+  two large arrays are staged packed, ``int2e`` as PySCF's ``aosym="s4"`` (Ms x Ms) and ``int2e_ip1`` as
+  ``aosym="s2kl"`` (3,N,N,Ms): 12 MB instead of 26.6 MB per step at H30.  ``staging()`` hands out numpy views of
+  them, so a producer that can write into a caller-supplied array (``mol.intor(..., out=...)``) fills them without an
+  extra copy;
+* static device buffers, workspace and outputs;
+* ONE HIP graph of the whole step: upload of the small early inputs (S, hcore, int2e, ...) -> Loewdin, integral
+  rotation, H build, eigensolve on the main branch, while a forked branch uploads the late, large inputs
+  (``int2e_ip1``, ``dhcore``), which only the gradient tail reads -> join -> predicted RDMs and gradient -> download of
+  E and the forces into pinned memory.  A step is then one ``hipGraphLaunch`` instead of ~8 copies + 15 kernel
+  launches, and the PCIe transfer of the 10 MB array overlaps the first half of the device work.
+
+No CPU fallback: the graph only contains HIP work of ``libevcont_hip.so`` and copies.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .evaluator import BatchedEvaluator, DeviceAOBatch, DeviceTRDMs, F64
+
+_EARLY = ("S", "hcore", "eri", "enuc", "ipovlp", "gnuc")
+_LATE = ("dhcore", "eri_ip1")
+
+
+class HostedEvaluator:
+    def __init__(self, trdms: DeviceTRDMs, natm: int, aoslices, warm_start: bool = True, use_graph: bool = True,
+                 keep_density_matrices: bool = False):
+        self.t, self.natm = trdms, int(natm)
+        d, n = trdms.device, trdms.n
+        self.packed = trdms.layout == _lib.LAYOUT_SYM8 and n <= 32
+        npr = n * (n + 1) // 2
+        shapes = {"S": (1, n, n), "hcore": (1, n, n), "enuc": (1,), "ipovlp": (1, 3, n, n), "gnuc": (1, self.natm, 3),
+                  "dhcore": (1, self.natm, 3, n, n),
+                  "eri": (1, npr, npr) if self.packed else (1, n, n, n, n),
+                  "eri_ip1": (1, 3, n, n, npr) if self.packed else (1, 3, n, n, n, n)}
+        self.host: Dict[str, torch.Tensor] = {k: torch.zeros(s, dtype=F64).pin_memory() for k, s in shapes.items()}
+        self.dev: Dict[str, torch.Tensor] = {k: torch.zeros(s, dtype=F64, device=d) for k, s in shapes.items()}
+        sl = torch.from_numpy(np.ascontiguousarray(np.asarray(aoslices, dtype=np.int64).reshape(-1, 2))).to(d)
+        self.aob = DeviceAOBatch(S=self.dev["S"], hcore=self.dev["hcore"], eri=self.dev["eri"], enuc=self.dev["enuc"],
+                                 natm=self.natm, ipovlp=self.dev["ipovlp"], dhcore=self.dev["dhcore"],
+                                 eri_ip1=self.dev["eri_ip1"], gnuc=self.dev["gnuc"], aoslices=sl,
+                                 ip1_s2kl=self.packed, eri_s4=self.packed)
+        self.stream = torch.cuda.Stream(d)
+        self.side = torch.cuda.Stream(d)
+        self.ev = BatchedEvaluator(trdms, self.natm, 1, stream=self.stream, warm_start=warm_start,
+                                   keep_density_matrices=keep_density_matrices, keep_one_rdm=True)
+        self.out_host = {"energy": torch.zeros((1, trdms.T), dtype=F64).pin_memory(),
+                         "grad": torch.zeros((1, max(self.natm, 1), 3), dtype=F64).pin_memory()}
+        self.use_graph = bool(use_graph)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._calls = 0
+
+    # -- staging ------------------------------------------------------------------------------------
+    def staging(self) -> Dict[str, np.ndarray]:
+        """Pinned numpy views to be filled with the integrals of the next geometry (leading batch axis of 1 removed;
+        ``enuc`` has shape (1,)).  ``eri`` / ``eri_ip1`` are in the packed forms when ``self.packed``."""
+        return {k: (v.numpy()[0] if k != "enuc" else v.numpy()) for k, v in self.host.items()}
+
+    def stage(self, ao) -> None:
+        """Copy an ``AOArrays``-like object (numpy fields) into the staging buffers, packing the two large arrays on
+        the host when the device side wants them packed and they arrive full."""
+        st = self.staging()
+        n = self.t.n
+        for k in ("S", "hcore", "ipovlp", "dhcore", "gnuc"):
+            np.copyto(st[k], np.asarray(getattr(ao, k), dtype=np.float64).reshape(st[k].shape))
+        st["enuc"][0] = float(ao.enuc)
+        eri, ip1 = np.asarray(ao.eri), np.asarray(ao.eri_ip1)
+        if self.packed:
+            iu, ju = np.tril_indices(n)
+            if eri.size != st["eri"].size:
+                eri = eri.reshape(n, n, n, n)[iu, ju][:, iu, ju]
+            if ip1.size != st["eri_ip1"].size:
+                ip1 = ip1.reshape(3, n, n, n, n)[:, :, :, iu, ju]
+        np.copyto(st["eri"], eri.reshape(st["eri"].shape))
+        np.copyto(st["eri_ip1"], ip1.reshape(st["eri_ip1"].shape))
+
+    # -- one step -----------------------------------------------------------------------------------
+    def _enqueue_step(self) -> None:
+        """Uploads, the device DAG and the downloads, on self.stream with self.side forked for the late inputs."""
+        main, side = self.stream, self.side
+        side.wait_stream(main)                            # fork
+        with torch.cuda.stream(side):
+            for k in _LATE:
+                self.dev[k].copy_(self.host[k], non_blocking=True)
+        with torch.cuda.stream(main):
+            for k in _EARLY:
+                self.dev[k].copy_(self.host[k], non_blocking=True)
+            self.ev.enqueue(self.aob, 1, energy_only=True)       # Loewdin .. eigensolve (K3 is kept for the tail)
+            main.wait_stream(side)                        # join: the gradient tail reads eri_ip1 and dhcore
+            self.ev.phase_gradient(self.aob, False)
+            self.out_host["energy"].copy_(self.ev.energy, non_blocking=True)
+            self.out_host["grad"].copy_(self.ev.grad, non_blocking=True)
+
+    def run(self):
+        """Evaluate the geometry in the staging buffers: ``(E_total, grad (A,3))`` as numpy."""
+        self._calls += 1
+        # the first two calls run eagerly: the first primes the warm start (so the flag captured below is the one
+        # every later step uses) and performs the one-time set-up of the library; the third call captures
+        if not self.use_graph or self._calls <= 2:
+            self._enqueue_step()
+        else:
+            if self.graph is None:
+                self.stream.synchronize()
+                self.side.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream):
+                    self._enqueue_step()
+                self.graph = g
+            with torch.cuda.stream(self.stream):
+                self.graph.replay()
+        self.stream.synchronize()
+        e = float(self.out_host["energy"][0, 0])
+        if not np.isfinite(e):
+            raise np.linalg.LinAlgError("generalised eigenproblem failed: overlap matrix not positive definite "
+                                        "or non-finite input")
+        return e, self.out_host["grad"][0, : self.natm].numpy().copy()
+
+    def predicted_one_rdm(self) -> np.ndarray:
+        """Predicted 1-RDM (OAO basis) of the last evaluated geometry."""
+        return self.ev.d_pred[0].cpu().numpy().copy()
+
+    def energy_with_grad(self, ao, return_density_matrices: bool = False):
+        self.stage(ao)
+        e, g = self.run()
+        if return_density_matrices:
+            return e, g, self.ev.d_pred[0].cpu().numpy().copy(), self.ev.g_pred[0].cpu().numpy().copy()
+        return e, g

@@ -50,6 +50,42 @@ def ao_arrays(mol, need_grad: bool = True) -> AOArrays:
     return AOArrays(S, hcore, eri, ipovlp, dh, ip1, sl, enuc, gnuc)
 
 
+def stage_mol(mol, hev) -> None:
+    """Fill the pinned staging buffers of a ``hosted.HostedEvaluator`` with the AO integrals of ``mol``.  A PySCF
+    ``Mole`` writes the two large arrays straight into them (``intor(..., out=)``), packed as the device side wants
+    them (``aosym="s4"`` / ``"s2kl"``) -- no full N^4 array and no staging copy on the host."""
+    if is_array_mol(mol):
+        hev.stage(mol)
+        return
+    from pyscf import scf, grad
+    st = hev.staging()
+    n = int(mol.nao)
+    np.copyto(st["S"], mol.intor("int1e_ovlp"))
+    np.copyto(st["hcore"], scf.hf.get_hcore(mol))
+    np.copyto(st["ipovlp"], mol.intor("int1e_ipovlp", comp=3))
+    st["enuc"][0] = float(mol.energy_nuc())
+    g = grad.RHF(scf.RHF(mol))
+    gen = g.hcore_generator()
+    for ia in range(mol.natm):
+        np.copyto(st["dhcore"][ia], gen(ia))
+    np.copyto(st["gnuc"], g.grad_nuc())
+
+    def fill(dst, name, **kw):
+        try:
+            out = mol.intor(name, out=dst, **kw)
+        except TypeError:                 # an intor without `out=` support: one extra host copy
+            out = mol.intor(name, **kw)
+        if out is not dst and not np.shares_memory(out, dst):
+            np.copyto(dst, np.asarray(out).reshape(dst.shape))
+
+    if hev.packed:
+        fill(st["eri"], "int2e", aosym="s4")
+        fill(st["eri_ip1"], "int2e_ip1", comp=3, aosym="s2kl")
+    else:
+        fill(st["eri"].reshape(n * n, n * n), "int2e")
+        fill(st["eri_ip1"].reshape(3, n * n, n * n), "int2e_ip1", comp=3)
+
+
 def energy_nuc(mol) -> float:
     return float(mol.enuc) if is_array_mol(mol) else float(mol.energy_nuc())
 

@@ -62,6 +62,13 @@ for lay in ("sym8", "pack2"):
                     "kernel": k, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
                     "hbm_bytes_per_launch": hbm,
                     "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)"}
+# provenance: bench.py only quotes these numbers while the streaming-kernel sources are the ones profiled
+import hashlib
+_repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in ("gemv_mfma.hip", "gemv_stream.hip"):
+    _h.update(open(os.path.join(_repo, "evcont_amd", "csrc", _f), "rb").read())
+traffic["_source_sha256"] = _h.hexdigest()
 json.dump(traffic, open(os.path.join(OUT, "pmc_traffic.json"), "w"), indent=1)
 with open(os.path.join(OUT, f"{ROUND}_pmc_hbm_traffic.csv"), "w") as fo:
     fo.write("layout,regime,kernel,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_per_launch\n")
