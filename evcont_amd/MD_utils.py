@@ -15,7 +15,7 @@ from .ab_initio_eigenvector_continuation import (approximate_ground_state_OAO, _
 from .electron_integral_utils import get_basis, get_integrals  # noqa: F401 (re-export)
 from .evaluator import ContinuationEvaluator, DeviceAO
 from .hosted import HostedEvaluator
-from .integrals import ao_arrays, energy_nuc, grad_nuc, stage_mol
+from .integrals import ao_arrays, aoslices_of, energy_nuc, grad_nuc, stage_mol
 
 
 def _grad_scanner_base():
@@ -104,11 +104,9 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="defaul
             # layout the two large integral arrays are requested / staged packed: 12 instead of 26.6 MB at H30)
             if self._hev is None:
                 t = device_trdms if device_trdms is not None else _trdms(one_rdm, two_rdm, overlap, compress)
-                ao0 = ao_arrays(mol, need_grad=True)
-                self._hev = HostedEvaluator(t, int(np.asarray(ao0.aoslices).shape[0]), ao0.aoslices, warm_start=True)
-                self._hev.stage(ao0)
-            else:
-                stage_mol(mol, self._hev)
+                sl = aoslices_of(mol)
+                self._hev = HostedEvaluator(t, len(sl), sl, warm_start=True)
+            stage_mol(mol, self._hev)
             en, grad = self._hev.run()
             self._last = [mol, None, None]
             return en, grad

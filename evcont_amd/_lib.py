@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(HERE, "libevcont_hip.so")
 
 LAYOUT_FULL6, LAYOUT_PAIR5, LAYOUT_ELEC3, LAYOUT_PACK2 = 6, 5, 3, 2
 LAYOUT_SYM8 = 8   # device-side 8-fold compressed layout (include/evcont_hip.h EVC_LAYOUT_SYM8)
-FLAG_ENERGY_ONLY, FLAG_PARTIAL_RANK, FLAG_WARM_START, FLAG_IP1_S2KL, FLAG_ERI_S4 = 1, 2, 4, 8, 16
-ABI_VERSION = 5
+FLAG_ENERGY_ONLY, FLAG_PARTIAL_RANK, FLAG_WARM_START, FLAG_IP1_S2KL, FLAG_ERI_S4, FLAG_LOEWDIN_DONE = 1, 2, 4, 8, 16, 32
+ABI_VERSION = 6
 
 c_double_p = C.c_void_p  # device pointers travel as integers
 
@@ -88,6 +88,8 @@ SIGNATURES = {
     "evc_workspace_bytes_batch": (C.c_size_t, [C.POINTER(TrdmSet), C.c_int, C.c_int]),
     "evc_energy_with_grad_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.POINTER(OutputsBatch),
                                              C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "evc_phase_loewdin_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.c_int, C.c_void_p, C.c_size_t,
+                                          C.c_void_p]),
     "evc_phase_hamiltonian_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_phase_solve_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.c_void_p, C.c_int64,

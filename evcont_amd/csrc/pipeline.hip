@@ -85,6 +85,7 @@ struct Ws {
     // eigenvectors kept from call to call for EVC_FLAG_WARM_START (U above serves the Loewdin step)
     double *vstd;
     bool warm;
+    bool loewdin_done;   // X, U, s, h1 are already in the workspace (EVC_FLAG_LOEWDIN_DONE)
     size_t bytes;    // of ONE geometry
     int64_t stride;  // the same in doubles
     RowProblem rp2, rp1;
@@ -182,6 +183,7 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.evecs = take(T * T);
     w.vstd = take(((T + 1) & ~(size_t)1) * ((T + 1) & ~(size_t)1));
     w.warm = false;
+    w.loewdin_done = false;
     w.bytes = off;
     w.stride = (int64_t)(off / sizeof(double));
 }
@@ -248,7 +250,7 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
     la.sws = sw;
     la.n = n;
     la.warm = w.warm ? 1 : 0;
-    {
+    if (!w.loewdin_done) {
         const int pr = prof_start(EVC_PROF_LOEWDIN, st);
         if ((rc = launch_loewdin(la, cnt, st))) return rc;
         prof_stop(pr, st);
@@ -892,11 +894,38 @@ extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geome
     hipStream_t st = as_stream(stream);
     int rc;
     w.warm = (flags & EVC_FLAG_WARM_START) != 0;
+    w.loewdin_done = (flags & EVC_FLAG_LOEWDIN_DONE) != 0;
     g.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
     if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
     if ((rc = phase_solve(t, g, nullptr, 0, o, nroots, w, st))) return rc;
     if (energy_only) return 0;
     return phase_gradient(t, g, o, flags & EVC_FLAG_IP1_S2KL, w, st);
+}
+
+extern "C" int evc_phase_loewdin_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, int flags, void *ws,
+                                       size_t ws_bytes, void *stream) {
+    if (check_set(t)) return -1;
+    EVC_REQUIRE(gb && gb->count >= 1 && gb->count <= 4096 && gb->S && gb->hcore,
+                "evc_phase_loewdin_batch: batch descriptor / S / hcore missing");
+    EVC_REQUIRE(ws && aligned16(ws), "evc_phase_loewdin_batch: workspace NULL or misaligned");
+    Ws w;
+    carve(t, gb->natm, static_cast<char *>(ws), w);
+    EVC_REQUIRE(ws_bytes >= w.bytes * (size_t)gb->count, "evc_phase_loewdin_batch: workspace too small: %zu < %zu",
+                ws_bytes, w.bytes * (size_t)gb->count);
+    const int64_t n2 = (int64_t)t->n * t->n;
+    LoewdinArgs la{};
+    la.S = gb->S;
+    la.h = gb->hcore;
+    la.X = w.X;
+    la.U = w.U;
+    la.s = w.s;
+    la.h1 = w.h1;
+    la.sS = n2;
+    la.sh = n2;
+    la.sws = w.stride;
+    la.n = t->n;
+    la.warm = (flags & EVC_FLAG_WARM_START) ? 1 : 0;
+    return launch_loewdin(la, gb->count, as_stream(stream));
 }
 
 extern "C" int evc_phase_hamiltonian_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, double *rows_out,

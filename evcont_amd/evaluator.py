@@ -407,10 +407,26 @@ class BatchedEvaluator:
     def synchronize(self) -> None:
         (self.stream if self.stream is not None else torch.cuda.current_stream(self.t.device)).synchronize()
 
+    def phase_loewdin(self, aob: DeviceAOBatch, stream: Optional["torch.cuda.Stream"] = None) -> None:
+        """Loewdin orthogonalisation of the batch alone (reads S and hcore only): the next ``enqueue`` of the SAME
+        geometries skips it (``EVC_FLAG_LOEWDIN_DONE``).  ``stream``: enqueue it there instead of on this
+        evaluator's stream (the caller orders the streams)."""
+        assert aob.count == self.count
+        g = aob.cstruct()
+        flags = _lib.FLAG_WARM_START if (self.warm_start and self._primed) else 0
+        sp = stream.cuda_stream if stream is not None else self._sp()
+        rc = self.lib.evc_phase_loewdin_batch(C.byref(self.t.cstruct), C.byref(g), flags, self.ws.data_ptr(),
+                                              self.ws_bytes, sp)
+        check(rc, "evc_phase_loewdin_batch")
+        self._loewdin_done = True
+
     def enqueue(self, aob: DeviceAOBatch, nroots: int = 1, energy_only: bool = False) -> None:
         assert aob.count == self.count, "batch size is fixed at construction"
         g = aob.cstruct()
         flags = (_lib.FLAG_ENERGY_ONLY if energy_only else 0) | _ip1_flag(self.t, aob)
+        if getattr(self, "_loewdin_done", False):
+            flags |= _lib.FLAG_LOEWDIN_DONE
+            self._loewdin_done = False
         if self.warm_start and self._primed:
             flags |= _lib.FLAG_WARM_START
         rc = self.lib.evc_energy_with_grad_batch(C.byref(self.t.cstruct), C.byref(g), C.byref(self.out), int(nroots),

@@ -27,13 +27,18 @@ import torch
 from . import _lib
 from .evaluator import BatchedEvaluator, DeviceAOBatch, DeviceTRDMs, F64
 
-_EARLY = ("S", "hcore", "eri", "enuc", "ipovlp", "gnuc")
 _LATE = ("dhcore", "eri_ip1")
 
 
 class HostedEvaluator:
-    def __init__(self, trdms: DeviceTRDMs, natm: int, aoslices, warm_start: bool = True, use_graph: bool = True,
-                 keep_density_matrices: bool = False):
+    def __init__(self, trdms: DeviceTRDMs, natm: int, aoslices, warm_start: bool = True,
+                 use_graph: Optional[bool] = None, keep_density_matrices: bool = False):
+        """``use_graph``: replay the step as one HIP graph (default: ``EVCONT_AMD_HOSTED_GRAPH=1``, else off --
+        measured on MI355X / ROCm 7.2 the replay of a graph with memcpy nodes is no faster than the eager enqueue for
+        the small systems and slower for H30)."""
+        if use_graph is None:
+            import os
+            use_graph = os.environ.get("EVCONT_AMD_HOSTED_GRAPH", "0") not in ("", "0")
         self.t, self.natm = trdms, int(natm)
         d, n = trdms.device, trdms.n
         self.packed = trdms.layout == _lib.LAYOUT_SYM8 and n <= 32
@@ -42,8 +47,21 @@ class HostedEvaluator:
                   "dhcore": (1, self.natm, 3, n, n),
                   "eri": (1, npr, npr) if self.packed else (1, n, n, n, n),
                   "eri_ip1": (1, 3, n, n, npr) if self.packed else (1, 3, n, n, n, n)}
-        self.host: Dict[str, torch.Tensor] = {k: torch.zeros(s, dtype=F64).pin_memory() for k, s in shapes.items()}
-        self.dev: Dict[str, torch.Tensor] = {k: torch.zeros(s, dtype=F64, device=d) for k, s in shapes.items()}
+        # three slabs = three H2D copies per step (a copy costs ~12 us before its first byte moves): the small early
+        # arrays, int2e, and the late pair (dhcore, int2e_ip1); every array is a 16-byte aligned view of its slab
+        self._groups = (("S", "hcore", "enuc", "ipovlp", "gnuc"), ("eri",), _LATE)
+        self.host: Dict[str, torch.Tensor] = {}
+        self.dev: Dict[str, torch.Tensor] = {}
+        self._slabs = []
+        for grp in self._groups:
+            sizes = [int(np.prod(shapes[k])) for k in grp]
+            offs = np.concatenate([[0], np.cumsum([(x + 1) // 2 * 2 for x in sizes])])
+            hs = torch.zeros(int(offs[-1]), dtype=F64).pin_memory()
+            ds = torch.zeros(int(offs[-1]), dtype=F64, device=d)
+            self._slabs.append((hs, ds))
+            for k, o, x in zip(grp, offs[:-1], sizes):
+                self.host[k] = hs[int(o): int(o) + x].view(shapes[k])
+                self.dev[k] = ds[int(o): int(o) + x].view(shapes[k])
         sl = torch.from_numpy(np.ascontiguousarray(np.asarray(aoslices, dtype=np.int64).reshape(-1, 2))).to(d)
         self.aob = DeviceAOBatch(S=self.dev["S"], hcore=self.dev["hcore"], eri=self.dev["eri"], enuc=self.dev["enuc"],
                                  natm=self.natm, ipovlp=self.dev["ipovlp"], dhcore=self.dev["dhcore"],
@@ -87,13 +105,19 @@ class HostedEvaluator:
     def _enqueue_step(self) -> None:
         """Uploads, the device DAG and the downloads, on self.stream with self.side forked for the late inputs."""
         main, side = self.stream, self.side
-        side.wait_stream(main)                            # fork
+        (h0, d0), (h1, d1), (h2, d2) = self._slabs
+        # Early slabs on the main stream, the late slab on a forked one, joined in front of the gradient tail.
+        # (Measured alternatives on MI355X / ROCm 7.2, H30, per step: this order 425 us; int2e on the forked stream as
+        #  well with the Loewdin kernel started behind the small slab alone, evc_phase_loewdin_batch: 530-540 us -- every
+        #  cross-stream event wait on the critical path costs 20-25 us and the runtime takes tens of microseconds on
+        #  the host to accept a 10 MB copy; the same enqueue replayed as a HIP graph: 555-590 us.)
+        with torch.cuda.stream(main):                     # submitted FIRST: the copy engine works in submission order
+            d0.copy_(h0, non_blocking=True)
+            d1.copy_(h1, non_blocking=True)
+        side.wait_stream(main)                            # fork (behind the early copies)
         with torch.cuda.stream(side):
-            for k in _LATE:
-                self.dev[k].copy_(self.host[k], non_blocking=True)
+            d2.copy_(h2, non_blocking=True)
         with torch.cuda.stream(main):
-            for k in _EARLY:
-                self.dev[k].copy_(self.host[k], non_blocking=True)
             self.ev.enqueue(self.aob, 1, energy_only=True)       # Loewdin .. eigensolve (K3 is kept for the tail)
             main.wait_stream(side)                        # join: the gradient tail reads eri_ip1 and dhcore
             self.ev.phase_gradient(self.aob, False)

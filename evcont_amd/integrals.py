@@ -50,6 +50,13 @@ def ao_arrays(mol, need_grad: bool = True) -> AOArrays:
     return AOArrays(S, hcore, eri, ipovlp, dh, ip1, sl, enuc, gnuc)
 
 
+def aoslices_of(mol) -> np.ndarray:
+    """(A,2) [start, stop) of every atom's AOs."""
+    if is_array_mol(mol):
+        return np.asarray(mol.aoslices, dtype=np.int64).reshape(-1, 2)
+    return np.asarray([[s[2], s[3]] for s in mol.aoslice_by_atom()], dtype=np.int64)
+
+
 def stage_mol(mol, hev) -> None:
     """Fill the pinned staging buffers of a ``hosted.HostedEvaluator`` with the AO integrals of ``mol``.  A PySCF
     ``Mole`` writes the two large arrays straight into them (``intor(..., out=)``), packed as the device side wants

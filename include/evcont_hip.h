@@ -27,9 +27,9 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 5 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
+#define EVC_ABI_VERSION 6 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
                              3: EVC_LAYOUT_SYM8; 4: evc_profile_stage/_select, EVC_FLAG_IP1_S2KL, EVC_FLAG_ERI_S4;
-                             5: evc_phase_set_coeffs */
+                             5: evc_phase_set_coeffs; 6: evc_phase_loewdin_batch, EVC_FLAG_LOEWDIN_DONE */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
@@ -208,6 +208,12 @@ typedef struct evc_outputs {
                                    returns for mol.intor("int2e", aosym="s4").  A quarter of the bytes.  Fused entry points,
                                    EVC_LAYOUT_SYM8 and N <= 32 only. */
 
+#define EVC_FLAG_LOEWDIN_DONE 32 /* the workspace already holds X, U, s and h1 of THESE geometries (evc_phase_loewdin_batch
+                                   ran on it): phase A skips the Loewdin kernel.  Lets a host overlap that latency-bound
+                                   kernel -- it reads only S and hcore -- with the upload of the large integral arrays
+                                   (hosted MD) or with the previous batch's streaming kernels (throughput).  Batch entry
+                                   points only. */
+
 size_t evc_workspace_bytes(const evc_trdm_set *t, int natm);
 
 /* Phase A: Loewdin + integrals + H rows.  Writes h2rows_local[rows2] (scaled two-body rows of this
@@ -267,6 +273,12 @@ size_t evc_workspace_bytes_batch(const evc_trdm_set *t, int natm, int count);
 int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
                                const evc_outputs_batch *ob, int nroots, int flags, void *ws,
                                size_t ws_bytes, void *stream);
+
+/* Phase L: Loewdin orthogonalisation of the batch alone (electron_integral_utils.py:6-18,135): reads gb->S and
+ * gb->hcore only, leaves X, U, s, h1 in the workspace for a following call with EVC_FLAG_LOEWDIN_DONE.
+ * flags: EVC_FLAG_WARM_START. */
+int evc_phase_loewdin_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, int flags, void *ws, size_t ws_bytes,
+                            void *stream);
 
 /* The three phases of the pair-sharded evaluation for a batch (t may hold a row slice).
  * A: writes the scaled two-body rows of this rank to rows_out[g*ld_rows_out + r], r < t->rows2

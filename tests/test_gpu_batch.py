@@ -152,3 +152,27 @@ def test_h30_batch16_matches_single_full_size():
     be.enqueue(DeviceAOBatch.stack(aos))
     be.synchronize()
     assert np.array_equal(be.energy[:, 0].cpu().numpy(), E) and np.array_equal(be.grad.cpu().numpy(), grad)
+
+
+def test_phase_loewdin_then_flagged_call_equals_fused():
+    """evc_phase_loewdin_batch + EVC_FLAG_LOEWDIN_DONE (the Loewdin kernel of a batch run ahead of time, e.g. on
+    another stream beside the previous batch) gives bit-identical results to the fused call."""
+    import torch
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, BatchedEvaluator
+    from evcont_amd.synthetic import make_ao_arrays, make_trdms, pack_rows
+    dev = torch.device("cuda:0")
+    n, T, A, G = 13, 5, 3, 5
+    S, one, two = make_trdms(n, T, 61)
+    trd = DeviceTRDMs(one, pack_rows(two, True, True), S, dev, compress="sym8")
+    aob = DeviceAOBatch.from_arrays([make_ao_arrays(n, A, 900 + k, ao_sizes=(9, 2, 2), ip1_rs_symmetric=True)
+                                     for k in range(G)], dev, pack_ip1=True, pack_eri=True)
+    ref = BatchedEvaluator(trd, A, G)
+    E0, g0 = ref.energies_with_grads(aob)
+    be = BatchedEvaluator(trd, A, G)
+    side = torch.cuda.Stream(dev)
+    be.phase_loewdin(aob, stream=side)
+    side.synchronize()
+    E1, g1 = be.energies_with_grads(aob)
+    assert np.array_equal(E0, E1) and np.array_equal(g0, g1)
+    E2, g2 = be.energies_with_grads(aob)          # the flag is consumed by one call
+    assert np.array_equal(E0, E2) and np.array_equal(g0, g2)

@@ -102,14 +102,13 @@ def test_integrator_callback_reads_predicted_rdm():
         v0 = 2e-4 * np.random.default_rng(5).standard_normal((6, 3))
         ps.md.integrators.NVTBerendson(sc, 298.15, taut=250, steps=5, dt=6.0, incore_anyway=True, frames=frames,
                                        veloc=v0, callback=callback).run()
+        G = sc.base.predicted_two_rdm      # the N^4 predicted 2-RDM is produced on demand, for the last geometry
     assert len(frames) == 5 and len(seen) == 5
     for R, D, tr in seen:
         assert abs(tr - 6.0) < 1e-9                                     # six electrons
         _, _, Dref, _ = get_energy_with_grad(s_gaussian_mol(R), cont.one_rdm, cont.two_rdm, cont.overlap,
                                              return_density_matrices=True)
         np.testing.assert_allclose(D, Dref, rtol=0, atol=1e-9)
-    # the N^4 predicted 2-RDM is produced on demand and belongs to the last geometry
-    G = sc.base.predicted_two_rdm
     _, _, _, Gref = get_energy_with_grad(s_gaussian_mol(seen[-1][0]), cont.one_rdm, cont.two_rdm, cont.overlap,
                                          return_density_matrices=True)
     np.testing.assert_allclose(G, Gref, rtol=0, atol=1e-9)
@@ -131,7 +130,7 @@ def test_hosted_evaluator_matches_resident_path():
     a1 = make_ao_arrays(n, A, 32, ao_sizes=(9, 2, 2), ip1_rs_symmetric=True)
     for comp in (None, "sym8"):
         trd = DeviceTRDMs(one, two_p, S, dev, compress=comp)
-        hev = HostedEvaluator(trd, A, a0.aoslices)
+        hev = HostedEvaluator(trd, A, a0.aoslices, use_graph=(comp is None))
         ref = ContinuationEvaluator(trd, A)
         assert hev.packed == (comp == "sym8")
         for k in range(7):
@@ -140,7 +139,7 @@ def test_hosted_evaluator_matches_resident_path():
             Er, gr = ref.energy_with_grad(DeviceAO.from_arrays(ao, dev, pack_ip1=hev.packed, pack_eri=hev.packed))
             assert abs(E - Er) < 1e-11, (comp, k)
             np.testing.assert_allclose(g, gr, rtol=0, atol=1e-10)
-        assert hev.graph is not None
+        assert (hev.graph is not None) == (comp is None)
 
 
 @pytest.mark.parametrize("script,args", [
