@@ -69,12 +69,35 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // issued before it keep draining behind the work that follows.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Sum over the 64 lanes of a wave; every lane gets the total.  Fixed butterfly order,
-// so results are reproducible run to run.
+// Cross-lane moves on the DPP path (one v_mov_b32_dpp per 32-bit half).  __shfl_xor lowers to ds_bpermute_b32: an
+// LDS-pipeline round trip per half and level, ~10x the latency.  CTRL: quad_perm [1,0,3,2] = 0xB1 (xor 1),
+// [2,3,0,1] = 0x4E (xor 2), row_half_mirror = 0x141, row_mirror = 0x140.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Sum over the 64 lanes of a wave; every lane gets the total.  Fixed order (quads, half rows, rows on DPP moves, then
+// the four row sums through readlane), so results are reproducible run to run.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 // Sum over a workgroup of NW waves; result valid in thread 0 (and all threads of wave 0).

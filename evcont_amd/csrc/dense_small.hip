@@ -172,19 +172,9 @@ __device__ __forceinline__ void jacobi_eigh_lds(double *A, double *V, int m, dou
 constexpr int kJwPitch = 34;
 constexpr int kJwMax = 32;
 
-// Sum over the four lanes of a quad, every lane gets the total.  DPP quad_perm moves (one v_mov_b32_dpp per
-// 32-bit half), not __shfl_xor: that lowers to ds_bpermute_b32, an LDS-pipeline round trip per half and level.
-template <int CTRL>
-__device__ __forceinline__ double dpp_quad(double v) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
+// Sum over the four lanes of a quad, every lane gets the total (DPP moves, common.hpp).
+template <int CTRL, typename T>
+__device__ __forceinline__ T dpp_quad(T v) { return dpp_move<CTRL>(v); }
 constexpr int kQuadXor1 = 0xB1;   // quad_perm [1,0,3,2]
 constexpr int kQuadXor2 = 0x4E;   // quad_perm [2,3,0,1]
 template <typename T>
@@ -402,12 +392,6 @@ __device__ __forceinline__ void jacobi_onesided_wave_f32(float *Gf, int m) {
 // max over the workgroup (NaN-propagating: a NaN input yields a NaN result); red: 4 doubles of LDS.
 // Wave stage on DPP moves (quad xor 1, xor 2, row_half_mirror, row_mirror) + four readlanes, no LDS round trips.
 __device__ __forceinline__ double nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
 __device__ __forceinline__ double wave_max_nan(double v) {
     v = nanmax(v, dpp_quad<kQuadXor1>(v));
     v = nanmax(v, dpp_quad<kQuadXor2>(v));
