@@ -209,7 +209,7 @@ def main():
             evs = [BatchedEvaluator(trd, A, G, stream=mk_stream()) for _ in range(nslots)]
         else:
             inputs = aos
-            evs = [ContinuationEvaluator(trd, A, stream=mk_stream()) for _ in range(nslots)]
+            evs = [ContinuationEvaluator(trd, A, stream=mk_stream(), want_two_rdm=False) for _ in range(nslots)]
         if sharded_pairs:
             runners = [PairShardedContinuation(ev, rows) for ev in evs]
         else:
@@ -486,7 +486,7 @@ def main():
                 for t in (1e-3 * k for k in range(nsteps))]
         res = {}
         for name, warm in (("cold", False), ("warm", True)):
-            ev = ContinuationEvaluator(trd, A, warm_start=warm)
+            ev = ContinuationEvaluator(trd, A, warm_start=warm, want_two_rdm=False)
             for k in range(8):
                 ev.enqueue(traj[k])
             fence()

@@ -1418,6 +1418,36 @@ __global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) {
         a.Pao += g * a.sws;
         a.Y1 += g * a.sws;
     }
+    if (n <= 32) {
+        // row.row products at pitch kRp (16-byte LDS loads, no bank conflicts): X symmetric, so
+        //   T1t[j][i] = (X D)[i][j] = sum_k Dt[j][k] X[i][k],  Pao[i][j] = sum_k T1[i][k] X[j][k]   (T1 = T1t^T stored both ways)
+        //   T2t[j][i] = (X (D + D^T))[i][j] = sum_k Dsym[j][k] X[i][k],  Y1[i][j] = scale1 sum_k h[i][k] T2t[j][k]
+        double *Xp = sm, *Dt = Xp + kRsz, *Ds2 = Dt + kRsz, *Hp = Ds2 + kRsz, *T1 = Hp + kRsz, *T2t = T1 + kRsz;
+        const int m = (n + 1) & ~1;
+        for (int idx = threadIdx.x; idx < kRsz; idx += kThreads) {
+            const int i = idx / kRp, j = idx - i * kRp;
+            const bool in = i < n && j < n;
+            const double dij = in ? a.D[i * n + j] : 0.0, dji = in ? a.D[j * n + i] : 0.0;
+            Xp[idx] = in ? a.X[i * n + j] : 0.0;
+            Dt[idx] = dji;
+            Ds2[idx] = dij + dji;
+            Hp[idx] = in ? a.hcore[i * n + j] : 0.0;
+            T1[idx] = 0.0;
+            T2t[idx] = 0.0;
+        }
+        __syncthreads();
+        // T1[i][j] = (X D)[i][j] = sum_k X[i][k] Dt[j][k];  T2t[j][i] = sum_k Dsym[j][k] X[i][k]
+        mm_rowrow(m, Xp, Dt, [&](int i, int j, double v) { T1[i * kRp + j] = v; });
+        mm_rowrow(m, Ds2, Xp, [&](int j, int i, double v) { T2t[j * kRp + i] = v; });
+        __syncthreads();
+        mm_rowrow(m, T1, Xp, [&](int i, int j, double v) {
+            if (i < n && j < n) a.Pao[i * n + j] = v;
+        });
+        mm_rowrow(m, Hp, T2t, [&](int i, int j, double v) {
+            if (i < n && j < n) a.Y1[i * n + j] = a.scale1 * v;
+        });
+        return;
+    }
     double *Xs = sm;            // n*n
     double *Ds = Xs + n * n;    // n*n
     double *Hs = Ds + n * n;    // n*n
@@ -1441,7 +1471,7 @@ __global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) {
 }
 
 int launch_grad_prep(const GradPrepArgs &a, int count, hipStream_t st) {
-    const size_t lds = sizeof(double) * (size_t)4 * a.n * a.n;
+    const size_t lds = a.n <= 32 ? sizeof(double) * (size_t)6 * kRsz : sizeof(double) * (size_t)4 * a.n * a.n;
     static LdsAttr attr;
     if (int rc = allow_dynamic_lds(grad_prep_kernel, attr, 160 * 1024, "grad_prep")) return rc;
     hipLaunchKernelGGL(grad_prep_kernel, dim3(count), dim3(kThreads), lds, st, a);

@@ -477,7 +477,7 @@ class ContinuationEvaluator:
     (``get_energy_with_grad``, ``ab_initio_gradients_loewdin.py:308-379``)."""
 
     def __init__(self, trdms: DeviceTRDMs, natm: int, stream: Optional["torch.cuda.Stream"] = None,
-                 warm_start: bool = False):
+                 warm_start: bool = False, want_two_rdm: bool = True):
         """``stream``: HIP stream every call of this evaluator is enqueued on (default: torch's current
         stream at call time).  Several evaluators on different streams may share one ``DeviceTRDMs``:
         each owns its workspace and outputs, so independent geometries overlap on the device.
@@ -501,10 +501,11 @@ class ContinuationEvaluator:
         self.coeffs = torch.zeros((T, T), dtype=F64, device=d)
         self.grad = torch.zeros((max(self.natm, 1), 3), dtype=F64, device=d)
         self.d_pred = torch.zeros((n, n), dtype=F64, device=d)
-        self.g_pred = torch.zeros((n, n, n, n), dtype=F64, device=d)
+        self.g_pred = torch.zeros((n, n, n, n), dtype=F64, device=d) if want_two_rdm else None
         self.hmat = torch.zeros((T, T), dtype=F64, device=d)
         self.out = Outputs(energy=self.energy.data_ptr(), coeffs=self.coeffs.data_ptr(), grad=self.grad.data_ptr(),
-                           d_pred=self.d_pred.data_ptr(), g_pred=self.g_pred.data_ptr(), hmat=self.hmat.data_ptr())
+                           d_pred=self.d_pred.data_ptr(),
+                           g_pred=(self.g_pred.data_ptr() if want_two_rdm else None), hmat=self.hmat.data_ptr())
 
     def _sp(self) -> int:
         return self.stream.cuda_stream if self.stream is not None else _stream_ptr(self.t.device)
@@ -531,6 +532,8 @@ class ContinuationEvaluator:
         self._raise_if_nan(e)
         g = self.grad[: self.natm].cpu().numpy().copy()
         if return_density_matrices:
+            if self.g_pred is None:
+                raise _lib.EvcontHipError("this evaluator was built with want_two_rdm=False")
             return e, g, self.d_pred.cpu().numpy().copy(), self.g_pred.cpu().numpy().copy()
         return e, g
 
