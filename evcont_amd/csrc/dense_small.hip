@@ -668,8 +668,9 @@ __device__ __forceinline__ void mm_rowrow(int m, const double *__restrict__ P, c
 // start vectors as columns and Zt = Z^T (both pitch kRp, padding zero); B1, B2, B3: scratch matrices.  On success
 // (the error contracted to rounding) returns true with Z / Zt pointing at the refined pair (two of the five buffers)
 // and lam = eigenvalues; false when a pass does not contract (garbage, NaN or an unresolved cluster structure).
-__device__ __forceinline__ bool oa_refine(int m, const double *Ap, double *&Z, double *&Zt, double *B1, double *B2,
-                                          double *B3, double *lam, double *red, int max_pass) {
+// Rows / columns nreal..m-1 are the decoupled dummy dimension.
+__device__ __forceinline__ bool oa_refine(int m, int nreal, const double *Ap, double *&Z, double *&Zt, double *B1,
+                                          double *B2, double *B3, double *lam, double *red, int max_pass) {
     const int tid = threadIdx.x;
     bool ok = false;
     double prev = 1.0e300;
@@ -721,25 +722,38 @@ __device__ __forceinline__ bool oa_refine(int m, const double *Ap, double *&Z, d
         // degenerate eigenspace keeps whatever orthonormal basis it has).  Convergence measure: the rotation, but
         // never more than |sh| relative to 1e-8 max|l| (a large rotation inside a numerically degenerate pair moves
         // nothing that any smooth function of A can see), and the symmetric part.
-        const double floor_s = 1.5e-14 * lmax, inv_tol = 1.0e8 / (lmax > 0.0 ? lmax : 1.0);
-        double emax = 0.0;
+        // rounding leaves ~m eps max|l| in every element of S: below `conv_floor` an element says nothing about
+        // convergence, and if the rotation it asks for is large (a numerically degenerate pair: any orthonormal basis of
+        // its span is as good as any other) it is not applied at all; small rotations are applied down to `rot_floor`,
+        // which is what resolves eigenvectors of tiny eigenvalues as far as the arithmetic allows.  A large rotation
+        // of a significant element (a close pair found badly mixed) is limited to 0.3 per pass: the update is first
+        // order, and the symmetric part repairs the t^2 loss of orthogonality in the next pass.
+        const double rot_floor = 1.8e-15 * lmax, conv_floor = 1.5e-14 * (double)m * lmax;
+        double emax = 0.0, rmax = 0.0;
         for (int idx = tid; idx < m * 32; idx += kThreads) {
             const int i = idx >> 5, j = idx & 31;
             if (j < m) {
                 const double rv = R[i * kRp + j];
                 double e = 0.5 * rv, meas = fabs(e);
-                if (i != j) {
+                rmax = nanmax(rmax, meas);
+                // (the decoupled dummy dimension of an odd problem has S_ij = R_ij = 0 exactly: no rotation -- its
+                //  "eigenvalue" 0 may sit arbitrarily close to a real one)
+                if (i != j && i < nreal && j < nreal) {
                     const int lo = i < j ? i : j, hi = i < j ? j : i;
                     const double d = lam[hi] - lam[lo];
                     const double sh = S[i * kRp + j] + 0.5 * (lam[i] + lam[j]) * rv;
                     double t = 0.0;
-                    if (fabs(sh) > floor_s || sh != sh) {
+                    if (fabs(sh) > rot_floor || sh != sh) {
                         const double hd = 0.5 * d, rt = sqrt(fma(hd, hd, sh * sh));
                         t = sh / (hd + (hd < 0.0 ? -rt : rt));
+                        if (fabs(sh) > conv_floor || sh != sh) {
+                            meas = nanmax(meas, fabs(t));
+                            t = t > 0.3 ? 0.3 : (t < -0.3 ? -0.3 : t);
+                        } else if (fabs(t) > 1.0e-3) {
+                            t = 0.0;
+                        }
                     }
                     e += (i < j) ? t : -t;
-                    const double mt = fmin(fabs(t), fabs(sh) * inv_tol);
-                    meas = nanmax(meas, (t != t) ? t : mt);
                 }
                 B1[j * kRp + i] = e;
                 emax = nanmax(emax, meas);
@@ -748,7 +762,11 @@ __device__ __forceinline__ bool oa_refine(int m, const double *Ap, double *&Z, d
         emax = block_max_nan(emax, red);
         EVC_STAMP(3 + pass);
         EVC_DBGVAL(pass, emax);
-        if (!(emax < 0.5) || (pass >= 2 && !(emax < prev))) break;   // NaN / no contraction: give up
+        rmax = block_max_nan(rmax, red);
+        // give up on NaNs, on vectors that are far from orthonormal (the first-order update cannot repair that) and
+        // when the passes stop contracting; large ROTATIONS alone are fine: inside an eigenspace that is degenerate
+        // to working precision they are arbitrary and harmless, elsewhere they proceed 0.3 rad per pass
+        if (!(rmax < 0.5) || emax != emax || (pass >= 3 && !(emax < prev))) break;
         // Zt' = Zt + E^T Z^T: Zt'[j][i] = Zt[j][i] + sum_k Et[j][k] Z[i][k]; stored both ways (S and R are consumed)
         mm_rowrow(m, B1, Z, [&](int j, int i, double v) {
             const double z = Zt[j * kRp + i] + v;
@@ -765,6 +783,25 @@ __device__ __forceinline__ bool oa_refine(int m, const double *Ap, double *&Z, d
         prev = emax;
         if (emax < 3.0e-8) {   // the pass just applied leaves an error of ~emax^2
             ok = true;
+            // ... in the eigenvector directions; the rotations applied below the convergence floor (tiny eigenvalue
+            // gaps: t = noise-level element / gap can reach 1e-3) still cost t^2 of orthogonality, which one
+            // symmetric-only step Z <- Z (I + R / 2) repairs
+            {
+                mm_rowrow(m, Zt, Zt, [&](int i, int j, double v) { B1[j * kRp + i] = 0.5 * ((i == j ? 1.0 : 0.0) - v); });
+                __syncthreads();
+                mm_rowrow(m, B1, Z, [&](int j, int i, double v) {
+                    const double z = Zt[j * kRp + i] + v;
+                    B2[j * kRp + i] = z;
+                    B3[i * kRp + j] = z;
+                });
+                __syncthreads();
+                double *t2 = Zt;
+                Zt = B2;
+                B2 = t2;
+                t2 = Z;
+                Z = B3;
+                B3 = t2;
+            }
             break;
         }
     }
@@ -799,7 +836,7 @@ __device__ __forceinline__ void eigh_small(double *A, double *V, int m, int nrea
                 Zt[idx] = in ? V[j * m + i] : 0.0;
             }
             __syncthreads();
-            ok = oa_refine(m, Ap, Z, Zt, B1, B2, B3, lam, red, 6);
+            ok = oa_refine(m, nreal, Ap, Z, Zt, B1, B2, B3, lam, red, 10);
             if (!ok) {   // the buffers may have been permuted: re-establish the roles
                 Z = R6 + kRsz; Zt = R6 + 2 * kRsz; B1 = R6 + 3 * kRsz; B2 = R6 + 4 * kRsz; B3 = R6 + 5 * kRsz;
             }
@@ -840,7 +877,7 @@ __device__ __forceinline__ void eigh_small(double *A, double *V, int m, int nrea
                 Z[idx] = (i < m && j < m) ? Zt[j * kRp + i] : 0.0;
             }
             __syncthreads();
-            ok = oa_refine(m, Ap, Z, Zt, B1, B2, B3, lam, red, 6);
+            ok = oa_refine(m, nreal, Ap, Z, Zt, B1, B2, B3, lam, red, 10);
             EVC_DBGVAL(21, ok ? 1.0 : 0.0);
             if (!ok) {
                 Z = R6 + kRsz; Zt = R6 + 2 * kRsz; B1 = R6 + 3 * kRsz; B2 = R6 + 4 * kRsz; B3 = R6 + 5 * kRsz;
@@ -876,7 +913,7 @@ __device__ __forceinline__ void eigh_small(double *A, double *V, int m, int nrea
                     Z[idx] = (i < m && j < m) ? Zt[j * kRp + i] : 0.0;
                 }
                 __syncthreads();
-                ok = oa_refine(m, Ap, Z, Zt, B1, B2, B3, lam, red, 6);
+                ok = oa_refine(m, nreal, Ap, Z, Zt, B1, B2, B3, lam, red, 10);
             }
         }
         EVC_STAMP(10);

@@ -1,0 +1,90 @@
+"""Stress tests of the two small dense solvers behind the path (Loewdin orthogonalisation,
+electron_integral_utils.py:6-18; generalised subspace problem, ab_initio_eigenvector_continuation.py:73-88) on spectra
+that are hard for the staged algorithm (FP32 tridiagonal start -> FP64 refinement -> Jacobi fall-backs): every size
+1..32 and a few beyond, exactly degenerate and tightly clustered eigenvalues, graded spectra, the decoupled dummy
+dimension of odd sizes.  Reference: numpy.linalg.eigh / scipy.linalg.eigh in FP64.  What must hold is what the path
+consumes: X = S^-1/2 (any orthonormal basis inside a degenerate eigenspace gives the same X), the sorted eigenvalues,
+the ground-state vector where it is non-degenerate, S-orthonormality of the returned vectors."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+
+from evcont_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def spectrum(kind, n, rng):
+    if kind == "random":
+        return np.sort(0.2 + 3.0 * rng.random(n))
+    if kind == "degenerate":                      # exact pairs (symmetric molecules)
+        return np.sort(1.0 + 0.5 * (np.arange(n) // 2))
+    if kind == "triple":                          # one eigenvalue n // 2 times
+        v = 0.3 + np.arange(n, dtype=float)
+        v[: max(2, n // 2)] = 0.7
+        return np.sort(v)
+    if kind == "cluster1e-6":
+        v = 0.5 + np.arange(n, dtype=float)
+        v[1::2] = v[0::2][: len(v[1::2])] * (1 + 1e-6)
+        return np.sort(v)
+    if kind == "cluster1e-10":
+        v = 0.5 + np.arange(n, dtype=float)
+        v[1::2] = v[0::2][: len(v[1::2])] * (1 + 1e-10)
+        return np.sort(v)
+    if kind == "graded":                          # near-linear dependence: condition number 1e8
+        return np.logspace(-8, 0, n)
+    raise KeyError(kind)
+
+
+def with_spectrum(vals, rng):
+    q, _ = np.linalg.qr(rng.standard_normal((len(vals), len(vals))))
+    a = (q * vals) @ q.T
+    return 0.5 * (a + a.T)
+
+
+@pytest.mark.parametrize("kind", ["random", "degenerate", "triple", "cluster1e-6", "cluster1e-10", "graded"])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 13, 16, 17, 24, 29, 30, 31, 32, 33, 40])
+def test_loewdin_spectra(kind, n):
+    rng = np.random.default_rng(1000 + n)
+    vals = spectrum(kind, n, rng) if n > 1 else np.array([1.7])
+    S = with_spectrum(vals, rng)
+    h = rng.standard_normal((n, n))
+    h = 0.5 * (h + h.T)
+    X, U, s, h1 = ops.loewdin(torch.from_numpy(S).to(DEV), torch.from_numpy(h).to(DEV))
+    X, U, s, h1 = X.cpu().numpy(), U.cpu().numpy(), s.cpu().numpy(), h1.cpu().numpy()
+    w, v = np.linalg.eigh(S)
+    Xref = (v / np.sqrt(w)) @ v.T
+    scale = np.abs(Xref).max()
+    # graded: condition number 1e8, s^-1/2 up to 1e4 -- LAPACK itself is only good to ~1e-9 (relative) there
+    tol = 1e-10 if kind != "graded" else 2e-7
+    assert np.abs(X - Xref).max() < tol * scale, (kind, n, np.abs(X - Xref).max() / scale)
+    np.testing.assert_allclose(np.sort(s), w, rtol=0, atol=1e-11 * w.max())
+    assert np.abs(U.T @ U - np.eye(n)).max() < 1e-11
+    assert np.abs(h1 - Xref.T @ h @ Xref).max() < tol * scale * scale * max(1.0, np.abs(h).max()) * n
+
+
+@pytest.mark.parametrize("kind", ["random", "degenerate", "cluster1e-6", "cluster1e-10"])
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 7, 10, 15, 20, 21, 31, 32, 33, 48])
+def test_subspace_spectra(kind, T):
+    rng = np.random.default_rng(2000 + T)
+    A = rng.standard_normal((T, T))
+    S = A @ A.T / T + np.eye(T)
+    L = np.linalg.cholesky(S)
+    vals = (spectrum(kind, T, rng) if T > 1 else np.array([0.4])) - 2.0        # indefinite, like an energy spectrum
+    C = with_spectrum(vals, rng)
+    H = L @ C @ L.T                                                            # H c = E S c has the spectrum `vals`
+    H = 0.5 * (H + H.T)
+    nroots = min(T, 3)
+    rows1 = torch.from_numpy(np.ascontiguousarray(H.reshape(-1))).to(DEV)     # one-body part carries H (full6 layout)
+    rows2 = torch.zeros(T * T, dtype=torch.float64, device=DEV)
+    ev, vec, _, _, Hd = ops.subspace_solve(rows1, rows2, torch.from_numpy(S).to(DEV), 6, nroots)
+    ev, vec = ev.cpu().numpy(), vec.cpu().numpy()
+    w, v = sla.eigh(H, S)
+    np.testing.assert_allclose(ev, w[:nroots], rtol=0, atol=1e-10 * max(1.0, np.abs(w).max()))
+    # returned vectors: S-orthonormal, and each one an eigenvector of its eigenvalue
+    assert np.abs(vec @ S @ vec.T - np.eye(nroots)).max() < 1e-10
+    for k in range(nroots):
+        r = H @ vec[k] - ev[k] * (S @ vec[k])
+        assert np.abs(r).max() < 1e-9 * max(1.0, np.abs(H).max()), (kind, T, k)
