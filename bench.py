@@ -199,7 +199,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def measure(trd, aos, G, nslots, steps, warmup, sharded_pairs, all_stages=False):
+    def measure(trd, aos, G, nslots, steps, warmup, sharded_pairs, all_stages=False, pipelined=False):
         """Time `steps` passes over batches of G geometries with `nslots` batches in flight on this rank.
         all_stages: time every instrumented stage (two event records per launch), not only K5 and K8."""
         mk_stream = lambda: (torch.cuda.Stream(dev) if nslots > 1 else None)
@@ -215,6 +215,14 @@ def main():
         else:
             runners = evs
         step = lambda k: runners[k % nslots].enqueue(inputs[k % len(inputs)], 1, a.energy_only)
+        if pipelined:
+            # ONE caller stream, the Loewdin kernel of the next batch overlapped inside the library
+            from evcont_amd.evaluator import PipelinedBatchedEvaluator
+            pe = PipelinedBatchedEvaluator(trd, A, G)
+            evs = pe.evs
+            runners = [pe]
+            step = lambda k: pe.enqueue(inputs[k % len(inputs)], next_aob=inputs[(k + 1) % len(inputs)],
+                                        energy_only=a.energy_only)
         # set-up, not a step: every slot's evaluator is touched once (first-use kernel attributes, first touch of its
         # workspace), so that a small --warmup does not leave that inside the timed region of the other streams
         for k in range(nslots):
@@ -243,9 +251,14 @@ def main():
         e_last = float(evs[0].energy.reshape(-1)[0].item())
         assert np.isfinite(e_last), "non-finite energy in the timed region"
         # one more, untimed evaluation of the FIRST input: a number that can be compared between legs
-        runners[0].enqueue(inputs[0], 1, a.energy_only)
-        fence()
-        e_check = float(evs[0].energy.reshape(-1)[0].item())
+        if pipelined:
+            slot_ = runners[0].enqueue(inputs[0], energy_only=a.energy_only)
+            fence()
+            e_check = float(runners[0].results(slot_).energy.reshape(-1)[0].item())
+        else:
+            runners[0].enqueue(inputs[0], 1, a.energy_only)
+            fence()
+            e_check = float(evs[0].energy.reshape(-1)[0].item())
         per_rank = [steps * G / dt]          # this rank's own rate (its G geometries per step over ITS wall time)
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -397,7 +410,14 @@ def main():
     if world == 1 and not a.no_md_regime and S > 1:
         # the same batches on ONE stream: the streaming kernels without another batch's kernels beside them
         one = measure(trd, aos_run, G, 1, max(10, a.steps // 2), 3, False, all_stages=True)
+        pipe = measure(trd, aos_run, G, 1, max(10, a.steps // 2), 3, False, pipelined=True) if G > 1 else None
         if rank == 0:
+            if pipe is not None:
+                out["single_stream_pipelined"] = {
+                    "value": pipe["value"], "unit": "geometries/s", "ms_per_step": pipe["ms_per_step"],
+                    "note": "one caller stream; the Loewdin kernel of the NEXT batch runs on the library's internal side "
+                            "stream beside the current batch (evaluator.PipelinedBatchedEvaluator, "
+                            "evc_phase_loewdin_batch + EVC_FLAG_LOEWDIN_DONE)"}
             out["single_stream"] = {"value": one["value"], "unit": "geometries/s", "ms_per_step": one["ms_per_step"],
                                     "note": "same batch size, one stream: kernels of one batch at a time",
                                     "k5_rows_ms": one["k5_ms"], "k5_GBs": one["k5_GBs"],

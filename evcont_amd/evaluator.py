@@ -472,6 +472,61 @@ class BatchedEvaluator:
         check(rc, "evc_phase_gradient_batch")
 
 
+class PipelinedBatchedEvaluator:
+    """Batches submitted one after another by a caller that uses ONE stream, with the Loewdin orthogonalisation of
+    the NEXT batch taken off the critical path inside the library: it is a latency-bound kernel on one workgroup per
+    geometry that reads only ``S`` and ``hcore`` (``evc_phase_loewdin_batch``), so it runs on an internal side stream
+    while the current batch's chip-filling kernels execute, into the workspace of a second evaluator; the next
+    ``enqueue`` then skips it (``EVC_FLAG_LOEWDIN_DONE``).  Fork / join with events; results of batch k are in
+    ``self.results(k)`` (two slots, alternating).
+
+        pe = PipelinedBatchedEvaluator(trdms, natm, G)
+        for k, aob in enumerate(batches):
+            pe.enqueue(aob, next_aob=batches[k + 1] if k + 1 < len(batches) else None)
+    """
+
+    def __init__(self, trdms: DeviceTRDMs, natm: int, count: int, stream: Optional["torch.cuda.Stream"] = None):
+        d = trdms.device
+        self.stream = stream if stream is not None else torch.cuda.current_stream(d)
+        self.side = torch.cuda.Stream(d)
+        self.evs = [BatchedEvaluator(trdms, natm, count, stream=self.stream) for _ in range(2)]
+        self._batch_done = [torch.cuda.Event(), torch.cuda.Event()]   # main stream: slot's last batch has finished
+        self._l_done = [torch.cuda.Event(), torch.cuda.Event()]       # side stream: slot's Loewdin prefetch has finished
+        self._prefetched = [None, None]
+        self._used = [False, False]
+        self._k = 0
+
+    def enqueue(self, aob: DeviceAOBatch, next_aob: Optional[DeviceAOBatch] = None, nroots: int = 1,
+                energy_only: bool = False) -> int:
+        """Enqueue one batch; returns its slot (0 / 1).  ``next_aob``: the batch the NEXT call will submit."""
+        slot = self._k & 1
+        ev = self.evs[slot]
+        if self._prefetched[slot] is aob:
+            self.stream.wait_event(self._l_done[slot])          # join
+        else:
+            ev._loewdin_done = False                            # (a prefetch for another batch is simply dropped)
+        self._prefetched[slot] = None
+        ev.enqueue(aob, nroots, energy_only)
+        self._batch_done[slot].record(self.stream)
+        self._used[slot] = True
+        if next_aob is not None:
+            o = 1 - slot
+            if self._used[o]:
+                self.side.wait_event(self._batch_done[o])       # fork: that workspace is free once ITS batch is done
+            self.evs[o].phase_loewdin(next_aob, stream=self.side)
+            self._l_done[o].record(self.side)
+            self._prefetched[o] = next_aob
+        self._k += 1
+        return slot
+
+    def results(self, slot: int) -> "BatchedEvaluator":
+        return self.evs[slot]
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+        self.side.synchronize()
+
+
 class ContinuationEvaluator:
     """Energy / energy+force of the continuation at one geometry per call
     (``get_energy_with_grad``, ``ab_initio_gradients_loewdin.py:308-379``)."""

@@ -176,3 +176,30 @@ def test_phase_loewdin_then_flagged_call_equals_fused():
     assert np.array_equal(E0, E1) and np.array_equal(g0, g1)
     E2, g2 = be.energies_with_grads(aob)          # the flag is consumed by one call
     assert np.array_equal(E0, E2) and np.array_equal(g0, g2)
+
+
+def test_pipelined_batched_evaluator_matches_plain():
+    """Loewdin of the next batch on the library's side stream (PipelinedBatchedEvaluator): same numbers as the plain
+    evaluator for a sequence of different batches, including a dropped prefetch."""
+    import torch
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, BatchedEvaluator, PipelinedBatchedEvaluator
+    from evcont_amd.synthetic import make_ao_arrays, make_trdms, pack_rows
+    dev = torch.device("cuda:0")
+    n, T, A, G = 13, 5, 3, 4
+    S, one, two = make_trdms(n, T, 62)
+    trd = DeviceTRDMs(one, pack_rows(two, True, True), S, dev, compress="sym8")
+    batches = [DeviceAOBatch.from_arrays([make_ao_arrays(n, A, 950 + 10 * b + k, ao_sizes=(9, 2, 2), ip1_rs_symmetric=True)
+                                          for k in range(G)], dev, pack_ip1=True, pack_eri=True) for b in range(5)]
+    ref = BatchedEvaluator(trd, A, G)
+    want = [ref.energies_with_grads(b) for b in batches]
+    pe = PipelinedBatchedEvaluator(trd, A, G)
+    order = [0, 1, 2, 3, 4, 2]
+    for i, b in enumerate(order):
+        nxt = batches[order[i + 1]] if i + 1 < len(order) else None
+        if i == 2:
+            nxt = batches[0]                      # a wrong hint: the prefetch must be ignored by the next call
+        slot = pe.enqueue(batches[b], next_aob=nxt)
+        pe.synchronize()
+        r = pe.results(slot)
+        assert np.array_equal(r.energy[:, 0].cpu().numpy(), want[b][0])
+        assert np.array_equal(r.grad[:, :A].cpu().numpy(), want[b][1])

@@ -1,0 +1,31 @@
+"""The kernel variants that are selected by environment knobs (read once per process; DESIGN.md, table of tuning
+knobs) are held to the same parity tests as the defaults: each one is run in a fresh interpreter on a subset of the
+oracle-parity suite that reaches it."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.py::test_sym8_batched",
+          "tests/test_gpu_bench_config.py::test_h2o_shape_t10_against_oracle",
+          "tests/test_gpu_bench_config.py::test_k5_every_row_group_body"]
+
+
+@pytest.mark.parametrize("env", [
+    {"EVC_PT_DIRECT": "1"},                   # barrier-free pair transform (pt_sym_kernel)
+    {"EVC_PT_ROWBUF": "0"},                   # staged pair transform with the per-lane gather
+    {"EVC_ROWS_SHAPE2_NARROW": "722"},        # eight-wave split-set K5
+    {"EVC_ROWS_SHAPE2_NARROW": "422"},
+    {"EVC_EIGH_F32": "0"},                    # FP64 Jacobi eigensolvers
+    {"EVC_EIGH_F32": "1"},                    # FP32 Jacobi start + refinement
+], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_variant_passes_parity_subset(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + SUBSET,
+                       cwd=REPO, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
