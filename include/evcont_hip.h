@@ -11,8 +11,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to float64 (int64 for aoslices) unless noted;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
- *     synchronises, nothing allocates, there is no global state besides a thread-local
- *     error string (and the opt-in evc_profile_* measurement hook);
+ *     synchronises, nothing allocates.  State kept by the library: a thread-local error string; per
+ *     kernel one bit per device "dynamic LDS limit raised" (hipFuncSetAttribute is per device: one
+ *     process may drive several devices through this library); the opt-in evc_profile_* measurement
+ *     hook (process-wide, mutex-protected); tuning knobs read from the environment once per process;
  *   - return value 0 = success; <0 = argument error (nothing enqueued);
  *     >0 = hipError_t of a failed launch;
  *   - matrices are row-major (C order), exactly as numpy hands them to the reference.
