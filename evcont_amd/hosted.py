@@ -110,7 +110,9 @@ class HostedEvaluator:
         # (Measured alternatives on MI355X / ROCm 7.2, H30, per step: this order 425 us; int2e on the forked stream as
         #  well with the Loewdin kernel started behind the small slab alone, evc_phase_loewdin_batch: 530-540 us -- every
         #  cross-stream event wait on the critical path costs 20-25 us and the runtime takes tens of microseconds on
-        #  the host to accept a 10 MB copy; the same enqueue replayed as a HIP graph: 555-590 us.)
+        #  the host to accept a 10 MB copy; the same with the Loewdin kernel reading S / hcore straight from the pinned
+        #  host buffers (no upload in front of it at all) and every copy on the forked stream: 430-515 us; the same
+        #  enqueue replayed as a HIP graph: 555-590 us.)
         with torch.cuda.stream(main):                     # submitted FIRST: the copy engine works in submission order
             d0.copy_(h0, non_blocking=True)
             d1.copy_(h1, non_blocking=True)
