@@ -298,8 +298,8 @@ def main():
         t_min = nbytes / (HBM_PEAK_GBS * 1e9) + flops / (MFMA_F64_PEAK_TFLOPS * 1e12)
         return {"frac": t_min / (ms_per_step * 1e-3), "bytes_per_step": nbytes, "flops_per_step": flops,
                 "ms_at_peaks": t_min * 1e3, "ms_per_step": ms_per_step,
-                "note": "bytes / 8 TB/s + flops / 78.6 TFLOP/s over the measured step (per GPU); FP64 MFMA sustains "
-                        "47 TFLOP/s on this part (profiles/mfma_f64_peak.txt)"}
+                "note": "bytes / 8 TB/s + flops / 78.6 TFLOP/s over the measured step (per GPU); FP64 MFMA reaches "
+                        "77 TFLOP/s with ArchVGPR accumulators (profiles/mfma_f64_regclass.txt)"}
 
     G, S = max(1, a.batch), max(1, a.streams)
     pairs_first = world > 1 and a.shard == "pairs"

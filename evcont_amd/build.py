@@ -16,6 +16,11 @@ HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "evc
 ARCH = "gfx950"
 # EVC_DEBUG_STAMPS=1 builds the eigen-kernels with their phase stamps (tools/micro/loewdin_time.py); never shipped
 EXTRA = ["-DEVC_DEBUG_STAMPS"] if os.environ.get("EVC_DEBUG_STAMPS") else []
+# FP64 MFMA with its accumulator in ArchVGPRs issues every 64 cycles on gfx950, with an AccVGPR accumulator (what the
+# compiler's heuristic picks as soon as a kernel is register-hungry) only every ~105: 77 against 47 TFLOP/s
+# (tools/micro/mfma_f64_peak.hip built both ways, profiles/mfma_f64_peak.txt).  EVC_MFMA_AGPR=1 builds the old form.
+if not os.environ.get("EVC_MFMA_AGPR"):
+    EXTRA += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc() -> str:

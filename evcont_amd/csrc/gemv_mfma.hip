@@ -210,7 +210,11 @@ __global__ __launch_bounds__(256, MINW) void gemv_rows_mfma_pipe_kernel(GemvRows
     }
     if constexpr (MAXT >= 7) {
         if (ntile == 7) EVC_ROWS_BODY(7)  // wave-uniform
+    }
+    if constexpr (MAXT >= 6) {
         if (ntile == 6) EVC_ROWS_BODY(6)
+    }
+    if constexpr (MAXT >= 5) {
         if (ntile == 5) EVC_ROWS_BODY(5)
     }
     if constexpr (MAXT >= 4) {
@@ -337,7 +341,7 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, h
     static const int sh2n = getenv("EVC_ROWS_SHAPE2_NARROW") ? atoi(getenv("EVC_ROWS_SHAPE2_NARROW")) : 711;
     const int shape = gs == 2 ? (Lin.p[0].cols <= 200000 ? sh2n : sh2) : sh1;
     const int kernel_maxt = shape / 100;
-    int max_tiles = tiles <= 0 ? (kernel_maxt >= 7 ? 7 : kernel_maxt >= 3 ? 3 : kernel_maxt) : tiles;   // see the measurements above
+    int max_tiles = tiles <= 0 ? (kernel_maxt >= 5 ? kernel_maxt : kernel_maxt >= 3 ? 3 : kernel_maxt) : tiles;   // see the measurements above
     if (max_tiles > kernel_maxt) max_tiles = kernel_maxt;
     for (int k = 0; k < 2; ++k) {
         // balanced row groups of at most max_tiles tiles
@@ -365,6 +369,8 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, h
         switch (shape) {
             // in situ, G=32: pipelined 321 -> 226 us; lean 330 -> 238, 230 -> 247, 240 -> 259, 150 -> 300; 711 -> 270
             EVC_ROWS_CASE(2, 3, 2, 1) EVC_ROWS_CASE(2, 3, 3, 0) EVC_ROWS_CASE(2, 2, 4, 0) EVC_ROWS_CASE(2, 7, 1, 1)
+            // one wave per SIMD with everything in ArchVGPRs (<= 256): fast-form MFMA, single-buffer body
+            EVC_ROWS_CASE(2, 6, 1, 0) EVC_ROWS_CASE(2, 5, 1, 0) EVC_ROWS_CASE(2, 7, 1, 0)
             default: set_error("gemv_rows_mfma: unknown EVC_ROWS_SHAPE2=%d", shape); return -1;
         }
     } else {

@@ -18,3 +18,4 @@ for r in rows:
 for k,d in agg.items():
     print(k, {c: round(sum(v)/len(v),1) for c,v in d.items()}, 'n=',len(next(iter(d.values()))))
 PY
+rm -rf $R/gpurun_out/pmc_$TAG
