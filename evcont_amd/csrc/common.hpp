@@ -126,4 +126,12 @@ __device__ __forceinline__ int64_t tri_row(int64_t m) {
     return R;
 }
 
+// The same for small indices (m < 2^20) in 32-bit / single-precision arithmetic (a handful of instructions).
+__device__ __forceinline__ int tri_row_small(int m) {
+    int R = (int)((__builtin_sqrtf(8.0f * (float)m + 1.0f) - 1.0f) * 0.5f);
+    if (R * (R + 1) / 2 > m) --R;
+    if ((R + 1) * (R + 2) / 2 <= m) ++R;
+    return R;
+}
+
 }  // namespace evc

@@ -1,3 +1,12 @@
+#define EVC_PT_STAMP(i_)                                                                                       \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        long long t_;                                                                                          \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+        if (blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && (threadIdx.x & 63) == 0 && (i_) < 64) \
+            g_pt_stamp[(threadIdx.x >> 6) * 64 + (i_)] = t_;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
 // Four-index basis rotations on the FP64 matrix cores and the N^4-sized helpers around them.
 //   K3/K14  quarter transform (v_mfma_f64_16x16x4_f64)          electron_integral_utils.py:136,
 //                                                              gradients_loewdin.py:224-232,339
@@ -11,6 +20,7 @@
 namespace evc {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 // v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md §3):
 //   A[i][k]: lane l holds i = l&15, k = l>>4        B[k][j]: k = l>>4, j = l&15
@@ -145,6 +155,34 @@ int launch_quarter_transform(const double *in, int64_t sin, const double *C, int
 constexpr int kPtRawMax = (kPairTransformMaxN * (kPairTransformMaxN + 1) / 2 + 1 + 127) / 128;   // double2 per lane: 5
 constexpr int kPtRowLen = kPtRawMax * 128 + 4;   // + two zero slots (padding fragments), 16-byte multiple
 
+// Timing experiments (tools/micro/pt_stamps.py; build with EVC_DEBUG_STAMPS=1): the four waves of one workgroup in the
+// middle of the grid stamp their phases with the 100 MHz wall clock.  Compiled out of the product library.
+#ifdef EVC_DEBUG_STAMPS
+__device__ long long g_pt_stamp[4 * 64];
+__device__ long long g_pt_wg[4096 * 3];   // per workgroup: entry, exit, (XCC_ID << 8 | CU/SE id register)
+#define EVC_PT_WG(i_)                                                                                          \
+    do {                                                                                                       \
+        const int L_ = blockIdx.y * gridDim.x + blockIdx.x;                                                    \
+        if (threadIdx.x == 0 && L_ < 4096) {                                                                   \
+            g_pt_wg[3 * L_ + (i_)] = wall_clock64();                                                           \
+            if ((i_) == 0) {                                                                                   \
+                unsigned hw_, xcc_;                                                                            \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                              \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                            \
+                g_pt_wg[3 * L_ + 2] = ((long long)(xcc_ & 0xF) << 32) | hw_;                                   \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+#define EVC_PT_STAMP(i_)                                                                                       \
+    do {                                                                                                       \
+        if (blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && (threadIdx.x & 63) == 0 && (i_) < 64) \
+            g_pt_stamp[(threadIdx.x >> 6) * 64 + (i_)] = wall_clock64();                                        \
+    } while (0)
+#else
+#define EVC_PT_STAMP(i_) do { } while (0)
+#define EVC_PT_WG(i_) do { } while (0)
+#endif
+
 template <int NPAD, bool ROWBUF>
 __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     constexpr int LDX = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;
@@ -171,6 +209,23 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     const int ntiles = sym ? (npairs + QT - 1) / QT : n * ntq;
     const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(ntiles, t_begin + a.tiles_per_wg);
     if (t_begin >= t_end) return;
+    EVC_PT_STAMP(0);
+    EVC_PT_WG(0);
+    if (a.stagger_mode) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, tot = gridDim.x * gridDim.y;
+        bool late = false;
+        switch (a.stagger_mode) {
+            case 1: late = L >= tot / 2; break;
+            case 2: late = ((L >> 3) & 1) != 0; break;
+            case 3: late = (L & 1) != 0; break;
+            case 4: late = ((L >> 8) & 1) != 0; break;
+            default: late = ((L >> 3) / 32 & 1) != 0; break;
+        }
+        if (late) {
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     const bool lower = a.in_lower != 0;  // the n x n matrices are symmetric and valid for r >= s only
     // rs_lower: the consumer needs the result N[r'][s'] for s' <= r' only: upper tiles of X^T H are not computed,
     // the stage holds the lower triangle (row index tri(r',s')) and only those rows of `out` are written
@@ -270,21 +325,27 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
         Xs[d * LDX + c] = v;
     }
     lds_barrier();
+    EVC_PT_STAMP(1);
     double xf[KS][NT];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
         for (int t = 0; t < NT; ++t) xf[kk][t] = Xs[(4 * kk + l4) * LDX + t * 16 + l15];
     if constexpr (ROWBUF) row_to_fragments(mf, dlt);
+    EVC_PT_STAMP(2);
 
     for (int t = t_begin; t < t_end; ++t) {
+        [[maybe_unused]] const int sb = 3 + 8 * (t - t_begin);
         for (int ql = wave; ql < QT; ql += 4) {
             // prefetch the wave's next matrix: slot ql + 4 of this tile, else its first slot of the next tile
             double mn[ROWBUF ? 1 : NT][ROWBUF ? 1 : KS];
             int pn = 0, qn = 0;
             const bool have_next = (ql + 4 < QT) ? pair_of(t, ql + 4, pn, qn) : (t + 1 < t_end && pair_of(t + 1, wave, pn, qn));
+            [[maybe_unused]] const int fb = (t == t_begin + 1) ? 44 + (ql >= 4 ? 5 : 0) : 64;
+            EVC_PT_STAMP(fb);
             if constexpr (ROWBUF) fetch_row(have_next, pn, qn, dlt_next);
             else load_matrix(mn, have_next, pn, qn);
+            EVC_PT_STAMP(fb + 1);
             if (have) {  // wave-uniform
                 // H = M X
                 // (a dependent f64 MFMA costs ~3x the issue interval: the NT*NT tile chains are interleaved)
@@ -299,6 +360,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
                     for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
                         for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
+                EVC_PT_STAMP(fb + 2);
                 if (a.k3) {
                     // lead_sym: only K3[s'][p][q][:] with q <= p is written (its consumer folds the p <-> q symmetry),
                     // as K3[s'][tri(p,q)][:] times the multiplicity of (p,q)
@@ -329,6 +391,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 #pragma unroll
                         for (int st = 0; st < NT; ++st)
                             if (!(rsl && st > it)) nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
+                EVC_PT_STAMP(fb + 3);
 #pragma unroll
                 for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -341,7 +404,9 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
                                 else if (s2 <= r2) stage[(r2 * (r2 + 1) / 2 + s2) * QP + ql] = nn[it][st][reg];
                             }
                         }
+                EVC_PT_STAMP(fb + 4);
             }
+            EVC_PT_STAMP(sb + (ql >= 4 ? 2 : 0));
             if constexpr (ROWBUF) {
                 row_to_fragments(mf, dlt_next);   // (the fragments of the current matrix are consumed: same wave, in order)
             } else {
@@ -353,8 +418,10 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             have = have_next;
             p = pn;
             q = qn;
+            EVC_PT_STAMP(sb + (ql >= 4 ? 3 : 1));
         }
         lds_barrier();
+        EVC_PT_STAMP(sb + 4);
         // write-out: 8 lanes cover the pair run of one (r',s')
         const int wl = threadIdx.x & 7;
         int wp = 0, wq = 0;
@@ -430,8 +497,332 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
                 for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
             }
         }
+        EVC_PT_STAMP(sb + 5);
         lds_barrier();  // the stage is free again; the stores above drain while the next tile is computed
+        EVC_PT_STAMP(sb + 6);
     }
+    EVC_PT_WG(1);
+}
+
+// ------------------------------------------------------------------ software-pipelined pair transform
+// pt_kernel above alternates, per tile of eight leading pairs, a matrix-core phase (two matrices per wave) with a
+// write-out phase, and every workgroup of the launch does so at the same moments: phase stamps (tools/micro/
+// pt_stamps.py) show the 56 MFMAs of a matrix issue in 1.8 us of the 3.5 us a wave spends per matrix (the rest: index
+// arithmetic, the operand row's round trip through LDS, the stage writes), and the write-out of a tile takes 2.5-2.9 us
+// because the whole chip stores at once (15 MB per phase) and then not at all.  This kernel is the same arithmetic for
+// the fully symmetric case (dense (pair, pair) operand, q <= p, lower-triangle results) as ONE software pipeline per
+// wave: everything that is not an MFMA is cut into small pieces that are issued between the MFMA groups of the
+// CURRENT matrix --
+//   * H phase of matrix i (KS groups of NT*NT MFMAs): the stage writes of matrix i-1's result (kept in registers);
+//   * N phase: the operand row of matrix i+1 goes from registers to the wave's LDS row and comes back as MFMA
+//     fragments (the registers of matrix i's fragments are free after its H phase), the global fetch of matrix i+2's
+//     row is issued, K3 is stored (MODE 1), half of the write-out passes of an EARLIER tile --
+// with a double-buffered stage (8 doubles per result row and buffer, the slot XOR-swizzled by the row so that the
+// accumulator layout writes it without bank conflicts) and ONE workgroup barrier per tile: barrier(j) sits after the H phase of
+// the first matrix of tile j+1 (which wrote the last results of tile j); tile j is then written out during the
+// following two N phases, before barrier(j+1), after which its buffer is written again.  The stores of the launch
+// are spread evenly over its duration.  (vmcnt counts loads and stores in order on gfx9: the wait for an operand row
+// also waits for every store issued before it, so the write-out sits in the N phases only and the row is awaited at
+// the start of the next one, an H phase later.)
+// MODE 0: dense (pair, pair) result out[tri(r',s')][tri(p,q)] (x multiplicity of (p,q) with out_pairs = 2);
+// MODE 1: the 8-fold compressed packed vector (+ K3 when asked for).
+template <int NPAD, int MODE>
+__global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
+    constexpr int LDX = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;
+    constexpr int KS = NPAD / 4;
+    constexpr int NT = NPAD / 16;
+    constexpr int NPASS_MAX = (NPAD * (NPAD + 1) / 2 + 31) / 32;   // write-out passes of a tile (32 result rows each)
+    constexpr int PH2 = (NPASS_MAX + 1) / 2;                       // ... per N phase
+    constexpr int NRES = NT * (NT + 1) / 2 * 4;                    // result registers (doubles) of a matrix per lane
+    constexpr int SPG = (NRES + KS - 1) / KS;                      // stage writes per MFMA group
+    constexpr int FPG = (NT * KS + (KS - 2) - 1) / (KS - 2);       // fragment reads per MFMA group (groups 2..KS-1)
+    constexpr int EPG = (NT * NT * 4 + KS - 1) / KS;               // K3 stores per MFMA group
+    constexpr int PPG = (PH2 + KS - 1) / KS;                       // write-out passes per MFMA group (N phase)
+    constexpr int RAWN = (NPAD * (NPAD + 1) / 2 + 1 + 127) / 128;  // 16-byte loads per lane that cover a row
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n;
+    const int npairs = n * (n + 1) / 2;
+    const int64_t g = blockIdx.y;
+    const double *__restrict__ in = a.in + g * a.sin;
+    const double *__restrict__ C = a.C + g * a.sC;
+    const int ntiles = (npairs + 7) / 8;
+    const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(ntiles, t_begin + a.tiles_per_wg);
+    if (t_begin >= t_end) return;
+    EVC_PT_WG(0);
+    EVC_PT_STAMP(0);
+    const int niter = 2 * (t_end - t_begin);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *mrow = sm + wave * kPtRowLen;   // the wave's operand row
+    // the stage: result row u = tri(r',s') of buffer b (tile parity), slot s (pair of the tile) at
+    //   u * 16 + b * 8 + (s ^ f(u)),  f(u) = (u >> 1) & 7
+    // (16 consecutive rows of one slot fall on 16 different bank pairs; f(u + 32) = f(u))
+    double *stage = sm + 4 * kPtRowLen;
+    double *Xs = stage + npairs * 8;        // X is staged in the upper half (one extra barrier before the main loop)
+    char *__restrict__ outb = nullptr;
+    if constexpr (MODE == 0) outb = reinterpret_cast<char *>(a.out + g * a.sout);
+    else outb = reinterpret_cast<char *>(a.packed + g * a.spacked);
+    const bool weigh = MODE == 1 || a.out_pairs > 1;
+
+    int foff[NT][KS];   // fragment (rt, kk) of the symmetric n x n matrix in its packed row
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int r = rt * 16 + l15, s = 4 * kk + l4;
+            const int hi = s > r ? s : r, lo = s > r ? r : s;
+            foff[rt][kk] = (r < n && s < n) ? hi * (hi + 1) / 2 + lo : kPtRawMax * 128;   // else: a zero slot
+        }
+    // stage index of result register (it, st <= it, reg) for slot `wave` of buffer 0 (-1: not a result); the slot of
+    // the second matrix of a tile and the buffer are XORed in: (slot + 4) ^ f = (slot ^ f) ^ 4 for slot < 4
+    int sa[NT][NT][4];
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int st = 0; st <= it; ++st)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
+                const int u = r2 * (r2 + 1) / 2 + s2;
+                sa[it][st][reg] = (r2 < n && s2 <= r2) ? u * 16 + (wave ^ ((u >> 1) & 7)) : -1;
+            }
+    [[maybe_unused]] const int dq = l15 - l4;   // result register reg of a diagonal tile is r' == s'  <=>  dq == 4 reg
+    // K3 (MODE 1): bit (rt * NT + st) * 4 + reg: the lane holds an element of H with r < n, s' < n
+    [[maybe_unused]] unsigned kmask = 0;
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int st = 0; st < NT; ++st)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (rt * 16 + l4 + 4 * reg < n && st * 16 + l15 < n) kmask |= 1u << ((rt * NT + st) * 4 + reg);
+    }
+    if (lane < 4) mrow[kPtRawMax * 128 + lane] = 0.0;
+
+    d2 raw[RAWN];
+    // row e of the operand (e clamped: idle slots fetch row 0 and their result is never written out)
+    auto fetch = [&](int e) -> int {
+        const double *row = in + (int64_t)(e < npairs ? e : 0) * npairs;
+        const int d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
+        const double *w0 = row - d_;          // 16-byte aligned window
+        const int lim = npairs + d_;          // valid doubles of the window
+        // every lane loads an aligned 16-byte granule that holds at least one double of the row (lanes past the end
+        // re-read the first granule): no predicates, and such a load cannot leave the pages of the operand
+#pragma unroll
+        for (int u = 0; u < RAWN; ++u) {
+            const int j = 128 * u + 2 * lane;
+            raw[u] = *reinterpret_cast<const d2 *>(w0 + (j < lim ? j : 0));
+        }
+        return d_;
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int u = 0; u < RAWN; ++u) *reinterpret_cast<d2 *>(mrow + 128 * u + 2 * lane) = raw[u];
+    };
+    auto is_diag = [&](int x) -> bool {
+        const int r = tri_row_small(x);
+        return x == r * (r + 3) / 2;
+    };
+
+    const int e0 = 8 * t_begin + wave;   // this wave's leading pair of iteration i: e0 + 4 i
+    int d_rd = fetch(e0);
+    for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += 256) {
+        const int d = idx / NPAD, c = idx % NPAD;
+        double v = 0.0;
+        if (d < n && c < n) v = a.ct ? C[c * n + d] : C[d * n + c];
+        Xs[d * LDX + c] = v;
+    }
+    if constexpr (MODE == 1) {
+        if (blockIdx.x == 0) {   // zero the padding [M, packed_len) once per geometry
+            double *pk = a.packed + g * a.spacked;
+            const int64_t M = (int64_t)npairs * (npairs + 1) / 2;
+            for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
+        }
+    }
+    lds_barrier();
+    EVC_PT_STAMP(1);
+    double xf[KS][NT];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xf[kk][t] = Xs[(4 * kk + l4) * LDX + t * 16 + l15];
+    double mf[NT][KS];
+    park();
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = mrow[foff[rt][kk] + d_rd];
+    int d_next = fetch(e0 + 4);
+    lds_barrier();   // every wave has its X fragments: the stage may overwrite X
+    EVC_PT_STAMP(2);
+
+    // write-out: 8 lanes cover the pair run of one result row; thread (wl, ur) takes rows u0 + 32 k
+    const int wl = threadIdx.x & 7, ur = threadIdx.x >> 3;
+    [[maybe_unused]] const unsigned stride_b = 32u * (unsigned)npairs * 8u;   // MODE 0: bytes between two passes
+    [[maybe_unused]] const int64_t krow_b = (int64_t)npairs * n * 8;          // MODE 1: bytes between two K3 rows s'
+    [[maybe_unused]] const unsigned k3lane = (unsigned)((l15 * npairs * n + l4) * 8);
+
+    d4 nnp[NT][NT];      // result of the previous matrix (st <= it), staged during this matrix's H phase
+    bool prev_have = false;
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int st = 0; st < NT; ++st) nnp[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    for (int i = 0; i < niter + 2; ++i) {
+        const int ei = e0 + 4 * i;
+        const bool have = i < niter && ei < npairs;   // wave-uniform
+        const bool odd = (i & 1) != 0;
+        EVC_PT_STAMP(3 + 3 * i);
+        // ---------------------------------------------------------------- H = M X  (+ stage writes of matrix i-1)
+        d4 h[NT][NT];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int st = 0; st < NT; ++st) h[rt][st] = (d4){0.0, 0.0, 0.0, 0.0};
+        {
+            // results of matrix i-1: slot wave + 4 ((i-1) & 1) of the buffer of ITS tile
+            const int xm = ((((i - 1) >> 1) & 1) << 3) | (odd ? 0 : 4);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                if (have) {
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                        for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
+                }
+                if (prev_have) {
+#pragma unroll
+                    for (int it = 0; it < NT; ++it)
+#pragma unroll
+                        for (int st = 0; st <= it; ++st)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                const int f = ((it * (it + 1) / 2 + st) * 4 + reg);
+                                if (f / SPG == kk) {
+                                    double v = nnp[it][st][reg];
+                                    // MODE 1: the write-out doubles every element, r' == s' has multiplicity 1
+                                    if (MODE == 1 && it == st) v *= (dq == 4 * reg) ? 0.5 : 1.0;
+                                    const int si = sa[it][st][reg];
+                                    if (si >= 0) stage[si ^ xm] = v;
+                                }
+                            }
+                }
+            }
+        }
+        EVC_PT_STAMP(4 + 3 * i);
+        if (!odd && i >= 2 && i <= niter) lds_barrier();
+        EVC_PT_STAMP(5 + 3 * i);
+        // ---------------------------------------------------------------- N = X^T H
+        d4 nn[NT][NT];
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int st = 0; st < NT; ++st) nn[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
+        {
+            // write-out: tile j's result is complete after barrier(j) (H phase of iteration 2j+2); it is written out in
+            // the N phases of iterations 2j+2 (passes 0 .. PH2 - 1) and 2j+3 (the rest), PPG passes per MFMA group
+            const int jn = odd ? (i - 3) / 2 : (i - 2) / 2;
+            const int kn = odd ? PH2 : 0;
+            const bool dn = (odd ? i >= 3 : i >= 2) && 2 * jn < niter;
+            // per tile and thread: LDS index of pass 0, byte offset of its store, rows left, factor
+            const int ew = 8 * (t_begin + jn) + wl;            // the pair (column) this thread writes
+            const int u0 = (MODE == 0 ? 0 : ew) + ur;          // MODE 1: rows u >= v = ew only
+            const int rem = (dn && ew < npairs) ? npairs - u0 : 0;   // pass k is valid  <=>  32 k < rem
+            const double *dsrc = stage + (u0 * 16 + ((jn & 1) << 3) + (wl ^ ((u0 >> 1) & 7)));
+            double fac = 1.0;
+            [[maybe_unused]] double fac0 = 1.0;
+            unsigned off0 = 0;
+            [[maybe_unused]] unsigned offA = 0;
+            if (dn) {
+                if constexpr (MODE == 0) {
+                    fac = (weigh && !is_diag(ew)) ? 2.0 : 1.0;
+                    off0 = (unsigned)(u0 * npairs + ew) * 8u;
+                } else {
+                    fac = is_diag(ew) ? 2.0 : 4.0;                 // multiplicity of (p,q) x 2 (see the stage writes)
+                    fac0 = ur == 0 ? fac * a.diag_mult : fac;      // pass 0 of the thread with u == v
+                    off0 = (unsigned)(u0 * (u0 + 1) / 2 + ew) * 8u;
+                    offA = (unsigned)(32 * u0) * 8u;               // tri(u0 + 32 k) = tri(u0) + k (32 u0) + 512 k^2 + 16 k
+                }
+            }
+            const bool next = i + 1 < niter, next2 = i + 2 < niter;
+            [[maybe_unused]] char *K3b = nullptr;
+            [[maybe_unused]] double km = 1.0;
+            if constexpr (MODE == 1) {
+                if (a.k3 && have) {
+                    // only K3[s'][tri(p,q)][:] with q <= p is written (its consumer folds the p <-> q symmetry), times
+                    // the multiplicity of (p,q)
+                    K3b = reinterpret_cast<char *>(a.k3 + g * a.sk3 + (int64_t)ei * n) + k3lane;
+                    km = is_diag(ei) ? 1.0 : 2.0;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                double dv[PPG];
+#pragma unroll
+                for (int c = 0; c < PPG; ++c) {
+                    const int k = kk * PPG + c;   // pass kn + k
+                    dv[c] = (k < PH2 && 32 * (kn + k) < rem) ? dsrc[512 * (kn + k)] : 0.0;
+                }
+                if (have) {
+#pragma unroll
+                    for (int it = 0; it < NT; ++it)
+#pragma unroll
+                        for (int st = 0; st <= it; ++st)
+                            nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
+                }
+                if (kk == 0 && next) {   // the row of matrix i+1 (fetched one iteration ago) -> the wave's LDS row
+                    park();
+                    d_rd = d_next;
+                }
+                if (kk == 1 && next2) d_next = fetch(ei + 8);
+                if (kk >= 2 && next) {
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                        for (int k2 = 0; k2 < KS; ++k2)
+                            if ((rt * KS + k2) / FPG == kk - 2) mf[rt][k2] = mrow[foff[rt][k2] + d_rd];
+                }
+                if constexpr (MODE == 1) {
+                    if (K3b) {
+#pragma unroll
+                        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                            for (int st = 0; st < NT; ++st)
+#pragma unroll
+                                for (int reg = 0; reg < 4; ++reg) {
+                                    const int e = (rt * NT + st) * 4 + reg;
+                                    if (e / EPG == kk && (kmask >> e & 1u))
+                                        *reinterpret_cast<double *>(K3b + st * 16 * krow_b + (rt * 16 + 4 * reg) * 8) =
+                                            h[rt][st][reg] * km;
+                                }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < PPG; ++c) {
+                    const int k = kk * PPG + c;
+                    if (k < PH2 && 32 * (kn + k) < rem) {
+                        if constexpr (MODE == 0) {
+                            *reinterpret_cast<double *>(outb + (off0 + (unsigned)(kn + k) * stride_b)) = dv[c] * fac;
+                        } else {
+                            const unsigned kq = (unsigned)(kn + k);
+                            const unsigned off = off0 + kq * offA + (512u * kq * kq + 16u * kq) * 8u;
+                            *reinterpret_cast<double *>(outb + off) = dv[c] * ((kn + k) == 0 ? fac0 : fac);
+                        }
+                    }
+                }
+                if (i == 3) EVC_PT_STAMP(40 + kk);
+            }
+        }
+        prev_have = have;
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int st = 0; st <= it; ++st) nnp[it][st] = nn[it][st];
+    }
+    EVC_PT_STAMP(3 + 3 * (niter + 2));
+    EVC_PT_WG(1);
 }
 
 // ------------------------------------------------------------------ barrier-free pair transform (symmetric pipeline)
@@ -616,6 +1007,15 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     const int n = a.n;
     const int npad = (n + 15) / 16 * 16;
     const int ntq = (n + 7) / 8;
+    {
+        static int sm = -1, stk = 0;
+        if (sm < 0) {
+            sm = 0;
+            if (const char *e = getenv("EVC_PT_STAGGER")) sscanf(e, "%d,%d", &sm, &stk);
+        }
+        a.stagger_mode = sm;
+        a.stagger_ticks = stk;
+    }
     static const int tpw_env = getenv("EVC_PT_TILES") ? atoi(getenv("EVC_PT_TILES")) : 4;
     // few geometries: keep one tile per workgroup so that there are enough workgroups for the chip
     a.tiles_per_wg = (count < 4 || tpw_env < 1) ? 1 : (tpw_env > ntq ? ntq : tpw_env);
@@ -642,6 +1042,30 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
         }
         EVC_LAUNCH_CHECK("pair_transform_direct");
         return 0;
+    }
+    // fully symmetric step of the compressed layout's pipeline: the software-pipelined kernel, if two of its workgroups
+    // fit a CU's LDS (n <= 30; EVC_PT_PIPE=0: the phase-alternating kernel below)
+    static const bool pipe_on = !(getenv("EVC_PT_PIPE") && atoi(getenv("EVC_PT_PIPE")) == 0);
+    if (pipe_on && a.lead_sym && a.in_lower && a.rs_lower && a.in_pairs && (npad == 16 || npad == 32)) {
+        const int mode = (a.out && a.out_pairs && !a.packed && !a.k3) ? 0 : (a.packed && a.sym8 && !a.out) ? 1 : -1;
+        const size_t npairs = (size_t)n * (n + 1) / 2, xs = (size_t)npad * (npad == 32 ? 48 : 16);
+        const size_t lds = sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 8 + (npairs * 8 > xs ? npairs * 8 : xs));
+        if (mode >= 0 && lds <= 80 * 1024) {
+            const dim3 gridp((unsigned)(((npairs + 7) / 8 + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
+#define EVC_PT_PIPE_CASE(NP_, MODE_)                                                                            \
+    do {                                                                                                        \
+        static LdsAttr attr;                                                                                    \
+        if (int rc = allow_dynamic_lds(pt_pipe_kernel<NP_, MODE_>, attr, 160 * 1024, "pair_transform")) return rc; \
+        hipLaunchKernelGGL((pt_pipe_kernel<NP_, MODE_>), gridp, dim3(256), lds, st, a);                         \
+    } while (0)
+            if (npad == 16 && mode == 0) EVC_PT_PIPE_CASE(16, 0);
+            else if (npad == 16) EVC_PT_PIPE_CASE(16, 1);
+            else if (mode == 0) EVC_PT_PIPE_CASE(32, 0);
+            else EVC_PT_PIPE_CASE(32, 1);
+#undef EVC_PT_PIPE_CASE
+            EVC_LAUNCH_CHECK("pair_transform_pipe");
+            return 0;
+        }
     }
     // dense (pair, pair) operand: coalesced row fetch through a wave-private LDS row (EVC_PT_ROWBUF=0: gather)
     static const bool rowbuf_on = !(getenv("EVC_PT_ROWBUF") && atoi(getenv("EVC_PT_ROWBUF")) == 0);
@@ -1541,3 +1965,13 @@ extern "C" int evc_unpack_pair_sym(const double *packed, int n, double *out, voi
     EVC_REQUIRE(n >= 1 && n <= 215, "evc_unpack_pair_sym: n=%d out of range", n);
     return launch_unpack(packed, 0, n, out, 0, 1, as_stream(stream));
 }
+
+#ifdef EVC_DEBUG_STAMPS
+// Debug: the phase stamps of the last pt_kernel launch (4 waves x 64 stamps).
+extern "C" int evc_debug_read_pt(long long *stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(evc::g_pt_stamp), sizeof(long long) * 4 * 64);
+}
+extern "C" int evc_debug_read_pt_wg(long long *stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(evc::g_pt_wg), sizeof(long long) * 4096 * 3);
+}
+#endif
