@@ -75,7 +75,6 @@ struct PairTransformArgs {
     // transposed at write time; the transposition happens at read time instead:
     int direct;         // use that kernel
     int in_cols;        // its operand is such an output of a previous direct step: in[tri(r,s)][L] (column L)
-    int stagger_mode, stagger_ticks;   // set by launch_pair_transform (experiment: EVC_PT_STAGGER=mode,ticks)
 };
 constexpr int kPairTransformMaxN = 32;
 int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);

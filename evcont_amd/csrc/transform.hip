@@ -1,12 +1,3 @@
-#define EVC_PT_STAMP(i_)                                                                                       \
-    do {                                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
-        long long t_;                                                                                          \
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
-        if (blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && (threadIdx.x & 63) == 0 && (i_) < 64) \
-            g_pt_stamp[(threadIdx.x >> 6) * 64 + (i_)] = t_;                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
-    } while (0)
 // Four-index basis rotations on the FP64 matrix cores and the N^4-sized helpers around them.
 //   K3/K14  quarter transform (v_mfma_f64_16x16x4_f64)          electron_integral_utils.py:136,
 //                                                              gradients_loewdin.py:224-232,339
@@ -16,6 +7,7 @@
 // blockIdx.y = geometry of the batch (kernels.hpp).
 #include "common.hpp"
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace evc {
 
@@ -175,8 +167,12 @@ __device__ long long g_pt_wg[4096 * 3];   // per workgroup: entry, exit, (XCC_ID
     } while (0)
 #define EVC_PT_STAMP(i_)                                                                                       \
     do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        long long t_;                                                                                          \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
         if (blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && (threadIdx.x & 63) == 0 && (i_) < 64) \
-            g_pt_stamp[(threadIdx.x >> 6) * 64 + (i_)] = wall_clock64();                                        \
+            g_pt_stamp[(threadIdx.x >> 6) * 64 + (i_)] = t_;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
     } while (0)
 #else
 #define EVC_PT_STAMP(i_) do { } while (0)
@@ -211,21 +207,6 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     if (t_begin >= t_end) return;
     EVC_PT_STAMP(0);
     EVC_PT_WG(0);
-    if (a.stagger_mode) {
-        const int L = blockIdx.y * gridDim.x + blockIdx.x, tot = gridDim.x * gridDim.y;
-        bool late = false;
-        switch (a.stagger_mode) {
-            case 1: late = L >= tot / 2; break;
-            case 2: late = ((L >> 3) & 1) != 0; break;
-            case 3: late = (L & 1) != 0; break;
-            case 4: late = ((L >> 8) & 1) != 0; break;
-            default: late = ((L >> 3) / 32 & 1) != 0; break;
-        }
-        if (late) {
-            const long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     const bool lower = a.in_lower != 0;  // the n x n matrices are symmetric and valid for r >= s only
     // rs_lower: the consumer needs the result N[r'][s'] for s' <= r' only: upper tiles of X^T H are not computed,
     // the stage holds the lower triangle (row index tri(r',s')) and only those rows of `out` are written
@@ -558,7 +539,8 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     //   u * 16 + b * 8 + (s ^ f(u)),  f(u) = (u >> 1) & 7
     // (16 consecutive rows of one slot fall on 16 different bank pairs; f(u + 32) = f(u))
     double *stage = sm + 4 * kPtRowLen;
-    double *Xs = stage + npairs * 8;        // X is staged in the upper half (one extra barrier before the main loop)
+    double *Xs = stage + npairs * 8;        // X is staged in the upper half (one extra barrier before the main loop);
+                                            // (behind the npairs rows: one dump row of 16 doubles)
     char *__restrict__ outb = nullptr;
     if constexpr (MODE == 0) outb = reinterpret_cast<char *>(a.out + g * a.sout);
     else outb = reinterpret_cast<char *>(a.packed + g * a.spacked);
@@ -573,8 +555,9 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
             const int hi = s > r ? s : r, lo = s > r ? r : s;
             foff[rt][kk] = (r < n && s < n) ? hi * (hi + 1) / 2 + lo : kPtRawMax * 128;   // else: a zero slot
         }
-    // stage index of result register (it, st <= it, reg) for slot `wave` of buffer 0 (-1: not a result); the slot of
-    // the second matrix of a tile and the buffer are XORed in: (slot + 4) ^ f = (slot ^ f) ^ 4 for slot < 4
+    // stage index of result register (it, st <= it, reg) for slot `wave` of buffer 0 (registers that hold no result
+    // go to a dump row behind the last one); the slot of the second matrix of a tile and the buffer are XORed in:
+    // (slot + 4) ^ f = (slot ^ f) ^ 4 for slot < 4
     int sa[NT][NT][4];
 #pragma unroll
     for (int it = 0; it < NT; ++it)
@@ -584,7 +567,7 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
             for (int reg = 0; reg < 4; ++reg) {
                 const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
                 const int u = r2 * (r2 + 1) / 2 + s2;
-                sa[it][st][reg] = (r2 < n && s2 <= r2) ? u * 16 + (wave ^ ((u >> 1) & 7)) : -1;
+                sa[it][st][reg] = (r2 < n && s2 <= r2) ? u * 16 + (wave ^ ((u >> 1) & 7)) : npairs * 16 + wave;
             }
     [[maybe_unused]] const int dq = l15 - l4;   // result register reg of a diagonal tile is r' == s'  <=>  dq == 4 reg
     // K3 (MODE 1): bit (rt * NT + st) * 4 + reg: the lane holds an element of H with r < n, s' < n
@@ -663,17 +646,22 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     [[maybe_unused]] const int64_t krow_b = (int64_t)npairs * n * 8;          // MODE 1: bytes between two K3 rows s'
     [[maybe_unused]] const unsigned k3lane = (unsigned)((l15 * npairs * n + l4) * 8);
 
-    d4 nnp[NT][NT];      // result of the previous matrix (st <= it), staged during this matrix's H phase
-    bool prev_have = false;
+    // the result of a matrix stays in registers until it is staged during the next matrix's H phase: two register
+    // sets, alternating (the loop body is instantiated for even and odd i)
+    d4 nnA[NT][NT], nnB[NT][NT];
 #pragma unroll
     for (int it = 0; it < NT; ++it)
 #pragma unroll
-        for (int st = 0; st < NT; ++st) nnp[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int st = 0; st < NT; ++st) nnA[it][st] = nnB[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    for (int i = 0; i < niter + 2; ++i) {
+    // One iteration = one matrix.  COMPUTE: the main loop (idle slots of the last tile compute on row 0, their result is
+    // never written out); without: the two drain-only iterations behind it.  Everything that is not an MFMA sits
+    // BETWEEN two MFMAs in program order (sched_barrier pins it there), a few instructions at a time: the LDS and
+    // memory operations are spread evenly and their latencies end behind MFMAs, not behind each other.
+    auto iteration = [&](auto compute_tag, auto odd_tag, const int i, d4 (&nnp)[NT][NT], d4 (&nn)[NT][NT]) {
+        constexpr bool COMPUTE = decltype(compute_tag)::value, ODD = decltype(odd_tag)::value;
         const int ei = e0 + 4 * i;
-        const bool have = i < niter && ei < npairs;   // wave-uniform
-        const bool odd = (i & 1) != 0;
+        const bool have = COMPUTE && ei < npairs;   // wave-uniform
         EVC_PT_STAMP(3 + 3 * i);
         // ---------------------------------------------------------------- H = M X  (+ stage writes of matrix i-1)
         d4 h[NT][NT];
@@ -681,41 +669,35 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
         for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
             for (int st = 0; st < NT; ++st) h[rt][st] = (d4){0.0, 0.0, 0.0, 0.0};
-        {
-            // results of matrix i-1: slot wave + 4 ((i-1) & 1) of the buffer of ITS tile
-            const int xm = ((((i - 1) >> 1) & 1) << 3) | (odd ? 0 : 4);
+        if constexpr (COMPUTE || !ODD) {
+            // results of matrix i-1: slot wave + 4 ((i-1) & 1) of the buffer of ITS tile (iteration 0 and idle slots
+            // write values nobody reads)
+            const int xm = ((((i - 1) >> 1) & 1) << 3) | (ODD ? 0 : 4);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                if (have) {
 #pragma unroll
-                    for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                        for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
-                }
-                if (prev_have) {
-#pragma unroll
-                    for (int it = 0; it < NT; ++it)
-#pragma unroll
-                        for (int st = 0; st <= it; ++st)
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) {
-                                const int f = ((it * (it + 1) / 2 + st) * 4 + reg);
-                                if (f / SPG == kk) {
-                                    double v = nnp[it][st][reg];
-                                    // MODE 1: the write-out doubles every element, r' == s' has multiplicity 1
-                                    if (MODE == 1 && it == st) v *= (dq == 4 * reg) ? 0.5 : 1.0;
-                                    const int si = sa[it][st][reg];
-                                    if (si >= 0) stage[si ^ xm] = v;
-                                }
-                            }
+                for (int m = 0; m < NT * NT; ++m) {
+                    if constexpr (COMPUTE) {
+                        const int rt = m / NT, st = m % NT;
+                        h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
+                    }
+                    const int f = kk * SPG + m;   // the stage write that follows this MFMA
+                    if (m < SPG && f < NRES) {
+                        const int tile = f / 4, reg = f % 4;
+                        const int it = tile == 0 ? 0 : 1, st2 = tile == 2 ? 1 : 0;   // tiles (0,0), (1,0), (1,1)
+                        double v = nnp[it][st2][reg];
+                        // MODE 1: the write-out doubles every element, r' == s' has multiplicity 1
+                        if (MODE == 1 && it == st2) v *= (dq == 4 * reg) ? 0.5 : 1.0;
+                        stage[sa[it][st2][reg] ^ xm] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
         EVC_PT_STAMP(4 + 3 * i);
-        if (!odd && i >= 2 && i <= niter) lds_barrier();
+        if (!ODD && i >= 2 && i <= niter) lds_barrier();
         EVC_PT_STAMP(5 + 3 * i);
         // ---------------------------------------------------------------- N = X^T H
-        d4 nn[NT][NT];
 #pragma unroll
         for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -723,9 +705,9 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
         {
             // write-out: tile j's result is complete after barrier(j) (H phase of iteration 2j+2); it is written out in
             // the N phases of iterations 2j+2 (passes 0 .. PH2 - 1) and 2j+3 (the rest), PPG passes per MFMA group
-            const int jn = odd ? (i - 3) / 2 : (i - 2) / 2;
-            const int kn = odd ? PH2 : 0;
-            const bool dn = (odd ? i >= 3 : i >= 2) && 2 * jn < niter;
+            const int jn = ODD ? (i - 3) / 2 : (i - 2) / 2;
+            constexpr int kn = ODD ? PH2 : 0;
+            const bool dn = (ODD ? i >= 3 : i >= 2) && 2 * jn < niter;
             // per tile and thread: LDS index of pass 0, byte offset of its store, rows left, factor
             const int ew = 8 * (t_begin + jn) + wl;            // the pair (column) this thread writes
             const int u0 = (MODE == 0 ? 0 : ew) + ur;          // MODE 1: rows u >= v = ew only
@@ -746,10 +728,9 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
                     offA = (unsigned)(32 * u0) * 8u;               // tri(u0 + 32 k) = tri(u0) + k (32 u0) + 512 k^2 + 16 k
                 }
             }
-            const bool next = i + 1 < niter, next2 = i + 2 < niter;
             [[maybe_unused]] char *K3b = nullptr;
             [[maybe_unused]] double km = 1.0;
-            if constexpr (MODE == 1) {
+            if constexpr (MODE == 1 && COMPUTE) {
                 if (a.k3 && have) {
                     // only K3[s'][tri(p,q)][:] with q <= p is written (its consumer folds the p <-> q symmetry), times
                     // the multiplicity of (p,q)
@@ -757,6 +738,7 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
                     km = is_diag(ei) ? 1.0 : 2.0;
                 }
             }
+            constexpr int NM = NT * (NT + 1) / 2;   // MFMAs of a group: tiles (0,0), (1,0), (1,1)
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 double dv[PPG];
@@ -765,62 +747,71 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
                     const int k = kk * PPG + c;   // pass kn + k
                     dv[c] = (k < PH2 && 32 * (kn + k) < rem) ? dsrc[512 * (kn + k)] : 0.0;
                 }
-                if (have) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int it = 0; it < NT; ++it)
-#pragma unroll
-                        for (int st = 0; st <= it; ++st)
-                            nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
-                }
-                if (kk == 0 && next) {   // the row of matrix i+1 (fetched one iteration ago) -> the wave's LDS row
-                    park();
-                    d_rd = d_next;
-                }
-                if (kk == 1 && next2) d_next = fetch(ei + 8);
-                if (kk >= 2 && next) {
-#pragma unroll
-                    for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                        for (int k2 = 0; k2 < KS; ++k2)
-                            if ((rt * KS + k2) / FPG == kk - 2) mf[rt][k2] = mrow[foff[rt][k2] + d_rd];
-                }
-                if constexpr (MODE == 1) {
-                    if (K3b) {
-#pragma unroll
-                        for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                            for (int st = 0; st < NT; ++st)
-#pragma unroll
-                                for (int reg = 0; reg < 4; ++reg) {
-                                    const int e = (rt * NT + st) * 4 + reg;
-                                    if (e / EPG == kk && (kmask >> e & 1u))
-                                        *reinterpret_cast<double *>(K3b + st * 16 * krow_b + (rt * 16 + 4 * reg) * 8) =
-                                            h[rt][st][reg] * km;
-                                }
+                for (int m = 0; m < NM; ++m) {
+                    if constexpr (COMPUTE) {
+                        const int it = m == 0 ? 0 : 1, st = m == 2 ? 1 : 0;
+                        nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
                     }
-                }
+                    if (COMPUTE && m == 0) {
+                        // the operand row of matrix i+1 (fetched one iteration ago) -> the wave's LDS row -> fragments;
+                        // the row of matrix i+2 is requested (behind the last matrix: row 0, unused)
+                        if (kk == 0) {
+                            park();
+                            d_rd = d_next;
+                        }
+                        if (kk == 1) d_next = fetch(ei + 8);
+                        if (kk >= 2) {
 #pragma unroll
-                for (int c = 0; c < PPG; ++c) {
-                    const int k = kk * PPG + c;
-                    if (k < PH2 && 32 * (kn + k) < rem) {
-                        if constexpr (MODE == 0) {
-                            *reinterpret_cast<double *>(outb + (off0 + (unsigned)(kn + k) * stride_b)) = dv[c] * fac;
-                        } else {
-                            const unsigned kq = (unsigned)(kn + k);
-                            const unsigned off = off0 + kq * offA + (512u * kq * kq + 16u * kq) * 8u;
-                            *reinterpret_cast<double *>(outb + off) = dv[c] * ((kn + k) == 0 ? fac0 : fac);
+                            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                                for (int k2 = 0; k2 < KS; ++k2)
+                                    if ((rt * KS + k2) / FPG == kk - 2) mf[rt][k2] = mrow[foff[rt][k2] + d_rd];
                         }
                     }
+                    if constexpr (MODE == 1 && COMPUTE) {
+                        if (m == (NM > 1 ? 1 : 0) && K3b) {
+#pragma unroll
+                            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                                for (int st = 0; st < NT; ++st)
+#pragma unroll
+                                    for (int reg = 0; reg < 4; ++reg) {
+                                        const int e = (rt * NT + st) * 4 + reg;
+                                        if (e / EPG == kk && (kmask >> e & 1u))
+                                            *reinterpret_cast<double *>(K3b + st * 16 * krow_b + (rt * 16 + 4 * reg) * 8) =
+                                                h[rt][st][reg] * km;
+                                    }
+                        }
+                    }
+                    if (m == NM - 1) {
+#pragma unroll
+                        for (int c = 0; c < PPG; ++c) {
+                            const int k = kk * PPG + c;
+                            if (k < PH2 && 32 * (kn + k) < rem) {
+                                if constexpr (MODE == 0) {
+                                    *reinterpret_cast<double *>(outb + (off0 + (unsigned)(kn + k) * stride_b)) = dv[c] * fac;
+                                } else {
+                                    const unsigned kq = (unsigned)(kn + k);
+                                    const unsigned off = off0 + kq * offA + (512u * kq * kq + 16u * kq) * 8u;
+                                    *reinterpret_cast<double *>(outb + off) = dv[c] * ((kn + k) == 0 ? fac0 : fac);
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (i == 3) EVC_PT_STAMP(40 + kk);
             }
         }
-        prev_have = have;
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-#pragma unroll
-            for (int st = 0; st <= it; ++st) nnp[it][st] = nn[it][st];
+    };
+    for (int i = 0; i < niter; i += 2) {   // (niter is even)
+        iteration(std::true_type{}, std::false_type{}, i, nnB, nnA);
+        iteration(std::true_type{}, std::true_type{}, i + 1, nnA, nnB);
     }
+    iteration(std::false_type{}, std::false_type{}, niter, nnB, nnA);
+    iteration(std::false_type{}, std::true_type{}, niter + 1, nnA, nnB);
     EVC_PT_STAMP(3 + 3 * (niter + 2));
     EVC_PT_WG(1);
 }
@@ -1007,15 +998,6 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     const int n = a.n;
     const int npad = (n + 15) / 16 * 16;
     const int ntq = (n + 7) / 8;
-    {
-        static int sm = -1, stk = 0;
-        if (sm < 0) {
-            sm = 0;
-            if (const char *e = getenv("EVC_PT_STAGGER")) sscanf(e, "%d,%d", &sm, &stk);
-        }
-        a.stagger_mode = sm;
-        a.stagger_ticks = stk;
-    }
     static const int tpw_env = getenv("EVC_PT_TILES") ? atoi(getenv("EVC_PT_TILES")) : 4;
     // few geometries: keep one tile per workgroup so that there are enough workgroups for the chip
     a.tiles_per_wg = (count < 4 || tpw_env < 1) ? 1 : (tpw_env > ntq ? ntq : tpw_env);
@@ -1049,7 +1031,8 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     if (pipe_on && a.lead_sym && a.in_lower && a.rs_lower && a.in_pairs && (npad == 16 || npad == 32)) {
         const int mode = (a.out && a.out_pairs && !a.packed && !a.k3) ? 0 : (a.packed && a.sym8 && !a.out) ? 1 : -1;
         const size_t npairs = (size_t)n * (n + 1) / 2, xs = (size_t)npad * (npad == 32 ? 48 : 16);
-        const size_t lds = sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 8 + (npairs * 8 > xs ? npairs * 8 : xs));
+        const size_t lds =
+            sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 8 + (npairs * 8 + 16 > xs ? npairs * 8 + 16 : xs));
         if (mode >= 0 && lds <= 80 * 1024) {
             const dim3 gridp((unsigned)(((npairs + 7) / 8 + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
 #define EVC_PT_PIPE_CASE(NP_, MODE_)                                                                            \

@@ -59,6 +59,7 @@ static void run(int blocks, int iters) {
 
 int main() {
     const int it = 20000;
+    run<1>(256, it); run<2>(256, it); run<3>(256, it); run<3>(512, it);   // dependent chains: how many hide the latency
     run<4>(256, it); run<4>(512, it); run<4>(1024, it);
     run<8>(256, it / 2); run<8>(512, it / 2); run<8>(1024, it / 2);
     run<16>(256, it / 4); run<16>(512, it / 4);

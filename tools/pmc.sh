@@ -3,7 +3,7 @@
 TAG=$1; CNT=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $R/gpurun_out/pmc_$TAG -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/pmc_$TAG.log 2>&1
+timeout -k 10 ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $R/gpurun_out/pmc_$TAG -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/pmc_$TAG.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob('$R/gpurun_out/pmc_$TAG/*/*counter_collection.csv')
