@@ -19,6 +19,7 @@ EXTRA = ["-DEVC_DEBUG_STAMPS"] if os.environ.get("EVC_DEBUG_STAMPS") else []
 # FP64 MFMA with its accumulator in ArchVGPRs issues every 64 cycles on gfx950, with an AccVGPR accumulator (what the
 # compiler's heuristic picks as soon as a kernel is register-hungry) only every ~105: 77 against 47 TFLOP/s
 # (tools/micro/mfma_f64_peak.hip built both ways, profiles/mfma_f64_peak.txt).  EVC_MFMA_AGPR=1 builds the old form.
+EXTRA += os.environ.get("EVC_EXTRA_DEFS", "").split()   # experiments: extra -D flags
 if not os.environ.get("EVC_MFMA_AGPR"):
     EXTRA += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 

@@ -48,6 +48,27 @@ __device__ __forceinline__ double2 ld2_guard(const double *row, int64_t c, int64
 // Measured (tools/micro/rows_insitu.hip, 210 x 405450, G=16): 146 us with groups of <= 3 tiles,
 // 165 us with <= 4, 160 us with <= 2; wider groups (5..7 tiles, alternating half-chunk buffers) ran
 // out of registers at two waves per SIMD and were slower (200 us).
+// Timing experiments (tools/micro/k5_stamps.py; build with EVC_DEBUG_STAMPS=1): every workgroup of the pipelined rows
+// kernel stamps its entry, the end of its main loop and its exit.  Compiled out of the product library.
+#ifdef EVC_DEBUG_STAMPS
+__device__ long long g_k5_wg[1024 * 4];   // per workgroup: entry, main loop done, exit, hw id
+#define EVC_K5_WG(i_)                                                                  \
+    do {                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                   \
+            long long t_;                                                              \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            g_k5_wg[4 * blockIdx.x + (i_)] = t_;                                       \
+            if ((i_) == 0) {                                                           \
+                unsigned hw_, xcc_;                                                    \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));      \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));    \
+                g_k5_wg[4 * blockIdx.x + 3] = ((long long)(xcc_ & 0xF) << 32) | hw_;   \
+            }                                                                          \
+        }                                                                              \
+    } while (0)
+#else
+#define EVC_K5_WG(i_) do { } while (0)
+#endif
 constexpr int kMC = 32;  // columns per wave chunk
 constexpr int kRG = 4;   // most 16-row tiles per row group (register budget of two waves per SIMD)
 
@@ -183,6 +204,7 @@ __global__ __launch_bounds__(256, MINW) void gemv_rows_mfma_pipe_kernel(GemvRows
         span = j * 8 + xcd;
         if (span >= L.p[0].nspans) return;
     }
+    EVC_K5_WG(0);
     const RowProblem &P = L.p[which];
     const int64_t rows = P.rows;
     const int tpg = L.tpg[which], trem = L.trem[which];
@@ -190,8 +212,8 @@ __global__ __launch_bounds__(256, MINW) void gemv_rows_mfma_pipe_kernel(GemvRows
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t row_base = (int64_t)(rg * tpg + min(rg, trem)) * 16;
     const int ntile = tpg + (rg < trem ? 1 : 0);  // tiles of this row group (the last one may be ragged)
-    const int64_t cbeg = (int64_t)span * P.cps * 512;
-    const int64_t cend = min(P.cols, (int64_t)(span + 1) * P.cps * 512);
+    const int64_t cbeg = (int64_t)span * P.span_cols;
+    const int64_t cend = min(P.cols, (int64_t)(span + 1) * P.span_cols);
     const double *__restrict__ vr[GS];
 #pragma unroll
     for (int gs = 0; gs < GS; ++gs) {
@@ -228,6 +250,7 @@ __global__ __launch_bounds__(256, MINW) void gemv_rows_mfma_pipe_kernel(GemvRows
     }
     if (ntile == 1) EVC_ROWS_BODY(1)
 #undef EVC_ROWS_BODY
+    EVC_K5_WG(1);
     // cross-wave sum, one geometry set per pass
 #pragma unroll
     for (int gs = 0; gs < GS; ++gs) {
@@ -247,6 +270,7 @@ __global__ __launch_bounds__(256, MINW) void gemv_rows_mfma_pipe_kernel(GemvRows
             }
         }
     }
+    EVC_K5_WG(2);
 }
 
 // Two geometry sets on EIGHT waves: waves 0-3 take geometries [g0, g0+16), waves 4-7 [g0+16, g0+32) of the same
@@ -283,8 +307,8 @@ __global__ __launch_bounds__(512, 2) void gemv_rows_mfma_split_kernel(GemvRowsLa
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t row_base = (int64_t)(rg * tpg + min(rg, trem)) * 16;
     const int ntile = tpg + (rg < trem ? 1 : 0);
-    const int64_t cbeg = (int64_t)span * P.cps * 512;
-    const int64_t cend = min(P.cols, (int64_t)(span + 1) * P.cps * 512);
+    const int64_t cbeg = (int64_t)span * P.span_cols;
+    const int64_t cend = min(P.cols, (int64_t)(span + 1) * P.span_cols);
     const int gs0 = g0 + 16 * set, Gs = min(16, G - 16 * set);   // this wave's geometries (Gs <= 0: idle set)
     const double *__restrict__ vr[1];
     vr[0] = P.v + (int64_t)(Gs > 0 ? gs0 + (l15 < Gs ? l15 : 0) : g0) * P.vstride;
@@ -643,3 +667,9 @@ int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
 }
 
 }  // namespace evc
+
+#ifdef EVC_DEBUG_STAMPS
+extern "C" int evc_debug_read_k5(long long *stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(evc::g_k5_wg), sizeof(long long) * 1024 * 4);
+}
+#endif

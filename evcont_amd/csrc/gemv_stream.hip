@@ -47,7 +47,7 @@ __device__ __forceinline__ double multi_reduce(double (&v)[N], int lane) {
 
 // ------------------------------------------------------------------ rows GEMV
 // Workgroup = 256 lanes x 16 B = one 512-column chunk of RB rows per step; a block owns a span of
-// `cps` chunks, keeps v[g] for the chunk in registers and RB*G accumulators per lane.
+// `span_cols` columns, keeps v[g] for the chunk in registers and RB*G accumulators per lane.
 // Partials go to ws[g][span][row]; the consumer sums the spans in fixed order (deterministic).
 template <int RB, int G>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvRowsLaunch L, int g0) {
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvRowsLaunch L, int g0
     const int nrows = (int)min((int64_t)RB, P.rows - row0);
     const int tid = threadIdx.x;
 
-    int64_t c = ((int64_t)span * P.cps) * kChunk + tid * 2;
-    const int64_t cend = min(P.cols, ((int64_t)(span + 1) * P.cps) * kChunk);
+    int64_t c = (int64_t)span * P.span_cols + tid * 2;
+    const int64_t cend = min(P.cols, (int64_t)(span + 1) * P.span_cols);
     const int64_t ld = P.ld;
     const double *__restrict__ v = P.v + (int64_t)g0 * P.vstride;
     const int64_t vs = P.vstride;
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256, 3) void gemv_rows_wr_kernel(GemvRowsLaunch L, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t rows = P.rows, cols = P.cols, ld = P.ld;
     const int64_t row0 = (int64_t)rg * (4 * RBW) + wave * RBW;
-    const int64_t cbeg = (int64_t)span * P.cps * kChunk;
-    const int64_t cend = min(cols, (int64_t)(span + 1) * P.cps * kChunk);
+    const int64_t cbeg = (int64_t)span * P.span_cols;
+    const int64_t cend = min(cols, (int64_t)(span + 1) * P.span_cols);
     const double *__restrict__ v = P.v + (int64_t)g0 * P.vstride;
     const double *__restrict__ Ar[RBW];
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 3) void gemv_rows_wr_kernel(GemvRowsLaunch L, 
 
     for (int64_t c0 = cbeg; c0 < cend; c0 += TILE) {
         double2 a[SUB][RBW];
-        const bool full = c0 + TILE <= cols;
+        const bool full = c0 + TILE <= cend;   // (a span need not be a whole number of tiles)
         if (full) {
 #pragma unroll
             for (int u = 0; u < SUB; ++u)
@@ -171,10 +171,10 @@ __global__ __launch_bounds__(256, 3) void gemv_rows_wr_kernel(GemvRowsLaunch L, 
                 const int64_t c = c0 + u * kStep + lane * 2;
 #pragma unroll
                 for (int r = 0; r < RBW; ++r)
-                    a[u][r] = (c + 1 < cols) ? ld_stream(Ar[r] + c) : make_double2(c < cols ? Ar[r][c] : 0.0, 0.0);
+                    a[u][r] = (c + 1 < cend) ? ld_stream(Ar[r] + c) : make_double2(c < cend ? Ar[r][c] : 0.0, 0.0);
             }
 #pragma unroll
-            for (int k = 0; k < VPT; ++k) vt[sg][sc + k] = (c0 + sc + k < cols) ? vsrc[c0 + sc + k] : 0.0;
+            for (int k = 0; k < VPT; ++k) vt[sg][sc + k] = (c0 + sc + k < cend) ? vsrc[c0 + sc + k] : 0.0;
         }
         __syncthreads();  // v tile staged
 #pragma unroll
@@ -230,8 +230,21 @@ void plan_rows(RowProblem &P, bool batched) {
     int64_t cps = nchunks / want_spans;
     if (cps < min_cps) cps = nchunks < min_cps ? nchunks : min_cps;
     if (cps < 1) cps = 1;
-    P.cps = (int)cps;
-    P.nspans = (int)ceil_div(nchunks, cps);
+    P.span_cols = cps * kChunk;
+    // EVC_ROWS_NARROW_WGS=W (experiment, off by default): cut the spans of a narrow matrix (the compressed layout, one
+    // 7-tile row group per workgroup and CU) in 32-column chunks so that about W workgroups result.  Measured on the
+    // 210 x 108345 matrix (tools/micro/k5_stamps.py): the main loops of 216 workgroups x 8 chunks per wave and of
+    // 252 x 7 both take 48-52 us -- the stream, not the share of a wave, sets the time -- and more than ~248 workgroups
+    // (the small second problem's blocks included) start a second round on the 256 CUs: 57 -> 81 us.
+    static const int narrow_wgs = env_int("EVC_ROWS_NARROW_WGS", 0);
+    if (batched && narrow_wgs > 0 && P.cols <= 200000) {
+        const int64_t nrg = ceil_div(ceil_div(P.rows, 16), 7);
+        const int64_t spans = narrow_wgs / nrg > 0 ? narrow_wgs / nrg : 1;
+        int64_t span32 = ceil_div(ceil_div(P.cols, 32), spans);
+        if (span32 < 16) span32 = 16;   // at least four chunks per wave
+        if (span32 * 32 < P.span_cols) P.span_cols = span32 * 32;
+    }
+    P.nspans = (int)ceil_div(P.cols, P.span_cols);
     P.nblocks = (int)(nrb * P.nspans);
 }
 
@@ -243,7 +256,7 @@ size_t rows_ws_doubles(int64_t rows, int64_t cols) {
     return (size_t)rows * P.nspans;
 }
 
-// The span decomposition (cps, nspans -> layout of the partials) is fixed by plan_rows; the row-block
+// The span decomposition (span_cols, nspans -> layout of the partials) is fixed by plan_rows; the row-block
 // height RB is a property of the kernel variant only: nblocks = ceil(rows/RB) * nspans.
 template <int RB, int G>
 static void rows_launch(GemvRowsLaunch L, int g0, hipStream_t st) {

@@ -17,7 +17,8 @@ struct RowProblem {
     const double *v;   // (cols)            + g*vstride
     double *partial;   // (nspans, rows)    + g*pstride
     int64_t rows, cols, ld, vstride, pstride;
-    int nspans, cps, nblocks;
+    int nspans, nblocks;
+    int64_t span_cols;  // columns per span (a multiple of 32; the last span may be shorter): span s = [s, s+1) * span_cols
 };
 struct GemvRowsLaunch {
     RowProblem p[2];

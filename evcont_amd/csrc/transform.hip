@@ -679,7 +679,11 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
                 for (int m = 0; m < NT * NT; ++m) {
                     if constexpr (COMPUTE) {
                         const int rt = m / NT, st = m % NT;
+                        // (equal priorities let a wave that issues MFMAs back to back keep the issue port: the SIMD mate's
+                        // loads, stores and LDS operations go first, tools/micro/mfma_coissue.hip)
+                        __builtin_amdgcn_s_setprio(0);
                         h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
+                        __builtin_amdgcn_s_setprio(1);
                     }
                     const int f = kk * SPG + m;   // the stage write that follows this MFMA
                     if (m < SPG && f < NRES) {
@@ -752,7 +756,9 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
                 for (int m = 0; m < NM; ++m) {
                     if constexpr (COMPUTE) {
                         const int it = m == 0 ? 0 : 1, st = m == 2 ? 1 : 0;
+                        __builtin_amdgcn_s_setprio(0);
                         nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
+                        __builtin_amdgcn_s_setprio(1);
                     }
                     if (COMPUTE && m == 0) {
                         // the operand row of matrix i+1 (fetched one iteration ago) -> the wave's LDS row -> fragments;

@@ -7,6 +7,38 @@
 #include <stdlib.h>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+// MIX 6 / 7: a streaming read (16-byte loads, 8 per iteration and lane, scalar base + constant lane offset: no vector
+// instruction per load) with 16 loads in flight per lane; 7 also waits for everything once per iteration
+template <int MIX>
+__device__ __forceinline__ void stream_work(int iters, double *sink, const char *buf) {
+    const char *vb = buf + ((size_t)(blockIdx.x * 4 + (threadIdx.x >> 6) - 4) * iters) * 8192;
+    const unsigned long long ub = (unsigned long long)vb;
+    unsigned long long sb = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub);
+    const unsigned voff = (threadIdx.x & 63) * 16;
+    f4 r0, r1, r2, r3, r4, r5, r6, r7;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("global_load_dwordx4 %0, %8, %9\n\t"
+                     "global_load_dwordx4 %1, %8, %9 offset:1024\n\t"
+                     "global_load_dwordx4 %2, %8, %9 offset:2048\n\t"
+                     "global_load_dwordx4 %3, %8, %9 offset:3072\n\t"
+                     "s_waitcnt vmcnt(12)\n\t"
+                     "global_load_dwordx4 %4, %8, %10\n\t"
+                     "global_load_dwordx4 %5, %8, %10 offset:1024\n\t"
+                     "global_load_dwordx4 %6, %8, %10 offset:2048\n\t"
+                     "global_load_dwordx4 %7, %8, %10 offset:3072\n\t"
+                     "s_waitcnt vmcnt(12)"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                     : "v"(voff), "s"(sb), "s"(sb + 4096)
+                     : "memory");
+        if (MIX == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sb += 8192;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sink[blockIdx.x * 512 + threadIdx.x] = r0[0] + r1[0] + r2[0] + r3[0] + r4[0] + r5[0] + r6[0] + r7[0];
+}
+
 template <int MIX>   // 0 int VALU, 1 f32 FMA, 2 f64 FMA, 3 LDS read, 4 v_mov, 5 SALU
 __device__ __forceinline__ void other_work(int iters, double *sink, double *lds) {
     unsigned x = threadIdx.x, y = 12345u;
@@ -29,7 +61,8 @@ __device__ __forceinline__ void other_work(int iters, double *sink, double *lds)
 }
 
 template <int MIX>
-__global__ __launch_bounds__(512) void k(double *out, long long *clk, int mf_iters, int ot_iters, double a0) {
+__global__ __launch_bounds__(512) void k(double *out, long long *clk, int mf_iters, int ot_iters, double a0,
+                                         const char *buf, int prio) {
     __shared__ double lds[2048];
     for (int i = threadIdx.x; i < 2048; i += 512) lds[i] = i;
     __syncthreads();
@@ -46,24 +79,31 @@ __global__ __launch_bounds__(512) void k(double *out, long long *clk, int mf_ite
         }
         out[blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
     } else {
-        other_work<MIX>(ot_iters, out, lds);
+        if (prio) __builtin_amdgcn_s_setprio(3);
+        if constexpr (MIX >= 6) stream_work<MIX>(ot_iters, out, buf);
+        else other_work<MIX>(ot_iters, out, lds);
     }
     const long long t1 = wall_clock64();
     if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
 template <int MIX>
-static void run(const char *name, int ot_iters) {
+static void run(const char *name, int ot_iters, int prio = 0) {
     const int blocks = 256, mf_iters = 2000;   // 8000 MFMAs per wave = 512K cycles
     double *out;
     long long *clk, h[256 * 8];
+    static char *buf = nullptr;
+    if (!buf) {
+        (void)hipMalloc(&buf, (size_t)1024 * 300 * 8192 + 8192);   // 2.5 GB: every streaming wave reads its own range
+        (void)hipMemset(buf, 0, (size_t)1024 * 300 * 8192 + 8192);
+    }
     (void)hipMalloc(&out, sizeof(double) * blocks * 512);
     (void)hipMalloc(&clk, sizeof(long long) * blocks * 8);
     double res[3][2];
     for (int cfg = 0; cfg < 3; ++cfg) {   // 0: MFMA alone, 1: mix alone, 2: together
         const int mi = cfg == 1 ? 0 : mf_iters, oi = cfg == 0 ? 0 : ot_iters;
         for (int rep = 0; rep < 2; ++rep) {
-            hipLaunchKernelGGL(k<MIX>, dim3(blocks), dim3(512), 0, 0, out, clk, mi, oi, 1.0);
+            hipLaunchKernelGGL(k<MIX>, dim3(blocks), dim3(512), 0, 0, out, clk, mi, oi, 1.0, buf, prio);
             (void)hipDeviceSynchronize();
         }
         (void)hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
@@ -86,5 +126,12 @@ int main() {
     run<3>("LDS read", 300);
     run<4>("v_mov", 1000);
     run<5>("SALU", 1000);
+    run<6>("stream 16", 300);   // 300 x 8 KB per wave: 2.5 GB in all
+    run<7>("stream 8", 300);
+    // the same with s_setprio 3 in the second wave of every SIMD
+    run<0>("int VALU p3", 500, 1);
+    run<2>("f64 FMA p3", 500, 1);
+    run<5>("SALU p3", 1000, 1);
+    run<6>("stream16 p3", 300, 1);
     return 0;
 }

@@ -1,0 +1,102 @@
+// What HBM bandwidth do the two ways of reading a (rows x cols) row-major matrix reach on gfx950?
+//   A: the MFMA-fragment pattern of the rows GEMM (K5): a load instruction takes 16 rows x 64 bytes (lane l15 = row,
+//      l4 = 16-byte piece), four of them per 16-row tile and 32-column chunk, 7 tiles per wave and chunk;
+//   B: whole-row pieces: a load instruction takes 1 KiB of ONE row (64 lanes x 16 bytes), 28 rows per wave and step;
+// same matrix (210 x 108345 doubles by default), same bytes per workgroup step (112 rows x 1 KiB), same grid, the
+// values are folded with integer XORs (no FP, no MFMA): pure streaming.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+template <int PATTERN>
+__global__ __launch_bounds__(256) void k(const double *A, int64_t rows, int64_t cols, int64_t ld, int steps_per_wg,
+                                         unsigned *out) {
+    extern __shared__ double occupancy_pad[];   // dynamic LDS: limits the workgroups per CU (argv[4] KB)
+    if (steps_per_wg < 0) occupancy_pad[threadIdx.x] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nrg = (int)((rows + 111) / 112);
+    const int rg = blockIdx.x % nrg, span = blockIdx.x / nrg;
+    const int64_t rb = (int64_t)rg * 112;
+    u4 acc = {0, 0, 0, 0};
+    for (int s = 0; s < steps_per_wg; ++s) {
+        const int64_t c0 = ((int64_t)span * steps_per_wg + s) * 128;   // 128 columns per workgroup step
+        if (c0 + 128 > cols) break;
+        if (PATTERN == 0) {
+            const int64_t c = c0 + wave * 32 + 2 * l4;
+#pragma unroll
+            for (int tt = 0; tt < 7; ++tt) {
+                const int64_t r = rb + 16 * tt + l15;
+                const double *p = A + (r < rows ? r : rows - 1) * ld + c;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    u4 v;
+                    const double *q = p + 8 * u;
+                    if ((reinterpret_cast<uintptr_t>(q) & 15) == 0) v = *reinterpret_cast<const u4 *>(q);
+                    else { const uint2 a = *reinterpret_cast<const uint2 *>(q), b = *reinterpret_cast<const uint2 *>(q + 1); v = (u4){a.x, a.y, b.x, b.y}; }
+                    acc ^= v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 28; ++t) {
+                const int64_t r = rb + wave * 28 + t;
+                const double *q = A + (r < rows ? r : rows - 1) * ld + c0 + 2 * lane;
+                u4 v;
+                if ((reinterpret_cast<uintptr_t>(q) & 15) == 0) v = *reinterpret_cast<const u4 *>(q);
+                else { const uint2 a = *reinterpret_cast<const uint2 *>(q), b = *reinterpret_cast<const uint2 *>(q + 1); v = (u4){a.x, a.y, b.x, b.y}; }
+                acc ^= v;
+            }
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+}
+
+int main(int argc, char **argv) {
+    const int64_t rows = argc > 1 ? atoll(argv[1]) : 210, cols = argc > 2 ? atoll(argv[2]) : 108345;
+    const int64_t ld = argc > 3 ? atoll(argv[3]) : cols;
+    const int lds_kb = argc > 4 ? atoi(argv[4]) : 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    double *A;
+    unsigned *out;
+    (void)hipMalloc(&A, sizeof(double) * rows * ld + 4096);
+    (void)hipMemset(A, 1, sizeof(double) * rows * ld + 4096);
+    if (argc > 5 && atoi(argv[5])) {   // random contents instead of a constant byte
+        const size_t nw = (size_t)rows * ld * 2;
+        unsigned *h = (unsigned *)malloc(nw * 4);
+        unsigned long long x = 88172645463325252ull;
+        for (size_t i = 0; i < nw; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[i] = (unsigned)x; }
+        (void)hipMemcpy(A, h, nw * 4, hipMemcpyHostToDevice);
+        free(h);
+        printf("random contents\n");
+    }
+    const int nrg = (int)((rows + 111) / 112);
+    const int64_t nsteps = cols / 128;
+    printf("dynamic LDS %d KB per workgroup\n", lds_kb);
+    for (int spw = 1; spw <= 16; spw *= 2) {
+        const int spans = (int)((nsteps + spw - 1) / spw);
+        const int blocks = spans * nrg;
+        (void)hipMalloc(&out, sizeof(unsigned) * blocks * 256);
+        for (int pat = 0; pat < 2; ++pat) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                (void)hipEventRecord(e0);
+                if (pat == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), lds_kb * 1024, 0, A, rows, cols, ld, spw, out);
+                else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), lds_kb * 1024, 0, A, rows, cols, ld, spw, out);
+                (void)hipEventRecord(e1);
+                (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                if (rep >= 2 && ms < best) best = ms;
+            }
+            const double bytes = (double)rows * (double)(nsteps * 128) * 8.0;
+            printf("ld=%lld steps/wg=%d blocks=%5d pattern %c: %.1f us  %.2f TB/s\n", (long long)ld, spw, blocks, pat ? 'B' : 'A',
+                   best * 1e3, bytes / (best * 1e-3) / 1e12);
+        }
+        (void)hipFree(out);
+    }
+    return 0;
+}
