@@ -436,7 +436,7 @@ def main():
                 pairs = n * (n + 1) // 2 if a.layout == "sym8" else n * n
                 flops = G * pairs * 4.0 * n ** 3          # two N x N x N products per leading pair, unpadded
                 tf = flops / (st["pair_transform_ms"] * 1e-3) / 1e12
-                others.append({"kernel": "pt_kernel: one fused pair step of a four-index rotation (4 launches per "
+                others.append({"kernel": "pt_pipe_kernel: one fused pair step of a four-index rotation (4 launches per "
                                          "evaluation, the largest share of the step)", "bound": "mfma",
                                "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / MFMA_F64_PEAK_TFLOPS, "flops_per_launch": flops,
