@@ -225,7 +225,10 @@ def test_sym8_through_the_reference_api(h10_fci, tmp_path):
         aec.set_trdm_compression("sym4")
 
 
-@pytest.mark.parametrize("n,T,A", [(5, 3, 2), (7, 3, 3), (10, 5, 10), (18, 4, 3), (30, 3, 5), (32, 2, 4)])
+# (sizes around the shapes of the pair-transform kernels: fewer pairs than one 8-pair tile (n = 2, 3), the 16/17 and 30/31
+# boundaries -- the software-pipelined kernel takes n <= 30, n = 31, 32 the phase-alternating one --, odd and even n(n+1)/2)
+@pytest.mark.parametrize("n,T,A", [(2, 2, 1), (3, 2, 2), (5, 3, 2), (7, 3, 3), (10, 5, 10), (16, 3, 2), (17, 3, 2),
+                                   (18, 4, 3), (29, 2, 3), (30, 3, 5), (31, 2, 3), (32, 2, 4)])
 def test_packed_ip1_input(n, T, A):
     """EVC_FLAG_IP1_S2KL: int2e_ip1 handed over packed in its last two AO indices (PySCF aosym="s2kl"), host-packed
     and device-gathered, single and batched, against the oracle on the full arrays and the original t-RDMs."""
