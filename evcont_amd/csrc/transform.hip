@@ -509,7 +509,6 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 // MODE 1: the 8-fold compressed packed vector (+ K3 when asked for).
 template <int NPAD, int MODE>
 __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
-    constexpr int LDX = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;
     constexpr int KS = NPAD / 4;
     constexpr int NT = NPAD / 16;
     constexpr int NPASS_MAX = (NPAD * (NPAD + 1) / 2 + 31) / 32;   // write-out passes of a tile (32 result rows each)
@@ -538,9 +537,7 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     // the stage: result row u = tri(r',s') of buffer b (tile parity), slot s (pair of the tile) at
     //   u * 16 + b * 8 + (s ^ f(u)),  f(u) = (u >> 1) & 7
     // (16 consecutive rows of one slot fall on 16 different bank pairs; f(u + 32) = f(u))
-    double *stage = sm + 4 * kPtRowLen;
-    double *Xs = stage + npairs * 8;        // X is staged in the upper half (one extra barrier before the main loop);
-                                            // (behind the npairs rows: one dump row of 16 doubles)
+    double *stage = sm + 4 * kPtRowLen;     // (behind the npairs rows: one dump row of 16 doubles)
     char *__restrict__ outb = nullptr;
     if constexpr (MODE == 0) outb = reinterpret_cast<char *>(a.out + g * a.sout);
     else outb = reinterpret_cast<char *>(a.packed + g * a.spacked);
@@ -610,12 +607,19 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
 
     const int e0 = 8 * t_begin + wave;   // this wave's leading pair of iteration i: e0 + 4 i
     int d_rd = fetch(e0);
-    for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += 256) {
-        const int d = idx / NPAD, c = idx % NPAD;
-        double v = 0.0;
-        if (d < n && c < n) v = a.ct ? C[c * n + d] : C[d * n + c];
-        Xs[d * LDX + c] = v;
-    }
+    // the X fragments straight from global memory (every wave its own copy: 16 rows of 128 bytes per load instruction,
+    // one latency together with the first operand row; no LDS staging, no barrier)
+    double xf[KS][NT];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int d = 4 * kk + l4, c = t * 16 + l15;
+            const bool ok = d < n && c < n;
+            const double *src = C + (ok ? (a.ct ? c * n + d : d * n + c) : 0);
+            const double v = *src;
+            xf[kk][t] = ok ? v : 0.0;
+        }
     if constexpr (MODE == 1) {
         if (blockIdx.x == 0) {   // zero the padding [M, packed_len) once per geometry
             double *pk = a.packed + g * a.spacked;
@@ -623,13 +627,7 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
             for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
         }
     }
-    lds_barrier();
     EVC_PT_STAMP(1);
-    double xf[KS][NT];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) xf[kk][t] = Xs[(4 * kk + l4) * LDX + t * 16 + l15];
     double mf[NT][KS];
     park();
 #pragma unroll
@@ -637,7 +635,6 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = mrow[foff[rt][kk] + d_rd];
     int d_next = fetch(e0 + 4);
-    lds_barrier();   // every wave has its X fragments: the stage may overwrite X
     EVC_PT_STAMP(2);
 
     // write-out: 8 lanes cover the pair run of one result row; thread (wl, ur) takes rows u0 + 32 k
@@ -1036,9 +1033,8 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     static const bool pipe_on = !(getenv("EVC_PT_PIPE") && atoi(getenv("EVC_PT_PIPE")) == 0);
     if (pipe_on && a.lead_sym && a.in_lower && a.rs_lower && a.in_pairs && (npad == 16 || npad == 32)) {
         const int mode = (a.out && a.out_pairs && !a.packed && !a.k3) ? 0 : (a.packed && a.sym8 && !a.out) ? 1 : -1;
-        const size_t npairs = (size_t)n * (n + 1) / 2, xs = (size_t)npad * (npad == 32 ? 48 : 16);
-        const size_t lds =
-            sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 8 + (npairs * 8 + 16 > xs ? npairs * 8 + 16 : xs));
+        const size_t npairs = (size_t)n * (n + 1) / 2;
+        const size_t lds = sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 16 + 16);
         if (mode >= 0 && lds <= 80 * 1024) {
             const dim3 gridp((unsigned)(((npairs + 7) / 8 + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
 #define EVC_PT_PIPE_CASE(NP_, MODE_)                                                                            \
