@@ -498,8 +498,8 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 //   * N phase: the operand row of matrix i+1 goes from registers to the wave's LDS row and comes back as MFMA
 //     fragments (the registers of matrix i's fragments are free after its H phase), the global fetch of matrix i+2's
 //     row is issued, K3 is stored (MODE 1), half of the write-out passes of an EARLIER tile --
-// with a double-buffered stage (8 doubles per result row and buffer, the slot XOR-swizzled by the row so that the
-// accumulator layout writes it without bank conflicts) and ONE workgroup barrier per tile: barrier(j) sits after the H phase of
+// with a double-buffered stage (8 doubles per result row and buffer, the slot XOR-swizzled by the row against bank
+// conflicts of the accumulator layout) and ONE workgroup barrier per tile: barrier(j) sits after the H phase of
 // the first matrix of tile j+1 (which wrote the last results of tile j); tile j is then written out during the
 // following two N phases, before barrier(j+1), after which its buffer is written again.  The stores of the launch
 // are spread evenly over its duration.  (vmcnt counts loads and stores in order on gfx9: the wait for an operand row
@@ -511,7 +511,7 @@ template <int NPAD, int MODE>
 __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     constexpr int KS = NPAD / 4;
     constexpr int NT = NPAD / 16;
-    constexpr int NPASS_MAX = (NPAD * (NPAD + 1) / 2 + 31) / 32;   // write-out passes of a tile (32 result rows each)
+    constexpr int NPASS_MAX = (NPAD * (NPAD + 1) / 2 + 63) / 64;   // write-out passes of a tile (64 result rows each)
     constexpr int PH2 = (NPASS_MAX + 1) / 2;                       // ... per N phase
     constexpr int NRES = NT * (NT + 1) / 2 * 4;                    // result registers (doubles) of a matrix per lane
     constexpr int SPG = (NRES + KS - 1) / KS;                      // stage writes per MFMA group
@@ -535,8 +535,10 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     const int l15 = lane & 15, l4 = lane >> 4;
     double *mrow = sm + wave * kPtRowLen;   // the wave's operand row
     // the stage: result row u = tri(r',s') of buffer b (tile parity), slot s (pair of the tile) at
-    //   u * 16 + b * 8 + (s ^ f(u)),  f(u) = (u >> 1) & 7
-    // (16 consecutive rows of one slot fall on 16 different bank pairs; f(u + 32) = f(u))
+    //   u * 16 + b * 8 + (s ^ f(u)),  f(u) = 2 ((u >> 1) & 3)
+    // (f is even: the slots 2t, 2t+1 of a row stay an aligned 16-byte pair, which the write-out reads with one
+    //  ds_read_b128; 16 consecutive rows of one slot fall on 8 bank pairs, a 2-way conflict on the 12 stage writes of
+    //  a matrix; f(u + 64) = f(u))
     double *stage = sm + 4 * kPtRowLen;     // (behind the npairs rows: one dump row of 16 doubles)
     char *__restrict__ outb = nullptr;
     if constexpr (MODE == 0) outb = reinterpret_cast<char *>(a.out + g * a.sout);
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
             for (int reg = 0; reg < 4; ++reg) {
                 const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
                 const int u = r2 * (r2 + 1) / 2 + s2;
-                sa[it][st][reg] = (r2 < n && s2 <= r2) ? u * 16 + (wave ^ ((u >> 1) & 7)) : npairs * 16 + wave;
+                sa[it][st][reg] = (r2 < n && s2 <= r2) ? u * 16 + (wave ^ (((u >> 1) & 3) << 1)) : npairs * 16 + wave;
             }
     [[maybe_unused]] const int dq = l15 - l4;   // result register reg of a diagonal tile is r' == s'  <=>  dq == 4 reg
     // K3 (MODE 1): bit (rt * NT + st) * 4 + reg: the lane holds an element of H with r < n, s' < n
@@ -637,9 +639,10 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     int d_next = fetch(e0 + 4);
     EVC_PT_STAMP(2);
 
-    // write-out: 8 lanes cover the pair run of one result row; thread (wl, ur) takes rows u0 + 32 k
-    const int wl = threadIdx.x & 7, ur = threadIdx.x >> 3;
-    [[maybe_unused]] const unsigned stride_b = 32u * (unsigned)npairs * 8u;   // MODE 0: bytes between two passes
+    // write-out: 4 lanes cover the pair run of one result row, two pairs (16 bytes) each; thread (wl, ur) takes the
+    // columns wl, wl + 1 (wl even) of rows u0 + 64 k
+    const int wl = 2 * (threadIdx.x & 3), ur = threadIdx.x >> 2;
+    [[maybe_unused]] const unsigned stride_b = 64u * (unsigned)npairs * 8u;   // MODE 0: bytes between two passes
     [[maybe_unused]] const int64_t krow_b = (int64_t)npairs * n * 8;          // MODE 1: bytes between two K3 rows s'
     [[maybe_unused]] const unsigned k3lane = (unsigned)((l15 * npairs * n + l4) * 8);
 
@@ -709,24 +712,29 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
             const int jn = ODD ? (i - 3) / 2 : (i - 2) / 2;
             constexpr int kn = ODD ? PH2 : 0;
             const bool dn = (ODD ? i >= 3 : i >= 2) && 2 * jn < niter;
-            // per tile and thread: LDS index of pass 0, byte offset of its store, rows left, factor
-            const int ew = 8 * (t_begin + jn) + wl;            // the pair (column) this thread writes
+            // per tile and thread: LDS index of pass 0, byte offset of its store, rows left, the factors of its two columns
+            const int ew = 8 * (t_begin + jn) + wl;            // the first pair (column) this thread writes
             const int u0 = (MODE == 0 ? 0 : ew) + ur;          // MODE 1: rows u >= v = ew only
-            const int rem = (dn && ew < npairs) ? npairs - u0 : 0;   // pass k is valid  <=>  32 k < rem
-            const double *dsrc = stage + (u0 * 16 + ((jn & 1) << 3) + (wl ^ ((u0 >> 1) & 7)));
-            double fac = 1.0;
-            [[maybe_unused]] double fac0 = 1.0;
+            const int rem = (dn && ew < npairs) ? npairs - u0 : 0;   // pass k is valid  <=>  64 k < rem
+            const bool two = ew + 1 < npairs;                  // (the last pair of an odd count stands alone)
+            const d2 *dsrc = reinterpret_cast<const d2 *>(stage + (u0 * 16 + ((jn & 1) << 3) + (wl ^ (((u0 >> 1) & 3) << 1))));
+            d2 fac = {1.0, 1.0};
+            [[maybe_unused]] d2 fac0 = {1.0, 1.0};
             unsigned off0 = 0;
             [[maybe_unused]] unsigned offA = 0;
             if (dn) {
                 if constexpr (MODE == 0) {
-                    fac = (weigh && !is_diag(ew)) ? 2.0 : 1.0;
+                    fac[0] = (weigh && !is_diag(ew)) ? 2.0 : 1.0;
+                    fac[1] = (weigh && !is_diag(ew + 1)) ? 2.0 : 1.0;
                     off0 = (unsigned)(u0 * npairs + ew) * 8u;
                 } else {
-                    fac = is_diag(ew) ? 2.0 : 4.0;                 // multiplicity of (p,q) x 2 (see the stage writes)
-                    fac0 = ur == 0 ? fac * a.diag_mult : fac;      // pass 0 of the thread with u == v
+                    fac[0] = is_diag(ew) ? 2.0 : 4.0;              // multiplicity of (p,q) x 2 (see the stage writes)
+                    fac[1] = is_diag(ew + 1) ? 2.0 : 4.0;
+                    // pass 0: the thread with u == v takes diag_mult; row u = ew has no column ew + 1 (u < v)
+                    fac0[0] = ur == 0 ? fac[0] * a.diag_mult : fac[0];
+                    fac0[1] = ur == 1 ? fac[1] * a.diag_mult : fac[1];
                     off0 = (unsigned)(u0 * (u0 + 1) / 2 + ew) * 8u;
-                    offA = (unsigned)(32 * u0) * 8u;               // tri(u0 + 32 k) = tri(u0) + k (32 u0) + 512 k^2 + 16 k
+                    offA = (unsigned)(64 * u0) * 8u;               // tri(u0 + 64 k) = tri(u0) + k (64 u0) + 2048 k^2 + 32 k
                 }
             }
             [[maybe_unused]] char *K3b = nullptr;
@@ -742,11 +750,11 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
             constexpr int NM = NT * (NT + 1) / 2;   // MFMAs of a group: tiles (0,0), (1,0), (1,1)
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                double dv[PPG];
+                d2 dv[PPG];
 #pragma unroll
                 for (int c = 0; c < PPG; ++c) {
                     const int k = kk * PPG + c;   // pass kn + k
-                    dv[c] = (k < PH2 && 32 * (kn + k) < rem) ? dsrc[512 * (kn + k)] : 0.0;
+                    dv[c] = (k < PH2 && 64 * (kn + k) < rem) ? dsrc[512 * (kn + k)] : (d2){0.0, 0.0};
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -792,14 +800,21 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
 #pragma unroll
                         for (int c = 0; c < PPG; ++c) {
                             const int k = kk * PPG + c;
-                            if (k < PH2 && 32 * (kn + k) < rem) {
+                            if (k < PH2 && 64 * (kn + k) < rem) {
+                                const unsigned kq = (unsigned)(kn + k);
+                                unsigned off;
+                                d2 v;
+                                bool second = two;
                                 if constexpr (MODE == 0) {
-                                    *reinterpret_cast<double *>(outb + (off0 + (unsigned)(kn + k) * stride_b)) = dv[c] * fac;
+                                    off = off0 + kq * stride_b;
+                                    v = dv[c] * fac;
                                 } else {
-                                    const unsigned kq = (unsigned)(kn + k);
-                                    const unsigned off = off0 + kq * offA + (512u * kq * kq + 16u * kq) * 8u;
-                                    *reinterpret_cast<double *>(outb + off) = dv[c] * ((kn + k) == 0 ? fac0 : fac);
+                                    off = off0 + kq * offA + (2048u * kq * kq + 32u * kq) * 8u;
+                                    v = dv[c] * (kq == 0 ? fac0 : fac);
+                                    if (kq == 0) second = two && ur >= 1;   // row u = ew: column ew + 1 is above the diagonal
                                 }
+                                if (second) *reinterpret_cast<d2 *>(outb + off) = v;
+                                else *reinterpret_cast<double *>(outb + off) = v[0];
                             }
                         }
                     }
