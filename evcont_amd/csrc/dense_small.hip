@@ -19,8 +19,45 @@ constexpr int kThreads = 256;
 
 // ------------------------------------------------------------------ small LDS matmul
 // C[i][j] = sum_k a(i,k) * b(k,j),  i,j < n;  thread (tj,tk) owns i = tj+16*, j = tk+16*.
+typedef double d4s __attribute__((ext_vector_type(4)));
+// Small products on the FP64 matrix cores (n <= 32): wave w of the workgroup owns the 16 x 16 output tile
+// (w >> 1, w & 1); operand maps of v_mfma_f64_16x16x4_f64: A[i][k]: lane l holds i = l & 15, k = l >> 4; B[k][j]:
+// k = l >> 4, j = l & 15; D[i][j]: j = l & 15, i = (l >> 4) + 4 reg.  One eighth of the LDS traffic of the 2 x 2
+// register-blocked vector version (which was LDS-bandwidth bound: ~1 us per 32^3 product against ~0.3 us).
+// EVC_SMALL_MM_VALU (build flag): the vector version everywhere.
+#ifndef EVC_SMALL_MM_VALU
+#define EVC_SMALL_MM_MFMA 1
+#endif
+
+// C[i][j] = sum_k a(i,k) b(k,j), i, j, k < n; operands through accessors, result through store(i, j, value).
 template <typename FA, typename FB, typename FC>
 __device__ __forceinline__ void mm16(int n, FA a, FB b, FC store) {
+#ifdef EVC_SMALL_MM_MFMA
+    if (n <= 32) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+        const int ti = wave >> 1, tj = wave & 1;
+        if (16 * ti < n && 16 * tj < n) {   // wave-uniform
+            const int i = 16 * ti + l15, j = 16 * tj + l15;
+            const int ic = i < n ? i : 0, jc = j < n ? j : 0;   // (rows / columns beyond n: computed on row 0, never stored)
+            d4s acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (4 * kk < n) {
+                    const int k = 4 * kk + l4;
+                    const bool kv = k < n;
+                    const int kc = kv ? k : 0;
+                    const double av = a(ic, kc), bv = b(kc, jc);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kv ? av : 0.0, kv ? bv : 0.0, acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ii = 16 * ti + l4 + 4 * r;
+                if (ii < n && j < n) store(ii, j, acc[r]);
+            }
+        }
+        return;
+    }
+#endif
     const int tk = threadIdx.x & 15, tj = threadIdx.x >> 4;
     for (int i0 = 0; i0 < n; i0 += 32)
         for (int j0 = 0; j0 < n; j0 += 32) {
@@ -408,6 +445,20 @@ __device__ __forceinline__ double block_max_nan(double v, double *red) {
     __syncthreads();
     return t;
 }
+// two maxima with one pair of barriers (red: 8 doubles)
+__device__ __forceinline__ void block_max_nan2(double &a, double &b, double *red) {
+    a = wave_max_nan(a);
+    b = wave_max_nan(b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave] = a;
+        red[4 + wave] = b;
+    }
+    __syncthreads();
+    a = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
+    b = nanmax(nanmax(red[4], red[5]), nanmax(red[6], red[7]));
+    __syncthreads();
+}
 
 // ------------------------------------------------------------------ FP32 tridiagonal eigensolver on ONE wave
 // Start vectors for the refinement below, as LAPACK's xSYEVX would compute them, in single precision: Householder
@@ -643,6 +694,28 @@ constexpr int kRsz = 32 * kRp;   // doubles per matrix
 
 template <typename Store>
 __device__ __forceinline__ void mm_rowrow(int m, const double *__restrict__ P, const double *__restrict__ Q, Store store) {
+#ifdef EVC_SMALL_MM_MFMA
+    // (both fragments are "row l & 15, columns 4 kk + (l >> 4)" reads of a pitch-kRp matrix)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int ti = wave >> 1, tj = wave & 1;
+    if (16 * ti >= m || 16 * tj >= m) return;   // wave-uniform
+    const int i = 16 * ti + l15, j = 16 * tj + l15;
+    const double *pr = P + (i < m ? i : 0) * kRp, *qr = Q + (j < m ? j : 0) * kRp;
+    d4s acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+        if (4 * kk < m) {
+            const int k = 4 * kk + l4;
+            const bool kv = k < m;
+            const double av = pr[kv ? k : 0], bv = qr[kv ? k : 0];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kv ? av : 0.0, kv ? bv : 0.0, acc, 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ii = 16 * ti + l4 + 4 * r;
+        if (ii < m && j < m) store(ii, j, acc[r]);
+    }
+#else
     const int tk = threadIdx.x & 15, tj = threadIdx.x >> 4;
     const int ia = tj, ib = tj + 16, ja = tk, jb = tk + 16;
     const double *pa = P + (ia < m ? ia : 0) * kRp, *pb = P + (ib < m ? ib : 0) * kRp;
@@ -662,6 +735,7 @@ __device__ __forceinline__ void mm_rowrow(int m, const double *__restrict__ P, c
     if (ia < m && jb < m) store(ia, jb, c01);
     if (ib < m && ja < m) store(ib, ja, c10);
     if (ib < m && jb < m) store(ib, jb, c11);
+#endif
 }
 
 // Ogita-Aishima refinement of approximate eigenvectors of the symmetric matrix Ap (pitch kRp).  On entry Z holds the
@@ -676,9 +750,41 @@ __device__ __forceinline__ bool oa_refine(int m, int nreal, const double *Ap, do
     double prev = 1.0e300;
     for (int pass = 0; pass < max_pass; ++pass) {
         // Wt = Zt A  (A symmetric: Wt[j][i] = sum_k Zt[j][k] A[i][k])
+        if (pass == 0) EVC_STAMP(14);
         mm_rowrow(m, Zt, Ap, [&](int j, int i, double v) { B1[j * kRp + i] = v; });
         __syncthreads();
+        if (pass == 0) EVC_STAMP(15);
         // S = Z^T W -> B2,  R = I - Z^T Z -> B3, in one pass over the rows of Zt
+#ifdef EVC_SMALL_MM_MFMA
+        {
+            const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+            const int ti = wave >> 1, tj = wave & 1;
+            if (16 * ti < m && 16 * tj < m) {   // wave-uniform
+                const int i = 16 * ti + l15, j = 16 * tj + l15;
+                const double *pr = Zt + (i < m ? i : 0) * kRp;
+                const double *zr = Zt + (j < m ? j : 0) * kRp, *wr = B1 + (j < m ? j : 0) * kRp;
+                d4s sa = {0.0, 0.0, 0.0, 0.0}, ra = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    if (4 * kk < m) {
+                        const int k = 4 * kk + l4;
+                        const bool kv = k < m;
+                        const int kc = kv ? k : 0;
+                        const double av = kv ? pr[kc] : 0.0;
+                        sa = __builtin_amdgcn_mfma_f64_16x16x4f64(av, kv ? wr[kc] : 0.0, sa, 0, 0, 0);
+                        ra = __builtin_amdgcn_mfma_f64_16x16x4f64(av, kv ? zr[kc] : 0.0, ra, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ii = 16 * ti + l4 + 4 * r;
+                    if (ii < m && j < m) {
+                        B2[ii * kRp + j] = sa[r];
+                        B3[ii * kRp + j] = (ii == j ? 1.0 : 0.0) - ra[r];
+                    }
+                }
+            }
+        }
+#else
         {
             const int tk = tid & 15, tj = tid >> 4;
             const int ia = tj, ib = tj + 16, ja = tk, jb = tk + 16;
@@ -706,15 +812,23 @@ __device__ __forceinline__ bool oa_refine(int m, int nreal, const double *Ap, do
             if (ib < m && ja < m) { B2[ib * kRp + ja] = s10; B3[ib * kRp + ja] = -r10; }
             if (ib < m && jb < m) { B2[ib * kRp + jb] = s11; B3[ib * kRp + jb] = (ib == jb ? 1.0 : 0.0) - r11; }
         }
+#endif
         __syncthreads();
+        if (pass == 0) EVC_STAMP(16);
         const double *S = B2, *R = B3;
+        // (every wave evaluates the m Rayleigh quotients itself: its maximum needs no exchange, one barrier publishes lam)
         double lm = 0.0;
-        if (tid < m) {
-            lm = S[tid * kRp + tid] / (1.0 - R[tid * kRp + tid]);
-            lam[tid] = lm;
-            lm = fabs(lm);
+        {
+            const int ln = tid & 63;
+            if (ln < m) {
+                lm = S[ln * kRp + ln] / (1.0 - R[ln * kRp + ln]);
+                if (tid < m) lam[tid] = lm;
+                lm = fabs(lm);
+            }
         }
-        const double lmax = block_max_nan(lm, red);   // (its barriers also publish lam)
+        const double lmax = wave_max_nan(lm);
+        __syncthreads();
+        if (pass == 0) EVC_STAMP(17);
         // E^T -> B1 (Wt is consumed).  E = R/2 + a, a antisymmetric: a_ij = sh / (l_j - l_i) to first order with
         // sh = S_ij + (l_i + l_j)/2 R_ij; evaluated as the tangent of the Jacobi angle of the 2 x 2 problem
         // [[l_i, sh], [sh, l_j]], which is the same number for well separated pairs and stays bounded (|a| <= 1) for
@@ -759,10 +873,10 @@ __device__ __forceinline__ bool oa_refine(int m, int nreal, const double *Ap, do
                 emax = nanmax(emax, meas);
             }
         }
-        emax = block_max_nan(emax, red);
+        if (pass == 0) EVC_STAMP(18);
+        block_max_nan2(emax, rmax, red);
         EVC_STAMP(3 + pass);
         EVC_DBGVAL(pass, emax);
-        rmax = block_max_nan(rmax, red);
         // give up on NaNs, on vectors that are far from orthonormal (the first-order update cannot repair that) and
         // when the passes stop contracting; large ROTATIONS alone are fine: inside an eigenspace that is degenerate
         // to working precision they are arbitrary and harmless, elsewhere they proceed 0.3 rad per pass

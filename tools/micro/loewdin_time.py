@@ -25,6 +25,7 @@ def dbg(tag):
     fn = lib.evc_debug_read; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     fn(st, va, 64)
     t = [ (st[i] - st[0]) / 100.0 for i in range(14)]
+    print(tag, "pass 0: start %.1f, W done %.1f, S/R done %.1f, lam %.1f, elementwise %.1f, reduced %.1f" % tuple((st[i] - st[0]) / 100.0 for i in (14, 15, 16, 17, 18, 3)))
     print(tag, "kernel phases", [round((st[i]-st[30])/100.0,1) for i in range(30,37)]); print(tag, "stamps(us)", [round(x, 1) for x in t], "sweeps", va[20], "emax", [va[i] for i in range(4)], "delta", [va[8+i] for i in range(3)])
 print("loewdin n=%d: %.1f us" % (n, timeit(lambda: ops.loewdin(S, h))))
 dbg("loewdin")
