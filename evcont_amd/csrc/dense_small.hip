@@ -592,12 +592,11 @@ __device__ __forceinline__ void tridiag_eig_wg_f32(float *Af, int m, float *Zf, 
         int ca = qa < 0.0f ? 1 : 0, cb2 = qb < 0.0f ? 1 : 0;
 #pragma unroll
         for (int i = 1; i < 32; ++i) {
-            if (i < m) {   // uniform
-                qa = (dr[i] - xa) - e2[i - 1] * __builtin_amdgcn_rcpf(qa);
-                qb = (dr[i] - xb) - e2[i - 1] * __builtin_amdgcn_rcpf(qb);
-                ca += qa < 0.0f ? 1 : 0;
-                cb2 += qb < 0.0f ? 1 : 0;
-            }
+            if (i >= m) break;   // uniform: one test per step that is taken, none behind the end
+            qa = (dr[i] - xa) - e2[i - 1] * __builtin_amdgcn_rcpf(qa);
+            qb = (dr[i] - xb) - e2[i - 1] * __builtin_amdgcn_rcpf(qb);
+            ca += qa < 0.0f ? 1 : 0;
+            cb2 += qb < 0.0f ? 1 : 0;
         }
         int *cb = cntbuf + (it & 1) * 256;
         // eigenvalue j (ascending, 0-based) is >= x  <=>  count(x) <= j
