@@ -105,6 +105,14 @@ int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t 
 int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);
 // ... with SB only valid for i >= j, l <= k and K3[j][k][l][:] only for l <= k (symmetric pair-transform pipeline)
 // pairs: SB is the dense (pair, pair) matrix SB[tri(i,j)][tri(k,l)]
+// Y2 without K3 (symmetric pipeline): the half-transformed integrals are recomputed from the dense (pair, pair)
+// intermediate `M1` of the first pair step (kept by the energy phase) inside the contraction,
+//   Y2[i][a] = sum_v mult(v) sum_j SB[v][tri(i,j)] (M1_v X)[a][j];
+// writes y2_fused_slabs(n) partial (n, n) matrices per geometry (same layout as launch_y2_fold's)
+int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial,
+                    int64_t sws, int count, hipStream_t st);
+int y2_fused_slabs(int n);
+bool y2_fused_available(int n);
 int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, int pairs,
                    hipStream_t st);
 // partial[b][i][a] = sum_{k in slab b} GsT[k][i] * K3[k][a]   (k = jkl)

@@ -120,6 +120,11 @@ static int stage_chunk(int count) {
 static bool reduce_in_own_launch(const Ws &w) { return w.rp2.nspans > 48; }
 
 static bool is_sym8(int layout) { return layout == EVC_LAYOUT_SYM8; }
+// Y2 with the half-transformed integrals recomputed (transform.hip y2_fused_kernel): the energy phase then keeps the
+// dense (pair, pair) intermediate of its first pair step in the K3 buffer instead of writing K3 (EVC_Y2_FUSED=0: K3)
+static bool use_fused_y2(bool sym8, int n) {
+    return sym8 && use_pair_transform(n) && y2_fused_available(n) && !use_direct_pair_steps();
+}
 static bool is_packed(int layout) { return layout == EVC_LAYOUT_ELEC3 || layout == EVC_LAYOUT_PACK2 || is_sym8(layout); }
 static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout == EVC_LAYOUT_PACK2 || is_sym8(layout); }
 
@@ -283,7 +288,9 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
             pa.C = w.X + o;
             pa.sC = sw;
             pa.n = n;
-            pa.out = w.B1 + o;
+            const bool fused_y2 = use_fused_y2(is_sym8(t->layout), n);
+            double *mid = (fused_y2 ? w.K3 : w.B1) + o;   // the intermediate; kept for the gradient phase when fused
+            pa.out = mid;
             pa.sout = sw;
             // compressed layout: the AO integrals are 8-fold symmetric by contract, the first step only
             // produces the q <= p half of its output and the second one reads the lower triangles
@@ -302,9 +309,9 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
             pa.direct = direct ? 1 : 0;
             pa.in_cols = direct1 ? 1 : 0;   // a direct first step wrote rows by ITS leading pair
             // ... and the second step again only needs the q <= p half of ITS leading pair
-            pa.in = w.B1 + o;
+            pa.in = mid;
             pa.sin = sw;
-            pa.k3 = w.K3 + o;
+            pa.k3 = fused_y2 ? nullptr : w.K3 + o;
             pa.sk3 = sw;
             if (is_packed(t->layout)) {
                 pa.out = nullptr;
@@ -469,6 +476,8 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
     p.sD = sD;
     p.scale1 = scale1;
     if ((rc = launch_grad_prep(p, cnt, st))) return rc;
+    const bool fused_y2 = packed && use_fused_y2(sym8 != 0, n);
+    const int y2_slabs_used = fused_y2 ? y2_fused_slabs(n) : y2_slabs(n);
     auto ip1_stage = [&](const double *gao_, int c0, int cc) -> int {
         const int64_t o = (int64_t)c0 * sw;
         Ip1Args ia;
@@ -488,7 +497,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
         ia.sws = sw;
         ia.n = n;
         ia.natm = g.natm;
-        ia.nslab = y2_slabs(n);
+        ia.nslab = y2_slabs_used;
         ia.nchunk = ip1_chunks(n);
         return launch_ip1_dh(ia, cc, st);
     };
@@ -510,7 +519,20 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                         return rc;
                     prof_stop(pr, st);
                     pr = prof_start(EVC_PROF_Y2, st);
-                    if ((rc = launch_y2_fold(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, G ? 0 : 1, st))) return rc;
+                    if (fused_y2) {
+                        // (the K3 buffer holds the first pair step's intermediate; with the unpacked 2-RDM requested
+                        //  SB above is N^4-addressed: the dense (pair, pair) form goes to B2, free until the next step)
+                        const double *sbp = w.B1 + o;
+                        if (G) {
+                            if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, sw, nullptr, 0,
+                                                     cc, 2, st)))
+                                return rc;
+                            sbp = w.B2 + o;
+                        }
+                        if ((rc = launch_y2_fused(sbp, w.K3 + o, w.X + o, sw, n, w.y2part + o, sw, cc, st))) return rc;
+                    } else if ((rc = launch_y2_fold(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, G ? 0 : 1, st))) {
+                        return rc;
+                    }
                 } else {
                     if ((rc = launch_unpack_sym(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, w.B1 + o, sw,
                                                 G ? G + (int64_t)c0 * sG : nullptr, sG, cc, st)))

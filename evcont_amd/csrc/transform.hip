@@ -1684,6 +1684,194 @@ int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, i
     return 0;
 }
 
+// ------------------------------------------------------------------ Y2 with the half-transformed integrals recomputed
+// y2_pairs_kernel above reads K3p[j][v][a] = mult(v) (M1_v X)[a][j], which the second pair step of the energy phase
+// has to store (107 MB per 32 geometries at N = 30: +18 us there) and this contraction to read back.  M1_v -- row v of
+// the dense (pair, pair) intermediate of the FIRST pair step, a symmetric N x N matrix -- is 16x smaller, and
+// SB[tri(i,j)][v] = SB[v][tri(i,j)] is a contiguous row of the symmetric SB as well, so one wave per pair v does
+//   H^T = X^T M1_v            (32 MFMAs at N <= 32; X fragments as A operand, the fragments of the symmetric M1_v as B)
+//   Y  += mult(v) T_v H^T     (32 MFMAs; T_v = row v of SB as A operand, the accumulator tiles of H^T as B operand:
+//                              row 4 kk + (l >> 4) of H^T lives in register kk % 4 of its row tile kk / 4)
+// with both rows fetched like the operand rows of the pair transform (coalesced 16-byte loads, wave-private LDS row,
+// lane-constant triangle offsets) one pair ahead.  No stage, no stores but the (N, N) partial of the workgroup.
+template <int NPAD>
+__global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict__ SB, const double *__restrict__ M1,
+                                                       const double *__restrict__ X, int64_t sX, int n,
+                                                       double *__restrict__ partial, int64_t sws, int tiles_per_wg) {
+    constexpr int KS = NPAD / 4;
+    constexpr int NT = NPAD / 16;
+    constexpr int RAWN = (NPAD * (NPAD + 1) / 2 + 1 + 127) / 128;
+    extern __shared__ __align__(16) double sm[];
+    const int npairs = n * (n + 1) / 2;
+    const int64_t g = blockIdx.y;
+    SB += g * sws;
+    M1 += g * sws;
+    X += g * sX;
+    partial += g * sws;
+    const int ntiles = (npairs + 7) / 8;
+    const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *rowM = sm + wave * kPtRowLen;             // the wave's two operand rows
+    double *rowT = sm + (4 + wave) * kPtRowLen;
+    double *red = sm;                                 // [4][NPAD][NPAD + 1], over the rows once they are done with
+    d4 yacc[NT][NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) yacc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (t_begin < t_end) {
+        const int niter = 2 * (t_end - t_begin);
+        int foff[NT][KS];   // fragment (rt, kk) of a symmetric n x n matrix in its packed row
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int r = rt * 16 + l15, s = 4 * kk + l4;
+                const int hi = s > r ? s : r, lo = s > r ? r : s;
+                foff[rt][kk] = (r < n && s < n) ? hi * (hi + 1) / 2 + lo : kPtRawMax * 128;   // else: a zero slot
+            }
+        if (lane < 4) {
+            rowM[kPtRawMax * 128 + lane] = 0.0;
+            rowT[kPtRawMax * 128 + lane] = 0.0;
+        }
+        d2 rawM[RAWN], rawT[RAWN];
+        auto fetch = [&](const double *base, int e, d2 (&raw)[RAWN]) -> int {
+            const double *row = base + (int64_t)(e < npairs ? e : 0) * npairs;
+            const int d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
+            const double *w0 = row - d_;
+            const int lim = npairs + d_;
+#pragma unroll
+            for (int u = 0; u < RAWN; ++u) {
+                const int j = 128 * u + 2 * lane;
+                raw[u] = *reinterpret_cast<const d2 *>(w0 + (j < lim ? j : 0));
+            }
+            return d_;
+        };
+        auto park = [&](double *row, const d2 (&raw)[RAWN]) {
+#pragma unroll
+            for (int u = 0; u < RAWN; ++u) *reinterpret_cast<d2 *>(row + 128 * u + 2 * lane) = raw[u];
+        };
+        auto is_diag = [&](int x) -> bool {
+            const int r = tri_row_small(x);
+            return x == r * (r + 3) / 2;
+        };
+        const int e0 = 8 * t_begin + wave;   // this wave's pair of iteration i: e0 + 4 i
+        int dM = fetch(M1, e0, rawM), dT = fetch(SB, e0, rawT);
+        double xf[KS][NT];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int d = 4 * kk + l4, c = t * 16 + l15;
+                const bool ok = d < n && c < n;
+                const double v = X[ok ? d * n + c : 0];
+                xf[kk][t] = ok ? v : 0.0;
+            }
+        double mf[NT][KS], tf[NT][KS];
+        park(rowM, rawM);
+        park(rowT, rawT);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                mf[rt][kk] = rowM[foff[rt][kk] + dM];
+                tf[rt][kk] = rowT[foff[rt][kk] + dT];
+            }
+        int dMn = fetch(M1, e0 + 4, rawM), dTn = fetch(SB, e0 + 4, rawT);
+        for (int i = 0; i < niter; ++i) {
+            const int e = e0 + 4 * i;
+            const bool have = e < npairs;   // wave-uniform
+            if (have) {
+                // multiplicity of the pair (p,q): 2 off the diagonal
+                const double km = is_diag(e) ? 1.0 : 2.0;
+                d4 hT[NT][NT];   // H^T = X^T M: tile (it, st) = rows s' of tile it, columns r of tile st
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+#pragma unroll
+                    for (int st = 0; st < NT; ++st) hT[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                    for (int it = 0; it < NT; ++it)
+#pragma unroll
+                        for (int st = 0; st < NT; ++st) hT[it][st] = mfma_f64(xf[kk][it], mf[st][kk], hT[it][st]);
+                // the next M row: registers -> LDS row -> fragments (mf is free now)
+                park(rowM, rawM);
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti) {
+                        const double tv = tf[ti][kk] * km;
+#pragma unroll
+                        for (int ta = 0; ta < NT; ++ta)
+                            yacc[ti][ta] = mfma_f64(tv, hT[kk / 4][ta][kk % 4], yacc[ti][ta]);
+                    }
+            } else {
+                park(rowM, rawM);
+            }
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = rowM[foff[rt][kk] + dMn];
+            park(rowT, rawT);
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) tf[rt][kk] = rowT[foff[rt][kk] + dTn];
+            dMn = fetch(M1, e + 8, rawM);
+            dTn = fetch(SB, e + 8, rawT);
+        }
+    }
+    // cross-wave sum (every workgroup writes its slab, workgroups without tiles a zero one)
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(wave * NPAD + ti * 16 + l4 + 4 * r) * (NPAD + 1) + ta * 16 + l15] = yacc[ti][ta][r];
+    __syncthreads();
+    double *dst = partial + (int64_t)blockIdx.x * n * n;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, aa = idx % n;
+        const int o = i * (NPAD + 1) + aa;
+        constexpr int WS = NPAD * (NPAD + 1);
+        dst[idx] = (red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o]);
+    }
+}
+
+static int y2_fused_tiles() { return 4; }
+bool y2_fused_available(int n) {
+    static const bool on = !(getenv("EVC_Y2_FUSED") && atoi(getenv("EVC_Y2_FUSED")) == 0);
+    return on && n >= 1 && n <= kPairTransformMaxN;
+}
+int y2_fused_slabs(int n) {
+    const int ntiles = (n * (n + 1) / 2 + 7) / 8;
+    return (ntiles + y2_fused_tiles() - 1) / y2_fused_tiles();
+}
+int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial,
+                    int64_t sws, int count, hipStream_t st) {
+    const dim3 grid((unsigned)y2_fused_slabs(n), (unsigned)count);
+    const int npad = (n + 15) / 16 * 16;
+    const size_t rows = sizeof(double) * (size_t)8 * kPtRowLen;
+    if (npad == 16) {
+        const size_t redb = sizeof(double) * 4 * 16 * 17;
+        hipLaunchKernelGGL(y2_fused_kernel<16>, grid, dim3(256), rows > redb ? rows : redb, st, SB, M1, X, sX, n, partial,
+                           sws, y2_fused_tiles());
+    } else if (npad == 32) {
+        const size_t redb = sizeof(double) * 4 * 32 * 33;
+        hipLaunchKernelGGL(y2_fused_kernel<32>, grid, dim3(256), rows > redb ? rows : redb, st, SB, M1, X, sX, n, partial,
+                           sws, y2_fused_tiles());
+    } else {
+        set_error("y2_fused: n=%d not supported (1..32)", n);
+        return -1;
+    }
+    EVC_LAUNCH_CHECK("y2_fused");
+    return 0;
+}
+
 int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
     const int64_t ktot = (int64_t)n * n * n;
     const int nt = (n + 15) / 16;
