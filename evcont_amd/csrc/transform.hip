@@ -1917,8 +1917,10 @@ static int ip1_per_thread() {
     return pt;
 }
 int ip1_chunks(int n) {
+    // (at least n: the pair-block form of the packed contraction files its partials under the partner index b)
     const int64_t n3 = (int64_t)n * n * n;
-    return (int)ceil_div(n3, 256 * ip1_per_thread());
+    const int c = (int)ceil_div(n3, 256 * ip1_per_thread());
+    return c > n ? c : n;
 }
 
 template <int kIp1PerThread>
@@ -1928,8 +1930,55 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
     const int n = a.n, nchunk = a.nchunk;
     const int64_t n2 = (int64_t)n * n, n3 = n2 * n, n4 = n2 * n2;
     const int64_t g = blockIdx.y;
-    const int nb1 = n * nchunk;
-    if ((int)blockIdx.x < nb1) {
+    const bool pair_blocks = a.presym && a.fold_cd && a.ip1_s2kl;
+    const int nb1 = pair_blocks ? n * (n + 1) / 2 : n * nchunk;
+    if (pair_blocks && (int)blockIdx.x < nb1) {
+        // int2e_ip1 packed in (c,d), c >= d, against the dense (pair, pair) AO-basis 2-RDM G[tri(m,b)][v] (weight 2 for
+        // c != d folded in by the last rotation step): one block per unordered pair {m, b} -- the row G[tri(hi,lo)][:]
+        // is read once and contracted with ip1[x][hi][lo][:] (-> t2[x][hi], filed under partner lo) and, for
+        // hi != lo, with ip1[x][lo][hi][:] (-> t2[x][lo], partner hi): 7 contiguous streams of n(n+1)/2 doubles
+        const double *__restrict__ ip1 = a.ip1 + g * a.sip1;
+        const double *__restrict__ G = a.Gao + g * a.sws;
+        const int npr = n * (n + 1) / 2;
+        const int pidx = blockIdx.x, hi = tri_row_small(pidx), lo = pidx - hi * (hi + 1) / 2;
+        const int64_t len = (int64_t)n * npr;          // one (x, m) block of ip1
+        const double *__restrict__ gr = G + (int64_t)pidx * npr;
+        const double *__restrict__ qh = ip1 + ((int64_t)hi * n + lo) * npr;
+        const double *__restrict__ ql = ip1 + ((int64_t)lo * n + hi) * npr;
+        const bool both = hi != lo;
+        double ah[3] = {0.0, 0.0, 0.0}, al[3] = {0.0, 0.0, 0.0};
+        for (int v = threadIdx.x; v < npr; v += 256) {
+            const double gv = gr[v];
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                ah[x] = fma(qh[(int64_t)x * n * len + v], gv, ah[x]);
+                if (both) al[x] = fma(ql[(int64_t)x * n * len + v], gv, al[x]);
+            }
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __shared__ double pr6[6][4];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            const double sh = wave_sum(ah[x]), sl = wave_sum(al[x]);
+            if (lane == 0) {
+                pr6[x][wave] = sh;
+                pr6[3 + x][wave] = sl;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const int x = threadIdx.x % 3, role = threadIdx.x / 3;
+            const double t = (pr6[threadIdx.x][0] + pr6[threadIdx.x][1]) + (pr6[threadIdx.x][2] + pr6[threadIdx.x][3]);
+            double *tp = a.t2part + g * a.sws;
+            if (role == 0) tp[((int64_t)hi * 3 + x) * nchunk + lo] = t;
+            else if (both) tp[((int64_t)lo * 3 + x) * nchunk + hi] = t;
+        }
+        if (lo == 0 && nchunk > n) {   // slots behind the n partners (only if the chunk count exceeds n)
+            double *tp = a.t2part + g * a.sws;
+            for (int idx = threadIdx.x; idx < 3 * (nchunk - n); idx += 256)
+                tp[((int64_t)hi * 3 + idx / (nchunk - n)) * nchunk + n + idx % (nchunk - n)] = 0.0;
+        }
+    } else if ((int)blockIdx.x < nb1) {
         const double *__restrict__ ip1 = a.ip1 + g * a.sip1;
         const double *__restrict__ G = a.Gao + g * a.sws;
         const int m = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
@@ -2087,7 +2136,8 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
 }
 
 int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st) {
-    const int blocks = a.n * a.nchunk + a.natm * 3 + (a.n * a.n + 63) / 64;
+    const bool pair_blocks = a.presym && a.fold_cd && a.ip1_s2kl;
+    const int blocks = (pair_blocks ? a.n * (a.n + 1) / 2 : a.n * a.nchunk) + a.natm * 3 + (a.n * a.n + 63) / 64;
     switch (ip1_per_thread()) {
         case 16: hipLaunchKernelGGL(ip1_dh_kernel<16>, dim3(blocks, (unsigned)count), dim3(256), 0, st, a); break;
         case 8: hipLaunchKernelGGL(ip1_dh_kernel<8>, dim3(blocks, (unsigned)count), dim3(256), 0, st, a); break;
