@@ -1770,57 +1770,50 @@ __global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict_
             }
         double mf[NT][KS], tf[NT][KS];
         park(rowM, rawM);
-        park(rowT, rawT);
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                mf[rt][kk] = rowM[foff[rt][kk] + dM];
-                tf[rt][kk] = rowT[foff[rt][kk] + dT];
-            }
-        int dMn = fetch(M1, e0 + 4, rawM), dTn = fetch(SB, e0 + 4, rawT);
+            for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = rowM[foff[rt][kk] + dM];
+        dM = fetch(M1, e0 + 4, rawM);
+        // Iteration i: the T row (fetched one iteration ago) goes to LDS and comes back as fragments behind the MFMAs of
+        // the H^T phase (which does not use them) and the next T row is requested; the next M row goes to LDS and comes
+        // back behind the MFMAs of the Y phase (which does not use the M fragments), then the M row after that is
+        // requested.  No branches in the body: idle slots of the last tile run on row 0 with multiplicity 0.
         for (int i = 0; i < niter; ++i) {
             const int e = e0 + 4 * i;
-            const bool have = e < npairs;   // wave-uniform
-            if (have) {
-                // multiplicity of the pair (p,q): 2 off the diagonal
-                const double km = is_diag(e) ? 1.0 : 2.0;
-                d4 hT[NT][NT];   // H^T = X^T M: tile (it, st) = rows s' of tile it, columns r of tile st
-#pragma unroll
-                for (int it = 0; it < NT; ++it)
-#pragma unroll
-                    for (int st = 0; st < NT; ++st) hT[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                    for (int it = 0; it < NT; ++it)
-#pragma unroll
-                        for (int st = 0; st < NT; ++st) hT[it][st] = mfma_f64(xf[kk][it], mf[st][kk], hT[it][st]);
-                // the next M row: registers -> LDS row -> fragments (mf is free now)
-                park(rowM, rawM);
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                    for (int ti = 0; ti < NT; ++ti) {
-                        const double tv = tf[ti][kk] * km;
-#pragma unroll
-                        for (int ta = 0; ta < NT; ++ta)
-                            yacc[ti][ta] = mfma_f64(tv, hT[kk / 4][ta][kk % 4], yacc[ti][ta]);
-                    }
-            } else {
-                park(rowM, rawM);
-            }
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = rowM[foff[rt][kk] + dMn];
+            const double km = e < npairs ? (is_diag(e) ? 1.0 : 2.0) : 0.0;   // multiplicity of the pair (p,q)
             park(rowT, rawT);
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) tf[rt][kk] = rowT[foff[rt][kk] + dTn];
-            dMn = fetch(M1, e + 8, rawM);
-            dTn = fetch(SB, e + 8, rawT);
+                for (int kk = 0; kk < KS; ++kk) tf[rt][kk] = rowT[foff[rt][kk] + dT];
+            dT = fetch(SB, e + 4, rawT);
+            d4 hT[NT][NT];   // H^T = X^T M: tile (it, st) = rows s' of tile it, columns r of tile st
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int st = 0; st < NT; ++st) hT[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+#pragma unroll
+                    for (int st = 0; st < NT; ++st) hT[it][st] = mfma_f64(xf[kk][it], mf[st][kk], hT[it][st]);
+            park(rowM, rawM);
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = rowM[foff[rt][kk] + dM];
+            dM = fetch(M1, e + 8, rawM);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    const double tv = tf[ti][kk] * km;
+#pragma unroll
+                    for (int ta = 0; ta < NT; ++ta)
+                        yacc[ti][ta] = mfma_f64(tv, hT[kk / 4][ta][kk % 4], yacc[ti][ta]);
+                }
         }
     }
     // cross-wave sum (every workgroup writes its slab, workgroups without tiles a zero one)
