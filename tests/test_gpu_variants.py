@@ -21,6 +21,7 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
     {"EVC_PT_PIPE": "0", "EVC_PT_ROWBUF": "0"},   # pt_kernel with the per-lane gather
     {"EVC_PT_TILES": "1"},                    # pipelined pair transform, one tile per workgroup (two matrices per wave)
     {"EVC_PT_TILES": "3"},                    # ... an odd number of tiles (last workgroup ragged)
+    {"EVC_Y2_FUSED": "0"},                    # K3 stored by the second pair step, split-K Y2 over it
     {"EVC_ROWS_NARROW_WGS": "240"},           # K5 spans cut in 32-column chunks (span_cols not a multiple of 512)
     {"EVC_ROWS_SHAPE2_NARROW": "722"},        # eight-wave split-set K5
     {"EVC_ROWS_SHAPE2_NARROW": "422"},
