@@ -108,10 +108,10 @@ int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int
 // Y2 without K3 (symmetric pipeline): the half-transformed integrals are recomputed from the dense (pair, pair)
 // intermediate `M1` of the first pair step (kept by the energy phase) inside the contraction,
 //   Y2[i][a] = sum_v mult(v) sum_j SB[v][tri(i,j)] (M1_v X)[a][j];
-// writes y2_fused_slabs(n) partial (n, n) matrices per geometry (same layout as launch_y2_fold's)
+// writes y2_fused_slabs(n, count) partial (n, n) matrices per geometry (same layout as launch_y2_fold's)
 int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial,
                     int64_t sws, int count, hipStream_t st);
-int y2_fused_slabs(int n);
+int y2_fused_slabs(int n, int count);
 bool y2_fused_available(int n);
 int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, int pairs,
                    hipStream_t st);

@@ -477,7 +477,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
     p.scale1 = scale1;
     if ((rc = launch_grad_prep(p, cnt, st))) return rc;
     const bool fused_y2 = packed && use_fused_y2(sym8 != 0, n);
-    const int y2_slabs_used = fused_y2 ? y2_fused_slabs(n) : y2_slabs(n);
+    int y2_slabs_used = y2_slabs(n);   // (the fused kernel: per chunk of geometries, set where it is launched)
     auto ip1_stage = [&](const double *gao_, int c0, int cc) -> int {
         const int64_t o = (int64_t)c0 * sw;
         Ip1Args ia;
@@ -530,6 +530,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                             sbp = w.B2 + o;
                         }
                         if ((rc = launch_y2_fused(sbp, w.K3 + o, w.X + o, sw, n, w.y2part + o, sw, cc, st))) return rc;
+                        y2_slabs_used = y2_fused_slabs(n, cc);
                     } else if ((rc = launch_y2_fold(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, G ? 0 : 1, st))) {
                         return rc;
                     }

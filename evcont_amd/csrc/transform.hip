@@ -1835,28 +1835,35 @@ __global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict_
     }
 }
 
-static int y2_fused_tiles() { return 4; }
+// 8-pair tiles per workgroup: 4 for batches (as the pair transform), 1 for a few geometries (enough workgroups for the
+// chip), never more workgroups than the partial buffer has slabs
+static int y2_fused_tiles(int n, int count) {
+    const int ntiles = (n * (n + 1) / 2 + 7) / 8;
+    int t = count < 4 ? 1 : 4;
+    while ((ntiles + t - 1) / t > y2_slab_count()) ++t;
+    return t;
+}
 bool y2_fused_available(int n) {
     static const bool on = !(getenv("EVC_Y2_FUSED") && atoi(getenv("EVC_Y2_FUSED")) == 0);
     return on && n >= 1 && n <= kPairTransformMaxN;
 }
-int y2_fused_slabs(int n) {
-    const int ntiles = (n * (n + 1) / 2 + 7) / 8;
-    return (ntiles + y2_fused_tiles() - 1) / y2_fused_tiles();
+int y2_fused_slabs(int n, int count) {
+    const int ntiles = (n * (n + 1) / 2 + 7) / 8, t = y2_fused_tiles(n, count);
+    return (ntiles + t - 1) / t;
 }
 int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial,
                     int64_t sws, int count, hipStream_t st) {
-    const dim3 grid((unsigned)y2_fused_slabs(n), (unsigned)count);
+    const dim3 grid((unsigned)y2_fused_slabs(n, count), (unsigned)count);
     const int npad = (n + 15) / 16 * 16;
     const size_t rows = sizeof(double) * (size_t)8 * kPtRowLen;
     if (npad == 16) {
         const size_t redb = sizeof(double) * 4 * 16 * 17;
         hipLaunchKernelGGL(y2_fused_kernel<16>, grid, dim3(256), rows > redb ? rows : redb, st, SB, M1, X, sX, n, partial,
-                           sws, y2_fused_tiles());
+                           sws, y2_fused_tiles(n, count));
     } else if (npad == 32) {
         const size_t redb = sizeof(double) * 4 * 32 * 33;
         hipLaunchKernelGGL(y2_fused_kernel<32>, grid, dim3(256), rows > redb ? rows : redb, st, SB, M1, X, sX, n, partial,
-                           sws, y2_fused_tiles());
+                           sws, y2_fused_tiles(n, count));
     } else {
         set_error("y2_fused: n=%d not supported (1..32)", n);
         return -1;
