@@ -390,9 +390,12 @@ class BatchedEvaluator:
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
         self.ws_bytes = nbytes
         G = self.count
-        self.energy = torch.zeros((G, T), dtype=F64, device=d)
+        # energies and gradients share one buffer: a caller that wants both on the host fetches them with ONE copy
+        na = max(self.natm, 1)
+        self.energy_grad = torch.zeros(G * T + G * na * 3, dtype=F64, device=d)
+        self.energy = self.energy_grad[: G * T].view(G, T)
         self.coeffs = torch.zeros((G, T, T), dtype=F64, device=d)
-        self.grad = torch.zeros((G, max(self.natm, 1), 3), dtype=F64, device=d)
+        self.grad = self.energy_grad[G * T:].view(G, na, 3)
         self.d_pred = torch.zeros((G, n, n), dtype=F64, device=d) if (keep_density_matrices or keep_one_rdm) else None
         self.g_pred = torch.zeros((G, n, n, n, n), dtype=F64, device=d) if keep_density_matrices else None
         # the subspace Hamiltonians H(R) (lower triangles as handed to the eigensolver), for subset re-solves

@@ -47,9 +47,9 @@ class HostedEvaluator:
                   "dhcore": (1, self.natm, 3, n, n),
                   "eri": (1, npr, npr) if self.packed else (1, n, n, n, n),
                   "eri_ip1": (1, 3, n, n, npr) if self.packed else (1, 3, n, n, n, n)}
-        # three slabs = three H2D copies per step (a copy costs ~12 us before its first byte moves): the small early
-        # arrays, int2e, and the late pair (dhcore, int2e_ip1); every array is a 16-byte aligned view of its slab
-        self._groups = (("S", "hcore", "enuc", "ipovlp", "gnuc"), ("eri",), _LATE)
+        # two slabs = two H2D copies per step (a copy costs ~12 us before its first byte moves): the early arrays (the
+        # small ones and int2e) and the late pair (dhcore, int2e_ip1); every array is a 16-byte aligned view of its slab
+        self._groups = (("S", "hcore", "enuc", "ipovlp", "gnuc", "eri"), _LATE)
         self.host: Dict[str, torch.Tensor] = {}
         self.dev: Dict[str, torch.Tensor] = {}
         self._slabs = []
@@ -71,8 +71,11 @@ class HostedEvaluator:
         self.side = torch.cuda.Stream(d)
         self.ev = BatchedEvaluator(trdms, self.natm, 1, stream=self.stream, warm_start=warm_start,
                                    keep_density_matrices=keep_density_matrices, keep_one_rdm=True)
-        self.out_host = {"energy": torch.zeros((1, trdms.T), dtype=F64).pin_memory(),
-                         "grad": torch.zeros((1, max(self.natm, 1), 3), dtype=F64).pin_memory()}
+        # (energies and gradient come back with one copy: they share a device buffer, evaluator.BatchedEvaluator)
+        self._out_slab = torch.zeros(self.ev.energy_grad.numel(), dtype=F64).pin_memory()
+        T = trdms.T
+        self.out_host = {"energy": self._out_slab[:T].view(1, T),
+                         "grad": self._out_slab[T:].view(1, max(self.natm, 1), 3)}
         self.use_graph = bool(use_graph)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._calls = 0
@@ -105,9 +108,10 @@ class HostedEvaluator:
     def _enqueue_step(self) -> None:
         """Uploads, the device DAG and the downloads, on self.stream with self.side forked for the late inputs."""
         main, side = self.stream, self.side
-        (h0, d0), (h1, d1), (h2, d2) = self._slabs
-        # Early slabs on the main stream, the late slab on a forked one, joined in front of the gradient tail.
-        # (Measured alternatives on MI355X / ROCm 7.2, H30, per step: this order 425 us; int2e on the forked stream as
+        (h0, d0), (h2, d2) = self._slabs
+        # Early slab on the main stream, the late slab on a forked one, joined in front of the gradient tail.
+        # (Measured alternatives on MI355X / ROCm 7.2, H30, per step: this order 425 us -- 393-402 us since the small
+        #  arrays and int2e travel in ONE copy and energies + gradient come back in one --; int2e on the forked stream as
         #  well with the Loewdin kernel started behind the small slab alone, evc_phase_loewdin_batch: 530-540 us -- every
         #  cross-stream event wait on the critical path costs 20-25 us and the runtime takes tens of microseconds on
         #  the host to accept a 10 MB copy; the same with the Loewdin kernel reading S / hcore straight from the pinned
@@ -115,16 +119,14 @@ class HostedEvaluator:
         #  enqueue replayed as a HIP graph: 555-590 us.)
         with torch.cuda.stream(main):                     # submitted FIRST: the copy engine works in submission order
             d0.copy_(h0, non_blocking=True)
-            d1.copy_(h1, non_blocking=True)
-        side.wait_stream(main)                            # fork (behind the early copies)
+        side.wait_stream(main)                            # fork (behind the early copy)
         with torch.cuda.stream(side):
             d2.copy_(h2, non_blocking=True)
         with torch.cuda.stream(main):
-            self.ev.enqueue(self.aob, 1, energy_only=True)       # Loewdin .. eigensolve (K3 is kept for the tail)
+            self.ev.enqueue(self.aob, 1, energy_only=True)       # Loewdin .. eigensolve (what the tail needs stays in the workspace)
             main.wait_stream(side)                        # join: the gradient tail reads eri_ip1 and dhcore
             self.ev.phase_gradient(self.aob, False)
-            self.out_host["energy"].copy_(self.ev.energy, non_blocking=True)
-            self.out_host["grad"].copy_(self.ev.grad, non_blocking=True)
+            self._out_slab.copy_(self.ev.energy_grad, non_blocking=True)
 
     def run(self):
         """Evaluate the geometry in the staging buffers: ``(E_total, grad (A,3))`` as numpy."""
