@@ -630,12 +630,12 @@ int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
 #define EVC_COLS_RS_CASE(KSN_, MINW_, GS_) \
     case 1000 + 10 * KSN_ + MINW_: cols_mfma_rs_launch<KSN_, MINW_, GS_>(L, g0, G, st); break;
     static const int rs1 = getenv("EVC_COLS_RS_SHAPE") ? atoi(getenv("EVC_COLS_RS_SHAPE")) : 1026;
-    static const int rs2 = getenv("EVC_COLS_RS_SHAPE2") ? atoi(getenv("EVC_COLS_RS_SHAPE2")) : 1024;
+    static const int rs2 = getenv("EVC_COLS_RS_SHAPE2") ? atoi(getenv("EVC_COLS_RS_SHAPE2")) : 1083;
     static const int64_t rs_max_cols = getenv("EVC_COLS_RS_MAX") ? atoll(getenv("EVC_COLS_RS_MAX")) : 200000;
     if (L.p[0].cols <= rs_max_cols) {
         if (G > 16) {
             switch (rs2) {
-                EVC_COLS_RS_CASE(2, 4, 2) EVC_COLS_RS_CASE(1, 4, 2) EVC_COLS_RS_CASE(2, 3, 2) EVC_COLS_RS_CASE(4, 3, 2)
+                EVC_COLS_RS_CASE(2, 4, 2) EVC_COLS_RS_CASE(1, 4, 2) EVC_COLS_RS_CASE(2, 3, 2) EVC_COLS_RS_CASE(4, 3, 2) EVC_COLS_RS_CASE(4, 4, 2) EVC_COLS_RS_CASE(8, 3, 2) EVC_COLS_RS_CASE(8, 2, 2)
                 default: set_error("gemv_cols_mfma: unknown EVC_COLS_RS_SHAPE2=%d", rs2); return -1;
             }
         } else {
