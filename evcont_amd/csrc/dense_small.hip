@@ -1740,21 +1740,32 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
         }
         __syncthreads();
     }
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int ax = wave; ax < a.natm * 3; ax += 4) {
-        const int A = ax / 3, x = ax - 3 * A;
-        const int p0 = sl[2 * A], p1 = sl[2 * A + 1];
+    // two short steps instead of one wave-wide reduction per (atom, x): q[x][mu] = sum_nu ip[x,mu,nu] (W + W^T)[mu,nu]
+    // + t2[x][mu] / 2 by one thread per (x, mu) (sum_A (p1 - p0) = n: 3 n dots of length n in all), then one thread
+    // per (atom, x) adds up its AOs
+    for (int idx = tid; idx < 3 * n; idx += kThreads) {
+        const int x = idx / n, mu = idx - x * n;
         const double *ipx = x == 0 ? Y : x == 1 ? Q : Us;
+        double s0 = 0.0, s1 = 0.0;
+        int nu = 0;
+        for (; nu + 2 <= n; nu += 2) {
+            const double i0 = stage_ip ? ipx[mu * n + nu] : a.ipovlp[(x * n + mu) * n + nu];
+            const double i1 = stage_ip ? ipx[mu * n + nu + 1] : a.ipovlp[(x * n + mu) * n + nu + 1];
+            s0 = fma(i0, W[mu * n + nu] + W[nu * n + mu], s0);
+            s1 = fma(i1, W[mu * n + nu + 1] + W[(nu + 1) * n + mu], s1);
+        }
+        if (nu < n) {
+            const double i0 = stage_ip ? ipx[mu * n + nu] : a.ipovlp[(x * n + mu) * n + nu];
+            s0 = fma(i0, W[mu * n + nu] + W[nu * n + mu], s0);
+        }
+        t2[idx] = (s0 + s1) + 0.5 * t2[idx];
+    }
+    __syncthreads();
+    for (int ax = tid; ax < a.natm * 3; ax += kThreads) {
+        const int A = ax / 3, x = ax - 3 * A;
         double s = 0.0;
-        for (int mu = p0; mu < p1; ++mu)
-            for (int nu = lane; nu < n; nu += 64) {
-                const double ip = stage_ip ? ipx[mu * n + nu] : a.ipovlp[(x * n + mu) * n + nu];
-                s = fma(ip, W[mu * n + nu] + W[nu * n + mu], s);
-            }
-        s = -s;
-        for (int m_ = p0 + lane; m_ < p1; m_ += 64) s -= 0.5 * t2[x * n + m_];
-        s = wave_sum(s);
-        if (lane == 0) a.grad[ax] = s + add[ax];
+        for (int mu = sl[2 * A]; mu < sl[2 * A + 1]; ++mu) s += t2[x * n + mu];
+        a.grad[ax] = add[ax] - s;
     }
 }
 
