@@ -173,6 +173,9 @@ struct SolveArgs {
                                   // workspace from call to call (+ g*sw); may be NULL
     int warm;                     // start the Jacobi sweeps from vstd
     int fast;                     // set by launch_subspace_solve: FP32 Jacobi + FP64 refinement for T <= 32
+    double *bcache;               // (2, T, T) + g*sw or NULL: the lower triangle of the overlap matrix the cached
+                                  // B = L^-1 (second block) was computed from -- S_train does not depend on the
+                                  // geometry, so every call after the first finds its factorisation here (T <= 32)
 };
 int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st);
 // Weights of the t-RDM rows for the predicted RDMs of a GIVEN coefficient vector c[T] (gradients_loewdin.py:343-356):

@@ -84,6 +84,7 @@ struct Ws {
     double *evals, *evecs;
     // eigenvectors kept from call to call for EVC_FLAG_WARM_START (U above serves the Loewdin step)
     double *vstd;
+    double *bcache;   // (2, T, T): overlap matrix (lower triangle) and the inverse Cholesky factor computed from it
     bool warm;
     bool loewdin_done;   // X, U, s, h1 are already in the workspace (EVC_FLAG_LOEWDIN_DONE)
     size_t bytes;    // of ONE geometry
@@ -196,6 +197,7 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.evals = take(T);
     w.evecs = take(T * T);
     w.vstd = take(((T + 1) & ~(size_t)1) * ((T + 1) & ~(size_t)1));
+    w.bcache = take(2 * T * T);
     w.warm = false;
     w.loewdin_done = false;
     w.bytes = off;
@@ -417,6 +419,7 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
     a.w2_offset = t->row_offset;
     a.w2_count = t->rows2;
     a.vstd = w.vstd;
+    a.bcache = w.bcache;
     a.warm = w.warm ? 1 : 0;
     const int pr = prof_start(EVC_PROF_SUBSPACE, st);
     const int rc = launch_subspace_solve(a, g.count, st);

@@ -63,3 +63,34 @@ def test_warm_flag_on_stale_workspace_falls_back(fill):
     Ew, gw = ev.energy_with_grad(dao)
     assert abs(Ew - Ec) < 1e-11
     np.testing.assert_allclose(gw, gc, rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,T,A", [(13, 5, 3), (10, 20, 4)])
+def test_cached_overlap_factorisation_follows_the_training_set(n, T, A):
+    """The inverse Cholesky factor of S_train is cached in the workspace (it does not depend on the geometry) next to
+    the matrix it was computed from: a workspace that is reused with ANOTHER training set of the same shape (the C ABI
+    allows it) must notice and refactorise -- results identical to a fresh workspace's, in both directions, single
+    and batched."""
+    from evcont_amd.evaluator import (DeviceTRDMs, DeviceAO, DeviceAOBatch, ContinuationEvaluator, BatchedEvaluator)
+    dev = torch.device("cuda:0")
+    sets = []
+    for seed in (5, 6):
+        S, one, two = make_trdms(n, T, 300 + seed)
+        sets.append(DeviceTRDMs(one, pack_rows(two, True, True), S, dev))
+    aos = [make_ao_arrays(n, A, 40 + k) for k in range(3)]
+    dao = DeviceAO.from_arrays(aos[0], dev)
+    fresh = [ContinuationEvaluator(t, A).energy_with_grad(dao) for t in sets]
+    ev = ContinuationEvaluator(sets[0], A)
+    for k in (0, 0, 1, 1, 0):      # second call on a set: served from the cache; after a switch: a miss
+        ev.t = sets[k]
+        E, g = ev.energy_with_grad(dao)
+        assert abs(E - fresh[k][0]) < 1e-12, (k, E, fresh[k][0])
+        np.testing.assert_allclose(g, fresh[k][1], rtol=0, atol=1e-11)
+    aob = DeviceAOBatch.from_arrays(aos, dev)
+    freshb = [BatchedEvaluator(t, A, 3).energies_with_grads(aob) for t in sets]
+    be = BatchedEvaluator(sets[1], A, 3)
+    for k in (1, 1, 0, 0):
+        be.t = sets[k]
+        Eb, gb = be.energies_with_grads(aob)
+        np.testing.assert_allclose(Eb, freshb[k][0], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(gb, freshb[k][1], rtol=0, atol=1e-11)
