@@ -425,7 +425,7 @@ constexpr int kColsRsMaxCols = 200000;
 template <int G>
 __global__ __launch_bounds__(256) void gemv_cols_rs_kernel(GemvColsLaunch L, int g0) {
     __shared__ double2 red[4][G][64];
-    constexpr int U = 8;
+    constexpr int U = 16;
     int bid = blockIdx.x;
     const int which = bid >= L.nblk0 ? 1 : 0;
     if (which) bid -= L.nblk0;
