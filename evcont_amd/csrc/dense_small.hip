@@ -1113,6 +1113,15 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     }
     __syncthreads();
     // warm start from the eigenvectors the previous call left in U (same workspace, nearby geometry)
+    // (hcore is only needed behind the eigensolver: requested now, its latency is gone by then)
+    double hpre[(kRsz + kThreads - 1) / kThreads];
+    if (m <= kJwMax && a.fast) {
+#pragma unroll
+        for (int u = 0; u < (kRsz + kThreads - 1) / kThreads; ++u) {
+            const int idx = tid + u * kThreads, i = idx / kRp, j = idx - i * kRp;
+            hpre[u] = (idx < kRsz && i < n && j < n && h) ? h[i * n + j] : 0.0;
+        }
+    }
     if (m <= kJwMax && a.fast) {
         if (a.warm) {   // refinement straight from U (a stale or never-written buffer makes it fall back)
             for (int idx = tid; idx < m * m; idx += kThreads) {
@@ -1136,16 +1145,20 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     if (m <= kJwMax && a.fast) {
         // X = V diag(f) V^T and h1 = X^T h X as row.row products at pitch kRp (the refinement's buffers are free)
         double *Vf = R6, *Vp = R6 + kRsz, *Xp = R6 + 2 * kRsz, *hp = R6 + 3 * kRsz, *Tt = R6 + 4 * kRsz;
-        for (int idx = tid; idx < kRsz; idx += kThreads) {
-            const int i = idx / kRp, j = idx - i * kRp;
-            const bool in = i < n && j < n;
-            const double v = in ? V[i * m + j] : 0.0;
-            Vp[idx] = v;
-            Vf[idx] = in ? v * f[j] : 0.0;
-            hp[idx] = (in && h) ? h[i * n + j] : 0.0;
-            Xp[idx] = 0.0;
-            Tt[idx] = 0.0;
-            if (in) U[i * n + j] = v;
+#pragma unroll
+        for (int u = 0; u < (kRsz + kThreads - 1) / kThreads; ++u) {
+            const int idx = tid + u * kThreads;
+            if (idx < kRsz) {
+                const int i = idx / kRp, j = idx - i * kRp;
+                const bool in = i < n && j < n;
+                const double v = in ? V[i * m + j] : 0.0;
+                Vp[idx] = v;
+                Vf[idx] = in ? v * f[j] : 0.0;
+                hp[idx] = hpre[u];
+                Xp[idx] = 0.0;
+                Tt[idx] = 0.0;
+                if (in) U[i * n + j] = v;
+            }
         }
         __syncthreads();
         mm_rowrow(m, Vf, Vp, [&](int i, int j, double v) {
