@@ -834,6 +834,258 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     EVC_PT_WG(1);
 }
 
+// ------------------------------------------------------------------ the same for a few geometries: tiles of 4 pairs
+// With one or two geometries per launch pt_pipe_kernel has 59 workgroups of two matrices per wave and spends more
+// time in its prologue and drain-only tail than in between.  Here a tile is 4 leading pairs -- ONE matrix per wave --
+// so there are twice as many workgroups of half the length (the write-out runs are 32 bytes, which does not matter at
+// this size).  Same pipeline with period one: matrix i's result is staged during the H phase of matrix i+1, barrier,
+// and the tile is written out during that matrix's N phase; stage = 4 doubles per result row and buffer.  No K3.
+template <int NPAD, int MODE>
+__global__ __launch_bounds__(256) void pt_pipe4_kernel(PairTransformArgs a) {
+    constexpr int KS = NPAD / 4;
+    constexpr int NT = NPAD / 16;
+    constexpr int NPASS = (NPAD * (NPAD + 1) / 2 + 127) / 128;     // write-out passes of a tile (128 result rows each)
+    constexpr int NRES = NT * (NT + 1) / 2 * 4;
+    constexpr int SPG = (NRES + KS - 1) / KS;
+    constexpr int FPG = (NT * KS + (KS - 2) - 1) / (KS - 2);
+    constexpr int PPG = (NPASS + KS - 1) / KS;
+    constexpr int RAWN = (NPAD * (NPAD + 1) / 2 + 1 + 127) / 128;
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n;
+    const int npairs = n * (n + 1) / 2;
+    const int64_t g = blockIdx.y;
+    const double *__restrict__ in = a.in + g * a.sin;
+    const double *__restrict__ C = a.C + g * a.sC;
+    const int ntiles = (npairs + 3) / 4;
+    const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(ntiles, t_begin + a.tiles_per_wg);
+    if (t_begin >= t_end) return;
+    const int niter = t_end - t_begin;   // one matrix per wave and tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *mrow = sm + wave * kPtRowLen;
+    // stage: row u, buffer b, slot s at u * 8 + b * 4 + (s ^ f(u)), f(u) = 2 ((u >> 1) & 1); one dump row behind
+    double *stage = sm + 4 * kPtRowLen;
+    char *__restrict__ outb = nullptr;
+    if constexpr (MODE == 0) outb = reinterpret_cast<char *>(a.out + g * a.sout);
+    else outb = reinterpret_cast<char *>(a.packed + g * a.spacked);
+    const bool weigh = MODE == 1 || a.out_pairs > 1;
+
+    int foff[NT][KS];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int r = rt * 16 + l15, s = 4 * kk + l4;
+            const int hi = s > r ? s : r, lo = s > r ? r : s;
+            foff[rt][kk] = (r < n && s < n) ? hi * (hi + 1) / 2 + lo : kPtRawMax * 128;
+        }
+    int sa[NT][NT][4];
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int st = 0; st <= it; ++st)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
+                const int u = r2 * (r2 + 1) / 2 + s2;
+                sa[it][st][reg] = (r2 < n && s2 <= r2) ? u * 8 + (wave ^ (((u >> 1) & 1) << 1)) : npairs * 8 + wave;
+            }
+    [[maybe_unused]] const int dq = l15 - l4;
+    if (lane < 4) mrow[kPtRawMax * 128 + lane] = 0.0;
+
+    d2 raw[RAWN];
+    auto fetch = [&](int e) -> int {
+        const double *row = in + (int64_t)(e < npairs ? e : 0) * npairs;
+        const int d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
+        const double *w0 = row - d_;
+        const int lim = npairs + d_;
+#pragma unroll
+        for (int u = 0; u < RAWN; ++u) {
+            const int j = 128 * u + 2 * lane;
+            raw[u] = *reinterpret_cast<const d2 *>(w0 + (j < lim ? j : 0));
+        }
+        return d_;
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int u = 0; u < RAWN; ++u) *reinterpret_cast<d2 *>(mrow + 128 * u + 2 * lane) = raw[u];
+    };
+    auto is_diag = [&](int x) -> bool {
+        const int r = tri_row_small(x);
+        return x == r * (r + 3) / 2;
+    };
+
+    const int e0 = 4 * t_begin + wave;   // this wave's leading pair of iteration i: e0 + 4 i
+    int d_rd = fetch(e0);
+    double xf[KS][NT];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int d = 4 * kk + l4, c = t * 16 + l15;
+            const bool ok = d < n && c < n;
+            const double v = C[ok ? (a.ct ? c * n + d : d * n + c) : 0];
+            xf[kk][t] = ok ? v : 0.0;
+        }
+    if constexpr (MODE == 1) {
+        if (blockIdx.x == 0) {
+            double *pk = a.packed + g * a.spacked;
+            const int64_t M = (int64_t)npairs * (npairs + 1) / 2;
+            for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
+        }
+    }
+    double mf[NT][KS];
+    park();
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = mrow[foff[rt][kk] + d_rd];
+    int d_next = fetch(e0 + 4);
+
+    // write-out: 2 lanes cover the 4 pairs of one result row (16 bytes each); thread (wl, ur): columns wl, wl + 1 of
+    // rows u0 + 128 k
+    const int wl = 2 * (threadIdx.x & 1), ur = threadIdx.x >> 1;
+    [[maybe_unused]] const unsigned stride_b = 128u * (unsigned)npairs * 8u;
+
+    d4 nnp[NT][NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int st = 0; st < NT; ++st) nnp[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    auto iteration = [&](auto compute_tag, const int i) {
+        constexpr bool COMPUTE = decltype(compute_tag)::value;
+        const int ei = e0 + 4 * i;
+        // ---------------------------------------------------------------- H = M X  (+ stage writes of matrix i-1)
+        d4 h[NT][NT];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int st = 0; st < NT; ++st) h[rt][st] = (d4){0.0, 0.0, 0.0, 0.0};
+        {
+            const int xm = ((i - 1) & 1) << 2;   // buffer of tile i-1
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+                for (int m = 0; m < NT * NT; ++m) {
+                    if constexpr (COMPUTE) {
+                        const int rt = m / NT, st = m % NT;
+                        __builtin_amdgcn_s_setprio(0);
+                        h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
+                        __builtin_amdgcn_s_setprio(1);
+                    }
+                    const int f = kk * SPG + m;
+                    if (m < SPG && f < NRES) {
+                        const int tile = f / 4, reg = f % 4;
+                        const int it = tile == 0 ? 0 : 1, st2 = tile == 2 ? 1 : 0;
+                        double v = nnp[it][st2][reg];
+                        if (MODE == 1 && it == st2) v *= (dq == 4 * reg) ? 0.5 : 1.0;
+                        stage[sa[it][st2][reg] ^ xm] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (i >= 1) lds_barrier();   // tile i-1 is complete (and tile i-2 written out by everybody)
+        // ---------------------------------------------------------------- N = X^T H
+        d4 nn[NT][NT];
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int st = 0; st < NT; ++st) nn[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
+        {
+            const int jn = i - 1;                              // the tile written out now
+            const bool dn = jn >= 0;
+            const int ew = 4 * (t_begin + jn) + wl;
+            const int u0 = (MODE == 0 ? 0 : ew) + ur;
+            const int rem = (dn && ew < npairs) ? npairs - u0 : 0;   // pass k is valid  <=>  128 k < rem
+            const bool two = ew + 1 < npairs;
+            const d2 *dsrc = reinterpret_cast<const d2 *>(stage + (u0 * 8 + ((jn & 1) << 2) + (wl ^ (((u0 >> 1) & 1) << 1))));
+            d2 fac = {1.0, 1.0};
+            [[maybe_unused]] d2 fac0 = {1.0, 1.0};
+            unsigned off0 = 0;
+            [[maybe_unused]] unsigned offA = 0;
+            if (dn) {
+                if constexpr (MODE == 0) {
+                    fac[0] = (weigh && !is_diag(ew)) ? 2.0 : 1.0;
+                    fac[1] = (weigh && !is_diag(ew + 1)) ? 2.0 : 1.0;
+                    off0 = (unsigned)(u0 * npairs + ew) * 8u;
+                } else {
+                    fac[0] = is_diag(ew) ? 2.0 : 4.0;
+                    fac[1] = is_diag(ew + 1) ? 2.0 : 4.0;
+                    fac0[0] = ur == 0 ? fac[0] * a.diag_mult : fac[0];
+                    fac0[1] = ur == 1 ? fac[1] * a.diag_mult : fac[1];
+                    off0 = (unsigned)(u0 * (u0 + 1) / 2 + ew) * 8u;
+                    offA = (unsigned)(128 * u0) * 8u;   // tri(u0 + 128 k) = tri(u0) + k (128 u0) + 8192 k^2 + 64 k
+                }
+            }
+            constexpr int NM = NT * (NT + 1) / 2;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                d2 dv[PPG];
+#pragma unroll
+                for (int c = 0; c < PPG; ++c) {
+                    const int k = kk * PPG + c;
+                    dv[c] = (k < NPASS && 128 * k < rem) ? dsrc[512 * k] : (d2){0.0, 0.0};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    if constexpr (COMPUTE) {
+                        const int it = m == 0 ? 0 : 1, st = m == 2 ? 1 : 0;
+                        __builtin_amdgcn_s_setprio(0);
+                        nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
+                        __builtin_amdgcn_s_setprio(1);
+                    }
+                    if (COMPUTE && m == 0) {
+                        if (kk == 0) {
+                            park();
+                            d_rd = d_next;
+                        }
+                        if (kk == 1) d_next = fetch(ei + 8);
+                        if (kk >= 2) {
+#pragma unroll
+                            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                                for (int k2 = 0; k2 < KS; ++k2)
+                                    if ((rt * KS + k2) / FPG == kk - 2) mf[rt][k2] = mrow[foff[rt][k2] + d_rd];
+                        }
+                    }
+                    if (m == NM - 1) {
+#pragma unroll
+                        for (int c = 0; c < PPG; ++c) {
+                            const int k = kk * PPG + c;
+                            if (k < NPASS && 128 * k < rem) {
+                                const unsigned kq = (unsigned)k;
+                                unsigned off;
+                                d2 v;
+                                bool second = two;
+                                if constexpr (MODE == 0) {
+                                    off = off0 + kq * stride_b;
+                                    v = dv[c] * fac;
+                                } else {
+                                    off = off0 + kq * offA + (8192u * kq * kq + 64u * kq) * 8u;
+                                    v = dv[c] * (kq == 0 ? fac0 : fac);
+                                    if (kq == 0) second = two && ur >= 1;
+                                }
+                                if (second) *reinterpret_cast<d2 *>(outb + off) = v;
+                                else *reinterpret_cast<double *>(outb + off) = v[0];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int st = 0; st <= it; ++st) nnp[it][st] = nn[it][st];
+    };
+    for (int i = 0; i < niter; ++i) iteration(std::true_type{}, i);
+    iteration(std::false_type{}, niter);
+}
+
 // ------------------------------------------------------------------ barrier-free pair transform (symmetric pipeline)
 // Same arithmetic as pt_kernel for the fully symmetric case (dense (pair, pair) operands, q <= p leading pairs,
 // lower-triangle results), organised so that the waves never meet after X is staged: a wave fetches the matrix of its
@@ -1050,6 +1302,21 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
         const int mode = (a.out && a.out_pairs && !a.packed && !a.k3) ? 0 : (a.packed && a.sym8 && !a.out) ? 1 : -1;
         const size_t npairs = (size_t)n * (n + 1) / 2;
         const size_t lds = sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 16 + 16);
+        static const bool pipe4_on = !(getenv("EVC_PT_PIPE4") && atoi(getenv("EVC_PT_PIPE4")) == 0);
+        if (pipe4_on && mode >= 0 && count < 4 && !a.k3 && npairs >= 8) {
+            // a few geometries: tiles of 4 pairs, one per workgroup (twice the workgroups, half the length)
+            a.tiles_per_wg = 1;
+            const size_t lds4 = sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 8 + 8);
+            const dim3 grid4((unsigned)((npairs + 3) / 4), (unsigned)count);
+#define EVC_PT_PIPE4_CASE(NP_, MODE_) hipLaunchKernelGGL((pt_pipe4_kernel<NP_, MODE_>), grid4, dim3(256), lds4, st, a)
+            if (npad == 16 && mode == 0) EVC_PT_PIPE4_CASE(16, 0);
+            else if (npad == 16) EVC_PT_PIPE4_CASE(16, 1);
+            else if (mode == 0) EVC_PT_PIPE4_CASE(32, 0);
+            else EVC_PT_PIPE4_CASE(32, 1);
+#undef EVC_PT_PIPE4_CASE
+            EVC_LAUNCH_CHECK("pair_transform_pipe4");
+            return 0;
+        }
         if (mode >= 0 && lds <= 80 * 1024) {
             const dim3 gridp((unsigned)(((npairs + 7) / 8 + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
 #define EVC_PT_PIPE_CASE(NP_, MODE_)                                                                            \

@@ -19,6 +19,7 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
     {"EVC_PT_PIPE": "0"},                     # phase-alternating pair transform (pt_kernel) instead of pt_pipe_kernel
     {"EVC_PT_PIPE": "0", "EVC_PT_DIRECT": "1"},   # barrier-free pair transform (pt_sym_kernel)
     {"EVC_PT_PIPE": "0", "EVC_PT_ROWBUF": "0"},   # pt_kernel with the per-lane gather
+    {"EVC_PT_PIPE4": "0"},                    # a few geometries through pt_pipe_kernel (8-pair tiles) instead of pt_pipe4_kernel
     {"EVC_PT_TILES": "1"},                    # pipelined pair transform, one tile per workgroup (two matrices per wave)
     {"EVC_PT_TILES": "3"},                    # ... an odd number of tiles (last workgroup ragged)
     {"EVC_Y2_FUSED": "0"},                    # K3 stored by the second pair step, split-K Y2 over it
