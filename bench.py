@@ -487,8 +487,9 @@ def main():
             out["md_hosted"] = {"value": nst / dt_h, "unit": "geometries/s", "ms_per_step": 1e3 * dt_h / nst,
                                 "h2d_bytes_per_step": up_bytes, "graph": hevs[0].graph is not None,
                                 "note": "one geometry per step, AO integrals in pinned HOST memory, uploaded inside the "
-                                        "timed region; whole step = one HIP graph (uploads, 15 kernels, downloads); "
-                                        "cold start; PCIe-inclusive, never `value`"}
+                                        "timed region (two uploads, the late one on a forked stream; one download; "
+                                        "`graph`: whether the step is replayed as a HIP graph, "
+                                        "EVCONT_AMD_HOSTED_GRAPH); cold start; PCIe-inclusive, never `value`"}
         del hevs
     if world == 1 and not a.no_md_regime and not a.energy_only:
         # an MD-like sequence: geometries that change slowly from step to step (linear blend of two of the
