@@ -117,6 +117,7 @@ int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, i
                    hipStream_t st);
 // partial[b][i][a] = sum_{k in slab b} GsT[k][i] * K3[k][a]   (k = jkl)
 int y2_slabs(int n);
+int y2_slab_capacity(int n);   // slabs the pipeline's partial buffer holds (>= y2_slabs)
 int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);
 // ip1 contraction with on-the-fly AO symmetrisation (gradients_loewdin.py:234-252), dhcore:P_ao dots
 // and the fixed-order sum of the Y2 slabs (three block families of one launch)

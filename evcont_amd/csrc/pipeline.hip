@@ -190,7 +190,7 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.w2 = take((size_t)t->rows2 + 1);
     w.w2t = take((size_t)t->rows2 * kMaxBatchG + 1);
     w.w1 = take(T * T);
-    w.y2part = take((size_t)y2_slabs((int)n) * n2);
+    w.y2part = take((size_t)y2_slab_capacity((int)n) * n2);
     w.y2 = take(n2);
     w.t2part = take((size_t)n * 3 * ip1_chunks((int)n));
     w.term3 = take((size_t)(natm > 0 ? natm : 1) * 3);

@@ -1660,6 +1660,8 @@ static int y2_slab_count() {
     return v;
 }
 int y2_slabs(int) { return y2_slab_count(); }
+// slabs the partial buffer of the pipeline is sized for (the fused kernel below uses up to that many workgroups)
+int y2_slab_capacity(int) { return y2_slab_count() > 128 ? y2_slab_count() : 128; }
 
 template <int NT>
 __global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT, const double *__restrict__ K3,
@@ -1964,7 +1966,8 @@ int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, i
 template <int NPAD>
 __global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict__ SB, const double *__restrict__ M1,
                                                        const double *__restrict__ X, int64_t sX, int n,
-                                                       double *__restrict__ partial, int64_t sws, int tiles_per_wg) {
+                                                       double *__restrict__ partial, int64_t sws, int tiles_per_wg,
+                                                       int ppt) {
     constexpr int KS = NPAD / 4;
     constexpr int NT = NPAD / 16;
     constexpr int RAWN = (NPAD * (NPAD + 1) / 2 + 1 + 127) / 128;
@@ -1975,7 +1978,7 @@ __global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict_
     M1 += g * sws;
     X += g * sX;
     partial += g * sws;
-    const int ntiles = (npairs + 7) / 8;
+    const int ntiles = (npairs + ppt - 1) / ppt;   // ppt = 8 or 4 pairs per tile (two / one matrix per wave)
     const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1988,7 +1991,7 @@ __global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict_
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta) yacc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
     if (t_begin < t_end) {
-        const int niter = 2 * (t_end - t_begin);
+        const int niter = (ppt / 4) * (t_end - t_begin);
         int foff[NT][KS];   // fragment (rt, kk) of a symmetric n x n matrix in its packed row
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
@@ -2023,7 +2026,7 @@ __global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict_
             const int r = tri_row_small(x);
             return x == r * (r + 3) / 2;
         };
-        const int e0 = 8 * t_begin + wave;   // this wave's pair of iteration i: e0 + 4 i
+        const int e0 = ppt * t_begin + wave;   // this wave's pair of iteration i: e0 + 4 i
         int dM = fetch(M1, e0, rawM), dT = fetch(SB, e0, rawT);
         double xf[KS][NT];
 #pragma unroll
@@ -2104,10 +2107,12 @@ __global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict_
 
 // 8-pair tiles per workgroup: 4 for batches (as the pair transform), 1 for a few geometries (enough workgroups for the
 // chip), never more workgroups than the partial buffer has slabs
+static int y2_fused_ppt(int count) { return count < 4 ? 4 : 8; }   // pairs per tile: 4 (one matrix per wave) for a few geometries
 static int y2_fused_tiles(int n, int count) {
-    const int ntiles = (n * (n + 1) / 2 + 7) / 8;
+    const int ppt = y2_fused_ppt(count);
+    const int ntiles = (n * (n + 1) / 2 + ppt - 1) / ppt;
     int t = count < 4 ? 1 : 4;
-    while ((ntiles + t - 1) / t > y2_slab_count()) ++t;
+    while ((ntiles + t - 1) / t > y2_slab_capacity(n)) ++t;
     return t;
 }
 bool y2_fused_available(int n) {
@@ -2115,7 +2120,8 @@ bool y2_fused_available(int n) {
     return on && n >= 1 && n <= kPairTransformMaxN;
 }
 int y2_fused_slabs(int n, int count) {
-    const int ntiles = (n * (n + 1) / 2 + 7) / 8, t = y2_fused_tiles(n, count);
+    const int ppt = y2_fused_ppt(count);
+    const int ntiles = (n * (n + 1) / 2 + ppt - 1) / ppt, t = y2_fused_tiles(n, count);
     return (ntiles + t - 1) / t;
 }
 int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial,
@@ -2126,11 +2132,11 @@ int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t
     if (npad == 16) {
         const size_t redb = sizeof(double) * 4 * 16 * 17;
         hipLaunchKernelGGL(y2_fused_kernel<16>, grid, dim3(256), rows > redb ? rows : redb, st, SB, M1, X, sX, n, partial,
-                           sws, y2_fused_tiles(n, count));
+                           sws, y2_fused_tiles(n, count), y2_fused_ppt(count));
     } else if (npad == 32) {
         const size_t redb = sizeof(double) * 4 * 32 * 33;
         hipLaunchKernelGGL(y2_fused_kernel<32>, grid, dim3(256), rows > redb ? rows : redb, st, SB, M1, X, sX, n, partial,
-                           sws, y2_fused_tiles(n, count));
+                           sws, y2_fused_tiles(n, count), y2_fused_ppt(count));
     } else {
         set_error("y2_fused: n=%d not supported (1..32)", n);
         return -1;
