@@ -468,6 +468,11 @@ __device__ __forceinline__ void block_max_nan2(double &a, double &b, double *red
 // parallel -- eigenvalues closer than single precision resolves -- make it give up, and the caller falls back to the
 // Jacobi start), so there is no reorthogonalisation inside clusters and no safeguard beyond keeping pivots finite.
 // Lane map: j = lane & 31 (row of the matrix, eigenvalue, eigenvector), h = lane >> 5 (column half / direction).
+#ifndef EVC_STURM_ROUNDS
+#define EVC_STURM_ROUNDS 6
+#endif
+constexpr int kSturmRounds = EVC_STURM_ROUNDS;   // multisection rounds of 17 sub-intervals each: 17^6 = 2.4e7 ~ 1 / FP32 epsilon
+                                                 // (5 rounds: start error 1.5e-3 instead of 1.3e-4 at N = 30, a third refinement pass, +4 us)
 constexpr int kTp = 36;    // floats per row of the matrix being reduced (16-byte aligned rows)
 constexpr int kZfp = 33;   // floats per eigenvector row of the result (lane-private rows, conflict-free)
 
@@ -585,7 +590,7 @@ __device__ __forceinline__ void tridiag_eig_wg_f32(float *Af, int m, float *Zf, 
     for (int i = 0; i < 32; ++i) e2[i] = fmaxf(e2[i], 1.0e-36f);
     float lo = glo, hi = ghi;
     const int slot = 2 * wave + h;   // 0..7; this lane evaluates abscissae 2 slot + 1, 2 slot + 2 of 16
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < kSturmRounds; ++it) {
         const float wd = (hi - lo) * (1.0f / 17.0f);
         const float xa = lo + wd * (float)(2 * slot + 1), xb = lo + wd * (float)(2 * slot + 2);
         float qa = dr[0] - xa, qb = dr[0] - xb;
