@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libevcont_hip.so")
 LAYOUT_FULL6, LAYOUT_PAIR5, LAYOUT_ELEC3, LAYOUT_PACK2 = 6, 5, 3, 2
 LAYOUT_SYM8 = 8   # device-side 8-fold compressed layout (include/evcont_hip.h EVC_LAYOUT_SYM8)
 FLAG_ENERGY_ONLY, FLAG_PARTIAL_RANK, FLAG_WARM_START, FLAG_IP1_S2KL, FLAG_ERI_S4, FLAG_LOEWDIN_DONE = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_double_p = C.c_void_p  # device pointers travel as integers
 
@@ -67,19 +67,20 @@ SIGNATURES = {
                                            C.c_void_p, C.c_void_p]),
     "evc_loewdin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p]),
+    "evc_subspace_solve_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "evc_subspace_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p]),
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_subspace_solve_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_integrals_oao_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "evc_integrals_oao_batch": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_workspace_bytes": (C.c_size_t, [C.POINTER(TrdmSet), C.c_int]),
-    "evc_phase_hamiltonian": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(Geometry), C.c_void_p, C.c_size_t,
+    "evc_phase_hamiltonian": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(Geometry), C.c_int, C.c_void_p, C.c_size_t,
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
     "evc_phase_solve": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(Geometry), C.c_void_p, C.POINTER(Outputs),
-                                  C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                  C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_phase_gradient": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(Geometry), C.POINTER(Outputs), C.c_int,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_phase_set_coeffs": (C.c_int, [C.POINTER(TrdmSet), C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -90,10 +91,11 @@ SIGNATURES = {
                                              C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_phase_loewdin_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.c_int, C.c_void_p, C.c_size_t,
                                           C.c_void_p]),
-    "evc_phase_hamiltonian_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.c_void_p, C.c_int64,
-                                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "evc_phase_hamiltonian_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.c_int, C.c_void_p,
+                                              C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_phase_solve_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.c_void_p, C.c_int64,
-                                        C.POINTER(OutputsBatch), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                        C.POINTER(OutputsBatch), C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
     "evc_phase_gradient_batch": (C.c_int, [C.POINTER(TrdmSet), C.POINTER(GeometryBatch), C.POINTER(OutputsBatch),
                                            C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "evc_grad_elec_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -68,9 +68,12 @@ def subspace_energies(H: torch.Tensor, S: torch.Tensor, e_shift: Optional[torch.
     evals = torch.empty((count, T), dtype=F64, device=H.device)
     evecs = torch.empty((count, T, T), dtype=F64, device=H.device)
     es = e_shift.contiguous() if e_shift is not None else None
+    nws = lib.evc_subspace_solve_ws_bytes(T, count)   # 0 for T <= 32
+    ws = torch.empty(nws, dtype=torch.uint8, device=H.device) if nws else None
     check(lib.evc_subspace_solve_batch(H.data_ptr(), S.data_ptr(), 0 if shared else T * T, T, count, int(nroots),
                                        es.data_ptr() if es is not None else None, evals.data_ptr(),
-                                       evecs.data_ptr(), _stream_ptr(H.device)), "evc_subspace_solve_batch")
+                                       evecs.data_ptr(), ws.data_ptr() if ws is not None else None, nws,
+                                       _stream_ptr(H.device)), "evc_subspace_solve_batch")
     return evals[:, :nroots]
 
 

@@ -176,9 +176,17 @@ struct SolveArgs {
     int fast;                     // set by launch_subspace_solve: FP32 Jacobi + FP64 refinement for T <= 32
     double *bcache;               // (2, T, T) + g*sw or NULL: the lower triangle of the overlap matrix the cached
                                   // B = L^-1 (second block) was computed from -- S_train does not depend on the
-                                  // geometry, so every call after the first finds its factorisation here (T <= 32)
+                                  // geometry, so every call after the first finds its factorisation here
+                                  // (T > kSubspaceSmallT: two blocks of Tp^2, Tp = T rounded up to 16, B at pitch Tp)
+    double *scratch;              // T > kSubspaceSmallT: subspace_big_scratch_doubles(T) doubles + g*sscratch
+    int64_t sscratch;
 };
+constexpr int kSubspaceSmallT = 32;   // up to here: the register / 32 x 32-tile kernel of dense_small.hip
+constexpr int kSubspaceMaxT = 512;    // beyond kSubspaceSmallT: subspace_big.hip (LDS-resident up to 128, then global)
 int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st);
+// subspace_big.hip: T > kSubspaceSmallT (vstd, when given, holds Tp^2 doubles: the eigenvectors as ROWS at pitch Tp)
+size_t subspace_big_scratch_doubles(int T);
+int launch_subspace_big(const SolveArgs &a, int count, hipStream_t st);
 // Weights of the t-RDM rows for the predicted RDMs of a GIVEN coefficient vector c[T] (gradients_loewdin.py:343-356):
 // w1[a*T+b] = c_a c_b; w2 = the slice [w2_offset, +w2_count) of the two-body row weights (pairs: 2 c_a c_b, c_a^2 on
 // the diagonal; otherwise c_a c_b).

@@ -85,6 +85,7 @@ struct Ws {
     // eigenvectors kept from call to call for EVC_FLAG_WARM_START (U above serves the Loewdin step)
     double *vstd;
     double *bcache;   // (2, T, T): overlap matrix (lower triangle) and the inverse Cholesky factor computed from it
+    double *sbig;     // T > kSubspaceSmallT: scratch of the large-T subspace kernel (subspace_big.hip)
     bool warm;
     bool loewdin_done;   // X, U, s, h1 are already in the workspace (EVC_FLAG_LOEWDIN_DONE)
     size_t bytes;    // of ONE geometry
@@ -132,7 +133,8 @@ static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout =
 static int check_set(const evc_trdm_set *t) {
     EVC_REQUIRE(t != nullptr, "trdm_set is NULL");
     EVC_REQUIRE(t->n >= 1 && t->n <= 64, "trdm_set: n=%d out of range 1..64", t->n);
-    EVC_REQUIRE(t->ntrain >= 1 && t->ntrain <= 64, "trdm_set: ntrain=%d out of range 1..64", t->ntrain);
+    EVC_REQUIRE(t->ntrain >= 1 && t->ntrain <= kSubspaceMaxT, "trdm_set: ntrain=%d out of range 1..%d", t->ntrain,
+                kSubspaceMaxT);
     EVC_REQUIRE(t->layout == 6 || t->layout == 5 || t->layout == 3 || t->layout == 2 || t->layout == EVC_LAYOUT_SYM8,
                 "trdm_set: layout=%d (must be the ndim of two_RDM: 6, 5, 3 or 2, or EVC_LAYOUT_SYM8)", t->layout);
     const int64_t n2 = (int64_t)t->n * t->n, ns = (int64_t)t->n * (t->n + 1) / 2;
@@ -196,8 +198,11 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.term3 = take((size_t)(natm > 0 ? natm : 1) * 3);
     w.evals = take(T);
     w.evecs = take(T * T);
-    w.vstd = take(((T + 1) & ~(size_t)1) * ((T + 1) & ~(size_t)1));
-    w.bcache = take(2 * T * T);
+    const size_t Tp = (T + 15) & ~(size_t)15;   // T > kSubspaceSmallT: matrices at pitch Tp (subspace_big.hip)
+    const bool bigT = T > (size_t)kSubspaceSmallT;
+    w.vstd = take(bigT ? Tp * Tp : ((T + 1) & ~(size_t)1) * ((T + 1) & ~(size_t)1));
+    w.bcache = take(bigT ? 2 * Tp * Tp : 2 * T * T);
+    w.sbig = take(bigT ? subspace_big_scratch_doubles((int)T) : 0);
     w.warm = false;
     w.loewdin_done = false;
     w.bytes = off;
@@ -420,6 +425,8 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
     a.w2_count = t->rows2;
     a.vstd = w.vstd;
     a.bcache = w.bcache;
+    a.scratch = w.sbig;
+    a.sscratch = sw;
     a.warm = w.warm ? 1 : 0;
     const int pr = prof_start(EVC_PROF_SUBSPACE, st);
     const int rc = launch_subspace_solve(a, g.count, st);
@@ -813,10 +820,13 @@ extern "C" size_t evc_workspace_bytes_batch(const evc_trdm_set *t, int natm, int
     hipStream_t st = as_stream(stream);                                                           \
     const Geo geo = geo_single(g)
 
-extern "C" int evc_phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, void *ws, size_t ws_bytes,
+extern "C" int evc_phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, int flags, void *ws, size_t ws_bytes,
                                      double **h2rows_local, double **h1rows, void *stream) {
     EVC_SETUP(false);
-    int rc = phase_hamiltonian(t, geo, w, true, st);
+    w.warm = (flags & EVC_FLAG_WARM_START) != 0;
+    Geo gg = geo;
+    gg.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
+    int rc = phase_hamiltonian(t, gg, w, true, st);
     if (rc) return rc;
     if (h2rows_local) *h2rows_local = w.h2rows + t->row_offset;
     if (h1rows) *h1rows = w.h1part;
@@ -824,9 +834,10 @@ extern "C" int evc_phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *
 }
 
 extern "C" int evc_phase_solve(const evc_trdm_set *t, const evc_geometry *g, const double *h2rows_all,
-                               const evc_outputs *out, int nroots, void *ws, size_t ws_bytes, void *stream) {
+                               const evc_outputs *out, int nroots, int flags, void *ws, size_t ws_bytes, void *stream) {
     EVC_SETUP(false);
     EVC_REQUIRE(nroots >= 1 && nroots <= t->ntrain, "nroots=%d out of range 1..%d", nroots, t->ntrain);
+    w.warm = (flags & EVC_FLAG_WARM_START) != 0;
     return phase_solve(t, geo, h2rows_all ? h2rows_all : w.h2rows, 0, out_single(out), nroots, w, st);
 }
 
@@ -971,8 +982,9 @@ extern "C" int evc_phase_loewdin_batch(const evc_trdm_set *t, const evc_geometry
     return launch_loewdin(la, gb->count, as_stream(stream));
 }
 
-extern "C" int evc_phase_hamiltonian_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, double *rows_out,
-                                           int64_t ld_rows_out, void *ws, size_t ws_bytes, void *stream) {
+extern "C" int evc_phase_hamiltonian_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, int flags,
+                                           double *rows_out, int64_t ld_rows_out, void *ws, size_t ws_bytes,
+                                           void *stream) {
     Ws w;
     Geo g;
     Out o;
@@ -980,12 +992,15 @@ extern "C" int evc_phase_hamiltonian_batch(const evc_trdm_set *t, const evc_geom
     EVC_REQUIRE(t->rows2 == 0 || (rows_out && ld_rows_out >= t->rows2),
                 "evc_phase_hamiltonian_batch: rows_out NULL or ld_rows_out=%lld < rows2=%lld", (long long)ld_rows_out,
                 (long long)t->rows2);
+    w.warm = (flags & EVC_FLAG_WARM_START) != 0;
+    w.loewdin_done = (flags & EVC_FLAG_LOEWDIN_DONE) != 0;
+    g.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
     return phase_hamiltonian(t, g, w, true, as_stream(stream), rows_out, ld_rows_out);
 }
 
 extern "C" int evc_phase_solve_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, const double *h2rows_all,
-                                     int64_t ld_rows_all, const evc_outputs_batch *ob, int nroots, void *ws,
-                                     size_t ws_bytes, void *stream) {
+                                     int64_t ld_rows_all, const evc_outputs_batch *ob, int nroots, int flags,
+                                     void *ws, size_t ws_bytes, void *stream) {
     Ws w;
     Geo g;
     Out o;
@@ -996,6 +1011,7 @@ extern "C" int evc_phase_solve_batch(const evc_trdm_set *t, const evc_geometry_b
                 "evc_phase_solve_batch: h2rows_all NULL or ld_rows_all=%lld < rows2_total=%lld",
                 (long long)ld_rows_all, (long long)t->rows2_total);
     replan(t, w, g.count);
+    w.warm = (flags & EVC_FLAG_WARM_START) != 0;
     return phase_solve(t, g, h2rows_all, ld_rows_all, o, nroots, w, as_stream(stream));
 }
 
@@ -1010,11 +1026,18 @@ extern "C" int evc_phase_gradient_batch(const evc_trdm_set *t, const evc_geometr
     return phase_gradient(t, g, o, flags, w, as_stream(stream));
 }
 
+extern "C" size_t evc_subspace_solve_ws_bytes(int T, int count) {
+    if (T <= kSubspaceSmallT || T > kSubspaceMaxT || count < 1) return 0;
+    return sizeof(double) * subspace_big_scratch_doubles(T) * (size_t)count;
+}
+
 extern "C" int evc_subspace_solve(const double *h1rows, const double *h2rows, const double *S_train, int T,
                                   int layout, int nroots, double e_shift, double *evals, double *evecs,
-                                  double *w2, double *w1, double *Hout, void *stream) {
+                                  double *w2, double *w1, double *Hout, void *ws, size_t ws_bytes, void *stream) {
     EVC_REQUIRE(h1rows && h2rows && S_train && evals && evecs, "evc_subspace_solve: null pointer");
-    EVC_REQUIRE(T >= 1 && T <= 64, "evc_subspace_solve: T=%d out of range 1..64", T);
+    EVC_REQUIRE(T >= 1 && T <= kSubspaceMaxT, "evc_subspace_solve: T=%d out of range 1..%d", T, kSubspaceMaxT);
+    EVC_REQUIRE(T <= kSubspaceSmallT || (ws && aligned16(ws) && ws_bytes >= evc_subspace_solve_ws_bytes(T, 1)),
+                "evc_subspace_solve: T=%d needs a workspace of evc_subspace_solve_ws_bytes(T, 1) bytes", T);
     EVC_REQUIRE(layout == 6 || layout == 5 || layout == 3 || layout == 2 || layout == EVC_LAYOUT_SYM8,
                 "evc_subspace_solve: layout=%d", layout);
     EVC_REQUIRE(nroots >= 1 && nroots <= T, "evc_subspace_solve: nroots=%d out of range", nroots);
@@ -1038,14 +1061,17 @@ extern "C" int evc_subspace_solve(const double *h1rows, const double *h2rows, co
     a.Hout = Hout;
     a.w2_offset = 0;
     a.w2_count = is_pairs(layout) ? (int64_t)T * (T + 1) / 2 : (int64_t)T * T;
+    a.scratch = static_cast<double *>(ws);
     return launch_subspace_solve(a, 1, as_stream(stream));
 }
 
 extern "C" int evc_subspace_solve_batch(const double *H, const double *S, int64_t s_stride, int T, int count,
                                         int nroots, const double *e_shift, double *evals, double *evecs,
-                                        void *stream) {
+                                        void *ws, size_t ws_bytes, void *stream) {
     EVC_REQUIRE(H && S && evals && evecs, "evc_subspace_solve_batch: null pointer");
-    EVC_REQUIRE(T >= 1 && T <= 64, "evc_subspace_solve_batch: T=%d out of range 1..64", T);
+    EVC_REQUIRE(T >= 1 && T <= kSubspaceMaxT, "evc_subspace_solve_batch: T=%d out of range 1..%d", T, kSubspaceMaxT);
+    EVC_REQUIRE(T <= kSubspaceSmallT || (ws && aligned16(ws) && ws_bytes >= evc_subspace_solve_ws_bytes(T, count)),
+                "evc_subspace_solve_batch: T=%d needs a workspace of evc_subspace_solve_ws_bytes(T, count) bytes", T);
     EVC_REQUIRE(count >= 1 && count <= (1 << 24), "evc_subspace_solve_batch: count=%d out of range", count);
     EVC_REQUIRE(nroots >= 1 && nroots <= T, "evc_subspace_solve_batch: nroots=%d out of range", nroots);
     EVC_REQUIRE(s_stride == 0 || s_stride >= (int64_t)T * T, "evc_subspace_solve_batch: s_stride=%lld",
@@ -1068,6 +1094,8 @@ extern "C" int evc_subspace_solve_batch(const double *H, const double *S, int64_
     a.sev = T;
     a.evecs = evecs;
     a.svec = (int64_t)T * T;
+    a.scratch = static_cast<double *>(ws);
+    a.sscratch = T > kSubspaceSmallT ? (int64_t)subspace_big_scratch_doubles(T) : 0;
     return launch_subspace_solve(a, count, as_stream(stream));
 }
 

@@ -1,0 +1,492 @@
+// K6 for LARGE training sets (T > 32): the subspace generalised eigenproblem H c = E S c of
+// ab_initio_eigenvector_continuation.py:73-88 / :157-173 with LAPACK dsygvd semantics (lower triangles,
+// Cholesky of S, c^T S c = 1) and the row weights of ab_initio_gradients_loewdin.py:343-356, for training sets the
+// register / 32 x 32-tile kernel of dense_small.hip cannot hold.  The reference puts no bound on T (its Zundel
+// learning curve evaluates 80 and 100 training states, scripts/MD/Zundel_thermodynamics/continuation/
+// 05_Zundel_test_potential_energy.py:182-210; converge_EVCont_MD grows T without bound, MD_utils.py:128-502).
+//
+// One workgroup of 1024 threads (16 waves) per problem.  ONE T x T matrix lives in LDS at a time (128 KB at T = 128):
+//   (a) [only when the cached factor does not match] L = chol(S) right-looking in LDS, inverted in place, B = L^-1
+//       written to global memory (the per-workspace cache: S_train does not depend on the geometry);
+//   (b) H assembled from the span partials in LDS, symmetrised from its lower triangle;
+//   (c) W = B Hs and C = W B^T as "row . row" products on the FP64 matrix cores (16 x 16 tiles dealt to the 16 waves,
+//       operands read with 16-byte loads from L2-resident global scratch / LDS);
+//   (d) eigen-decomposition of C + sigma I (sigma: Gershgorin bound, makes it positive definite) by one-sided
+//       (Hestenes) Jacobi on its columns in LDS: 16 lanes per column pair, 16-byte conflict-free LDS rows, the three dot
+//       products reduced over a DPP row, one barrier per round-robin step; at convergence column j is
+//       (lambda_j + sigma) v_j, so no eigenvector matrix is carried through the rotations;
+//   (e) ascending order, back-transformation c = B^T y, weights.
+// With EVC_FLAG_WARM_START the sweeps start from G0 = (C + sigma I) V_prev (V_prev checked for orthonormality).
+// The same code runs with the matrix in global memory (template parameter) for T beyond what LDS holds.
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace evc {
+
+constexpr int kBT = 1024;   // threads of the workgroup
+constexpr int kBW = kBT / 64;
+typedef double d4b __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double sum8(double v) {    // over the 8 lanes of a half DPP row, every lane gets the total
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ double sum16(double v) {   // over the 16 lanes of a DPP row
+    v = sum8(v);
+    v += dpp_move<0x140>(v);
+    return v;
+}
+
+// block-wide reductions over the 16 waves (red: kBW doubles of LDS); all threads get the result
+__device__ __forceinline__ double big_block_sum(double v, double *red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBW; ++w) t += red[w];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ double big_nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ double big_block_max(double v, double *red) {   // NaN-propagating
+    v = big_nanmax(v, dpp_move<0xB1>(v));
+    v = big_nanmax(v, dpp_move<0x4E>(v));
+    v = big_nanmax(v, dpp_move<0x141>(v));
+    v = big_nanmax(v, dpp_move<0x140>(v));
+    v = big_nanmax(big_nanmax(readlane_f64(v, 0), readlane_f64(v, 16)), big_nanmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < kBW; ++w) t = big_nanmax(t, red[w]);
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ bool big_block_any(bool b, double *red) {
+    const unsigned long long m = __ballot(b);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m ? 1.0 : 0.0;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBW; ++w) t += red[w];
+    __syncthreads();
+    return t != 0.0;
+}
+
+// D[i][j] = sum_k P[i][k] Q[j][k], i, j, k < Tp (Tp a multiple of 16; pitches even, rows 16-byte aligned, padding zero).
+// v_mfma_f64_16x16x4_f64: A[i][k]: lane l holds i = l & 15, k slot l >> 4; B the same with j; D[i][j]: j = l & 15,
+// i = (l >> 4) + 4 reg.  A lane reads the two adjacent columns 8 kk + 2 (l >> 4), +1 of "its" row with one 16-byte load
+// and feeds .x / .y to two MFMAs (the K slot of a lane may be any column as long as A and B agree).
+template <typename Store>
+__device__ __forceinline__ void big_mm_rr(int Tp, const double *__restrict__ P, int ldp, const double *__restrict__ Q,
+                                          int ldq, Store store) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nt = Tp >> 4;
+    for (int t = wave; t < nt * nt; t += kBW) {
+        const int ti = t / nt, tj = t - ti * nt;
+        const double *pr = P + (size_t)(16 * ti + l15) * ldp + 2 * l4;
+        const double *qr = Q + (size_t)(16 * tj + l15) * ldq + 2 * l4;
+        d4b acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int k = 0; k < Tp; k += 8) {
+            const double2 av = *reinterpret_cast<const double2 *>(pr + k);
+            const double2 bv = *reinterpret_cast<const double2 *>(qr + k);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store(16 * ti + l4 + 4 * r, 16 * tj + l15, acc[r]);
+    }
+}
+
+__device__ __forceinline__ void big_pair_of(int step, int k, int m, int &p, int &q) {   // round-robin tournament
+    const int w = m - 1;
+    p = step + k;
+    if (p >= w) p -= w;
+    if (k == 0) p = w;
+    q = step + w - k;
+    if (q >= w) q -= w;
+}
+
+// One-sided Jacobi on the m columns (m even) of G, stored column-major with pitch Pj (a multiple of 32; rows >= the
+// matrix size are zero).  Pair k of a step belongs to the 16 lanes [16 k, 16 k + 16): lane s owns rows 2 s, 2 s + 1
+// (+ 32 u) -- the 16 lanes of a pair read 256 contiguous bytes.  Convergence: every pair orthogonal to 1e-9 BEFORE its
+// rotation in a sweep (the rotations of that sweep then leave ~1e-18).
+__device__ __forceinline__ void big_jacobi(double *G, int m, int Pj, double *red) {
+    const int tid = threadIdx.x, s = tid & 15;
+    const int half = m >> 1, nu = Pj >> 5;
+    const int npass = (half + (kBT / 16) - 1) / (kBT / 16);   // 1 for m <= 128
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool bad = false;
+        for (int step = 0; step < m - 1; ++step) {
+            for (int pass = 0; pass < npass; ++pass) {
+                const int k = (tid >> 4) + pass * (kBT / 16);
+                if (k < half) {   // uniform over the DPP row
+                    int p, q;
+                    big_pair_of(step, k, m, p, q);
+                    double *gp = G + (size_t)p * Pj + 2 * s, *gq = G + (size_t)q * Pj + 2 * s;
+                    double al = 0.0, be = 0.0, ga = 0.0;
+                    double2 x[4], y[4];   // the whole share of this lane when Pj <= 128 (the LDS-resident case)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = y[u] = make_double2(0.0, 0.0);
+                    for (int u0 = 0; u0 < nu; u0 += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u0 + u < nu) {
+                                x[u] = *reinterpret_cast<const double2 *>(gp + 32 * (u0 + u));
+                                y[u] = *reinterpret_cast<const double2 *>(gq + 32 * (u0 + u));
+                            }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u0 + u < nu) {
+                                al = fma(x[u].x, x[u].x, fma(x[u].y, x[u].y, al));
+                                be = fma(y[u].x, y[u].x, fma(y[u].y, y[u].y, be));
+                                ga = fma(x[u].x, y[u].x, fma(x[u].y, y[u].y, ga));
+                            }
+                    }
+                    al = sum16(al);
+                    be = sum16(be);
+                    ga = sum16(ga);
+                    const double ab = al * be, g2 = ga * ga;
+                    const bool rot = g2 > 1.0e-30 * ab;
+                    bad = bad || (g2 > 1.0e-18 * ab);
+                    if (rot) {   // uniform over the row
+                        // t = sgn(d) b / (|d| + sqrt(d^2 + b^2)), d = beta - alpha, b = 2 gamma (the smaller root); the
+                        // angle only has to make g_p . g_q small, c is refined to full precision (c^2 + s^2 = 1)
+                        const double d = be - al, b = 2.0 * ga;
+                        const double h2 = fma(d, d, b * b);
+                        double yv = __builtin_amdgcn_rsq(h2);
+                        yv = yv * fma(-0.5 * h2 * yv, yv, 1.5);
+                        const double den = fabs(d) + h2 * yv;
+                        double r = __builtin_amdgcn_rcp(den);
+                        r = r * fma(-den, r, 2.0);
+                        const double t = copysign(b, d * b == 0.0 ? b : d * b) * r;
+                        const double xx = fma(t, t, 1.0);
+                        double z = __builtin_amdgcn_rsq(xx);
+                        z = z * fma(-0.5 * xx * z, z, 1.5);
+                        z = z * fma(-0.5 * xx * z, z, 1.5);
+                        z = z * fma(-0.5 * xx * z, z, 1.5);
+                        const double c = z, sn = t * z;
+                        if (nu <= 4) {   // uniform: rotate the registers
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (u < nu) {
+                                    double2 a2, b2;
+                                    a2.x = c * x[u].x - sn * y[u].x;
+                                    a2.y = c * x[u].y - sn * y[u].y;
+                                    b2.x = sn * x[u].x + c * y[u].x;
+                                    b2.y = sn * x[u].y + c * y[u].y;
+                                    *reinterpret_cast<double2 *>(gp + 32 * u) = a2;
+                                    *reinterpret_cast<double2 *>(gq + 32 * u) = b2;
+                                }
+                        } else {
+                            for (int u = 0; u < nu; ++u) {
+                                const double2 xv = *reinterpret_cast<const double2 *>(gp + 32 * u);
+                                const double2 yw = *reinterpret_cast<const double2 *>(gq + 32 * u);
+                                double2 a2, b2;
+                                a2.x = c * xv.x - sn * yw.x;
+                                a2.y = c * xv.y - sn * yw.y;
+                                b2.x = sn * xv.x + c * yw.x;
+                                b2.y = sn * xv.y + c * yw.y;
+                                *reinterpret_cast<double2 *>(gp + 32 * u) = a2;
+                                *reinterpret_cast<double2 *>(gq + 32 * u) = b2;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (!big_block_any(bad, red)) break;
+    }
+}
+
+// In-place Cholesky factor of the lower triangle in M (pitch Tp) followed by its in-place inverse: on return the lower
+// triangle of M holds B = L^-1.  A matrix that is not positive definite yields NaNs.  dinv, tmp: T doubles each.
+__device__ __forceinline__ void big_chol_inverse(double *M, int T, int Tp, double *dinv, double *tmp) {
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    for (int j = 0; j < T; ++j) {
+        const double d = M[(size_t)j * Tp + j];
+        double rs = __builtin_amdgcn_rsq(d);
+        rs = rs * fma(-0.5 * d * rs, rs, 1.5);
+        rs = rs * fma(-0.5 * d * rs, rs, 1.5);
+        if (tid == 0) dinv[j] = rs;   // 1 / L_jj (the diagonal itself is fixed up below)
+        for (int i = j + 1 + tid; i < T; i += kBT) M[(size_t)i * Tp + j] *= rs;
+        __syncthreads();
+        for (int i = j + 1 + ty; i < T; i += 32) {
+            const double lij = M[(size_t)i * Tp + j];
+            for (int k = j + 1 + tx; k <= i; k += 32) M[(size_t)i * Tp + k] = fma(-lij, M[(size_t)k * Tp + j], M[(size_t)i * Tp + k]);
+        }
+        __syncthreads();
+    }
+    // inverse, column by column from the last: new column j below the diagonal = -(L22^-1 c) / L_jj
+    const int l8 = tid & 7, r8 = tid >> 3;
+    for (int j = T - 1; j >= 0; --j) {
+        for (int i = j + 1 + r8; i < T; i += kBT / 8) {   // (the eight lanes of a group share i)
+            double t = 0.0;
+            for (int k = j + 1 + l8; k <= i; k += 8) t = fma(M[(size_t)i * Tp + k], M[(size_t)k * Tp + j], t);
+            t = sum8(t);
+            if (l8 == 0) tmp[i] = t;
+        }
+        __syncthreads();
+        const double ajj = dinv[j];
+        for (int i = j + 1 + tid; i < T; i += kBT) M[(size_t)i * Tp + j] = -tmp[i] * ajj;
+        if (tid == 0) M[(size_t)j * Tp + j] = ajj;
+        __syncthreads();
+    }
+}
+
+template <bool kLds>
+__global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
+    extern __shared__ __align__(16) double sm[];
+    {
+        const int64_t g = blockIdx.x;
+        a.h1part += g * a.sh1;
+        if (a.h2part) a.h2part += g * a.sh2;
+        a.S += g * a.sS;
+        a.evals += g * a.sev;
+        a.evecs += g * a.svec;
+        if (a.Hout) a.Hout += g * a.sH;
+        if (a.w1) a.w1 += g * a.sw;
+        if (a.w2) a.w2 += g * a.sw;
+        if (a.w2t) a.w2t += (g - g % kMaxBatchG) * a.sw;
+        if (a.vstd) a.vstd += g * a.sw;
+        if (a.bcache) a.bcache += g * a.sw;
+        a.scratch += g * a.sscratch;
+        if (a.e_shift_dev) a.e_shift = a.e_shift_dev[g];
+    }
+    const int T = a.T, m = (T + 1) & ~1, Tp = (T + 15) & ~15, Pj = (m + 31) & ~31;
+    const size_t Tp2 = (size_t)Tp * Tp;
+    const size_t msz = (size_t)m * Pj > Tp2 ? (size_t)m * Pj : Tp2;
+    // global scratch: [B (when there is no cache) | W | C | the matrix itself when it does not fit LDS]
+    double *Bg = a.bcache ? a.bcache + Tp2 : a.scratch;
+    double *Wg = a.scratch + Tp2, *Cg = a.scratch + 2 * Tp2;
+    double *M = kLds ? sm : a.scratch + 3 * Tp2;
+    double *aux = kLds ? sm + msz : sm;
+    double *ev = aux, *tmp = ev + Tp, *c0 = tmp + Tp, *dinv = c0 + Tp, *red = dinv + Tp;
+    int *order = reinterpret_cast<int *>(red + 2 * kBW);
+    const int tid = threadIdx.x;
+    const int64_t P = (int64_t)T * (T + 1) / 2;
+    const bool pairs = (a.layout == EVC_LAYOUT_PAIR5 || a.layout == EVC_LAYOUT_PACK2 || a.layout == EVC_LAYOUT_SYM8);
+    const int64_t rows2 = pairs ? P : (int64_t)T * T;
+
+    // (a) B = L^-1: from the cache when the overlap matrix it was computed from is bit-identical to this call's
+    bool hit = false;
+    if (a.bcache) {
+        bool diff = false;
+        for (int idx = tid; idx < T * T; idx += kBT) {
+            const int i = idx / T, j = idx - i * T;
+            if (i >= j) diff = diff || !(a.bcache[idx] == a.S[idx]);
+        }
+        hit = !big_block_any(diff, red);
+    }
+    if (!hit) {   // uniform
+        for (size_t idx = tid; idx < Tp2; idx += kBT) {
+            const int i = (int)(idx / Tp), j = (int)(idx - (size_t)i * Tp);
+            M[idx] = (i < T && j <= i) ? a.S[(size_t)i * T + j] : 0.0;
+        }
+        __syncthreads();
+        big_chol_inverse(M, T, Tp, dinv, tmp);
+        for (size_t idx = tid; idx < Tp2; idx += kBT) {
+            const int i = (int)(idx / Tp), j = (int)(idx - (size_t)i * Tp);
+            Bg[idx] = (i < T && j <= i) ? M[idx] : 0.0;
+        }
+        if (a.bcache)
+            for (int idx = tid; idx < T * T; idx += kBT) a.bcache[idx] = a.S[idx];
+        __syncthreads();
+    }
+    // (b) H from the span partials (stored [span][row]), placed as the reference does (evcont.py:41-68)
+    for (size_t idx = tid; idx < Tp2; idx += kBT) M[idx] = 0.0;
+    __syncthreads();
+    for (int r = tid; r < T * T; r += kBT) {
+        double s = 0.0;
+        for (int k = 0; k < a.nsp1; ++k) s += a.h1part[(int64_t)k * T * T + r];
+        const int i = r / T;
+        M[(size_t)i * Tp + (r - i * T)] = a.alpha1 * s;
+    }
+    __syncthreads();
+    for (int64_t r = tid; r < rows2; r += kBT) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = 0;
+        for (; k + 4 <= a.nsp2; k += 4) {
+            s0 += a.h2part[(int64_t)(k + 0) * rows2 + r];
+            s1 += a.h2part[(int64_t)(k + 1) * rows2 + r];
+            s2 += a.h2part[(int64_t)(k + 2) * rows2 + r];
+            s3 += a.h2part[(int64_t)(k + 3) * rows2 + r];
+        }
+        for (; k < a.nsp2; ++k) s0 += a.h2part[(int64_t)k * rows2 + r];
+        const double s = (s0 + s1) + (s2 + s3);
+        int ia, ib;
+        if (pairs) {
+            ia = (int)tri_row(r);
+            ib = (int)(r - (int64_t)ia * (ia + 1) / 2);
+        } else {
+            ia = (int)(r / T);
+            ib = (int)(r - (int64_t)ia * T);
+        }
+        M[(size_t)ia * Tp + ib] += a.alpha2 * s;
+    }
+    __syncthreads();
+    if (a.Hout)
+        for (int idx = tid; idx < T * T; idx += kBT) {
+            const int i = idx / T;
+            a.Hout[idx] = M[(size_t)i * Tp + (idx - i * T)];
+        }
+    __syncthreads();
+    for (int idx = tid; idx < T * T; idx += kBT) {   // Hs from the LOWER triangle (dsygst)
+        const int i = idx / T, j = idx - i * T;
+        if (j > i) M[(size_t)i * Tp + j] = M[(size_t)j * Tp + i];
+    }
+    __syncthreads();
+    // (c) W = B Hs (W[i][k] = sum_l B[i][l] Hs[k][l]);  C = W B^T (C[i][j] = sum_k W[i][k] B[j][k])
+    big_mm_rr(Tp, Bg, Tp, M, Tp, [&](int i, int k, double v) { Wg[(size_t)i * Tp + k] = v; });
+    __syncthreads();
+    big_mm_rr(Tp, Wg, Tp, Bg, Tp, [&](int i, int j, double v) { Cg[(size_t)i * Tp + j] = v; });
+    __syncthreads();
+    // exact symmetry (as the rotations assume) and the Gershgorin bound of the shift
+    for (size_t idx = tid; idx < Tp2; idx += kBT) {
+        const int i = (int)(idx / Tp), j = (int)(idx - (size_t)i * Tp);
+        if (j < i) {
+            const double v = 0.5 * (Cg[idx] + Cg[(size_t)j * Tp + i]);
+            Cg[idx] = v;
+            Cg[(size_t)j * Tp + i] = v;
+        }
+    }
+    __syncthreads();
+    double rmax = 0.0;
+    for (int i = tid; i < T; i += kBT) {
+        double rs = 0.0;
+        for (int j = 0; j < T; ++j) rs += fabs(Cg[(size_t)i * Tp + j]);
+        rmax = big_nanmax(rmax, rs);
+    }
+    rmax = big_block_max(rmax, red);
+    const double shift = 2.0 * rmax + 1.0e-300;   // eigenvalues of the shifted matrix within [1, 3] x the bound
+    // (d) G0, column-major with pitch Pj
+    bool warm = false;
+    if (a.warm && a.vstd) {   // uniform: the previous eigenvectors (rows of vstd, pitch Tp) must be orthonormal
+        double dev = 0.0;
+        big_mm_rr(Tp, a.vstd, Tp, a.vstd, Tp, [&](int i, int j, double v) {
+            const double e = v - ((i == j && i < T) ? 1.0 : 0.0);
+            dev = fma(e, e, dev);
+        });
+        dev = big_block_sum(dev, red);
+        warm = dev < 1.0e-16;   // (NaN: false)
+    }
+    for (size_t idx = tid; idx < (size_t)m * Pj; idx += kBT) {
+        const int j = (int)(idx / Pj), i = (int)(idx - (size_t)j * Pj);
+        double v = 0.0;
+        if (!warm && i < T && j < T) v = Cg[(size_t)i * Tp + j] + (i == j ? shift : 0.0);
+        M[idx] = v;
+    }
+    __syncthreads();
+    if (warm) {   // G[j][i] = sum_k Vt[j][k] C[i][k] + shift Vt[j][i]
+        big_mm_rr(Tp, a.vstd, Tp, Cg, Tp, [&](int j, int i, double v) {
+            if (j < T && i < T) M[(size_t)j * Pj + i] = v + shift * a.vstd[(size_t)j * Tp + i];
+        });
+        __syncthreads();
+    }
+    big_jacobi(M, m, Pj, red);
+    // column norms = eigenvalues + shift; normalised columns = eigenvectors
+    for (int j = tid >> 4; j < m; j += kBT / 16) {
+        const int s = tid & 15;
+        double nn = 0.0;
+        for (int i = 2 * s; i < Pj; i += 32) {
+            const double2 x = *reinterpret_cast<const double2 *>(M + (size_t)j * Pj + i);
+            nn = fma(x.x, x.x, fma(x.y, x.y, nn));
+        }
+        nn = sum16(nn);
+        const double l = sqrt(nn);
+        const double inv = l > 1.0e-300 ? 1.0 / l : 0.0;   // (the decoupled dummy column of an odd problem stays zero)
+        for (int i = 2 * s; i < Pj; i += 32) {
+            double2 x = *reinterpret_cast<const double2 *>(M + (size_t)j * Pj + i);
+            x.x *= inv;
+            x.y *= inv;
+            *reinterpret_cast<double2 *>(M + (size_t)j * Pj + i) = x;
+        }
+        if (s == 0 && j < Tp) ev[j] = l - shift;
+    }
+    __syncthreads();
+    if (a.vstd)
+        for (size_t idx = tid; idx < Tp2; idx += kBT) {
+            const int j = (int)(idx / Tp), i = (int)(idx - (size_t)j * Tp);
+            a.vstd[idx] = (j < T && i < T) ? M[(size_t)j * Pj + i] : 0.0;
+        }
+    // (e) ascending order
+    for (int j = tid; j < T; j += kBT) {
+        int rank = 0;
+        const double v = ev[j];
+        for (int k = 0; k < T; ++k) rank += (ev[k] < v || (ev[k] == v && k < j)) ? 1 : 0;
+        order[rank] = j;
+    }
+    __syncthreads();
+    // back-transformation c_i = sum_{k >= i} B[k][i] y_k for the requested roots
+    for (int idx = tid; idx < a.nroots * T; idx += kBT) {
+        const int root = idx / T, i = idx - root * T, col = order[root];
+        double c = 0.0;
+        for (int k = i; k < T; ++k) c = fma(Bg[(size_t)k * Tp + i], M[(size_t)col * Pj + k], c);
+        a.evecs[idx] = c;
+        if (root == 0) c0[i] = c;
+    }
+    for (int r = tid; r < a.nroots; r += kBT) a.evals[r] = ev[order[r]] + a.e_shift;
+    __syncthreads();
+    // weights of root 0 for the predicted RDMs (gradients_loewdin.py:343-356)
+    if (a.w1)
+        for (int idx = tid; idx < T * T; idx += kBT) {
+            const int ia = idx / T;
+            a.w1[idx] = c0[ia] * c0[idx - ia * T];
+        }
+    if (a.w2) {
+        for (int64_t r = tid; r < a.w2_count; r += kBT) {
+            const int64_t g = r + a.w2_offset;
+            double w;
+            if (pairs) {
+                const int ia = (int)tri_row(g), ib = (int)(g - (int64_t)ia * (ia + 1) / 2);
+                w = (ia == ib) ? c0[ia] * c0[ia] : 2.0 * c0[ia] * c0[ib];
+            } else {
+                const int ia = (int)(g / T);
+                w = c0[ia] * c0[g - (int64_t)ia * T];
+            }
+            a.w2[r] = w;
+            if (a.w2t) a.w2t[r * kMaxBatchG + (int)(blockIdx.x % kMaxBatchG)] = w;
+        }
+    }
+}
+
+static size_t big_aux_bytes(int T) {
+    const int Tp = (T + 15) & ~15;
+    return sizeof(double) * ((size_t)4 * Tp + 2 * kBW) + sizeof(int) * (size_t)Tp + 64;
+}
+static size_t big_matrix_doubles(int T) {
+    const size_t m = (T + 1) & ~1, Tp = (T + 15) & ~15, Pj = (m + 31) & ~(size_t)31;
+    return m * Pj > Tp * Tp ? m * Pj : Tp * Tp;
+}
+static bool big_fits_lds(int T) { return sizeof(double) * big_matrix_doubles(T) + big_aux_bytes(T) <= 160 * 1024; }
+
+size_t subspace_big_scratch_doubles(int T) {
+    const size_t Tp = (T + 15) & ~15;
+    return 3 * Tp * Tp + (big_fits_lds(T) ? 0 : big_matrix_doubles(T));
+}
+
+int launch_subspace_big(const SolveArgs &a, int count, hipStream_t st) {
+    if (!a.scratch) {
+        set_error("subspace solve: T=%d needs a scratch buffer (evc_subspace_solve_ws_bytes)", a.T);
+        return -1;
+    }
+    if (big_fits_lds(a.T)) {
+        const size_t lds = sizeof(double) * big_matrix_doubles(a.T) + big_aux_bytes(a.T);
+        static LdsAttr attr;
+        if (int rc = allow_dynamic_lds(subspace_big_kernel<true>, attr, 160 * 1024, "subspace_big")) return rc;
+        hipLaunchKernelGGL(subspace_big_kernel<true>, dim3(count), dim3(kBT), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(subspace_big_kernel<false>, dim3(count), dim3(kBT), big_aux_bytes(a.T), st, a);
+    }
+    EVC_LAUNCH_CHECK("subspace_big");
+    return 0;
+}
+
+}  // namespace evc

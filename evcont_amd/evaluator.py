@@ -387,7 +387,9 @@ class BatchedEvaluator:
         nbytes = self.lib.evc_workspace_bytes_batch(C.byref(trdms.cstruct), self.natm, self.count)
         if nbytes == 0:
             raise _lib.EvcontHipError("evc_workspace_bytes_batch: " + self.lib.evc_last_error().decode())
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+        # zero-filled once: the cached factorisation of S_train in it is recognised by content (a recycled allocator
+        # block must not look like a hit)
+        self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=d)
         self.ws_bytes = nbytes
         G = self.count
         # energies and gradients share one buffer: a caller that wants both on the host fetches them with ONE copy
@@ -451,10 +453,14 @@ class BatchedEvaluator:
         """Scaled two-body rows of this rank's pairs -> ``rows_out[g, :rows_local]`` (row stride = rows_out.stride(0))."""
         assert rows_out.dtype == F64 and rows_out.dim() == 2 and rows_out.shape[0] == self.count
         assert rows_out.stride(1) == 1 and rows_out.shape[1] >= self.t.rows_local
-        if aob.eri_s4:
-            raise _lib.EvcontHipError("the phase entry points take the full eri (no EVC_FLAG_ERI_S4)")
         g = aob.cstruct()
-        rc = self.lib.evc_phase_hamiltonian_batch(C.byref(self.t.cstruct), C.byref(g), rows_out.data_ptr(),
+        flags = _ip1_flag(self.t, aob) & _lib.FLAG_ERI_S4
+        if getattr(self, "_loewdin_done", False):
+            flags |= _lib.FLAG_LOEWDIN_DONE
+            self._loewdin_done = False
+        if self.warm_start and self._primed:
+            flags |= _lib.FLAG_WARM_START
+        rc = self.lib.evc_phase_hamiltonian_batch(C.byref(self.t.cstruct), C.byref(g), flags, rows_out.data_ptr(),
                                                   int(rows_out.stride(0)), self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_phase_hamiltonian_batch")
 
@@ -462,10 +468,12 @@ class BatchedEvaluator:
         assert rows_all.dtype == F64 and rows_all.dim() == 2 and rows_all.shape[0] == self.count
         assert rows_all.stride(1) == 1 and rows_all.shape[1] >= self.t.rows_total
         g = aob.cstruct()
+        flags = _lib.FLAG_WARM_START if (self.warm_start and self._primed) else 0
         rc = self.lib.evc_phase_solve_batch(C.byref(self.t.cstruct), C.byref(g), rows_all.data_ptr(),
-                                            int(rows_all.stride(0)), C.byref(self.out), int(nroots),
+                                            int(rows_all.stride(0)), C.byref(self.out), int(nroots), flags,
                                             self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_phase_solve_batch")
+        self._primed = True
 
     def phase_gradient(self, aob: DeviceAOBatch, partial_rank: bool) -> None:
         g = aob.cstruct()
@@ -476,58 +484,66 @@ class BatchedEvaluator:
 
 
 class PipelinedBatchedEvaluator:
-    """Batches submitted one after another by a caller that uses ONE stream, with the Loewdin orthogonalisation of
-    the NEXT batch taken off the critical path inside the library: it is a latency-bound kernel on one workgroup per
-    geometry that reads only ``S`` and ``hcore`` (``evc_phase_loewdin_batch``), so it runs on an internal side stream
-    while the current batch's chip-filling kernels execute, into the workspace of a second evaluator; the next
-    ``enqueue`` then skips it (``EVC_FLAG_LOEWDIN_DONE``).  Fork / join with events; results of batch k are in
-    ``self.results(k)`` (two slots, alternating).
+    """Batches submitted one after another by a caller that uses ONE stream, kept ``depth`` deep in flight inside the
+    library: every batch runs on one of ``depth`` internal streams (each with its own workspace and result buffers),
+    forked from the caller's stream at submission and joined to it only when its results are asked for.  The
+    latency-bound single-workgroup kernels of one batch (Loewdin orthogonalisation, subspace solve, gradient tail:
+    a quarter of a batch's time on 32 of 256 CUs) then run beside the chip-filling kernels of its neighbours -- what a
+    caller would otherwise have to arrange with several streams of its own.
 
-        pe = PipelinedBatchedEvaluator(trdms, natm, G)
-        for k, aob in enumerate(batches):
-            pe.enqueue(aob, next_aob=batches[k + 1] if k + 1 < len(batches) else None)
-    """
+        pe = PipelinedBatchedEvaluator(trdms, natm, G)            # depth 3
+        tickets = [pe.enqueue(aob) for aob in batches[:3]]
+        for k, aob in enumerate(batches[3:]):
+            r = pe.results(tickets[k])        # caller's stream now waits for THAT batch (no host synchronisation)
+            ... consume r.energy / r.grad on the caller's stream ...
+            tickets.append(pe.enqueue(aob))   # reuses the slot just consumed
 
-    def __init__(self, trdms: DeviceTRDMs, natm: int, count: int, stream: Optional["torch.cuda.Stream"] = None):
+    Ordering guarantees: a batch starts after everything the caller's stream held at ``enqueue`` (inputs uploaded
+    asynchronously on that stream are complete), and after the previous batch of ITS slot has finished; a slot's
+    buffers are overwritten ``depth`` submissions later, so results must be consumed (or ``results`` called) before
+    then.  ``next_aob`` is accepted for compatibility with the round-2 interface and ignored."""
+
+    def __init__(self, trdms: DeviceTRDMs, natm: int, count: int, stream: Optional["torch.cuda.Stream"] = None,
+                 depth: int = 3, **kw):
         d = trdms.device
-        self.stream = stream if stream is not None else torch.cuda.current_stream(d)
-        self.side = torch.cuda.Stream(d)
-        self.evs = [BatchedEvaluator(trdms, natm, count, stream=self.stream) for _ in range(2)]
-        self._batch_done = [torch.cuda.Event(), torch.cuda.Event()]   # main stream: slot's last batch has finished
-        self._l_done = [torch.cuda.Event(), torch.cuda.Event()]       # side stream: slot's Loewdin prefetch has finished
-        self._prefetched = [None, None]
-        self._used = [False, False]
+        self.device = d
+        self._caller = stream          # None: torch's current stream at call time
+        self.depth = max(1, int(depth))
+        self.streams = [torch.cuda.Stream(d) for _ in range(self.depth)]
+        self.evs = [BatchedEvaluator(trdms, natm, count, stream=self.streams[k], **kw) for k in range(self.depth)]
+        self._submitted = [torch.cuda.Event() for _ in range(self.depth)]   # caller's stream at submission
+        self._done = [torch.cuda.Event() for _ in range(self.depth)]        # internal stream: the slot's batch finished
+        self._busy = [False] * self.depth
         self._k = 0
+
+    def _cs(self) -> "torch.cuda.Stream":
+        return self._caller if self._caller is not None else torch.cuda.current_stream(self.device)
 
     def enqueue(self, aob: DeviceAOBatch, next_aob: Optional[DeviceAOBatch] = None, nroots: int = 1,
                 energy_only: bool = False) -> int:
-        """Enqueue one batch; returns its slot (0 / 1).  ``next_aob``: the batch the NEXT call will submit."""
-        slot = self._k & 1
-        ev = self.evs[slot]
-        if self._prefetched[slot] is aob:
-            self.stream.wait_event(self._l_done[slot])          # join
-        else:
-            ev._loewdin_done = False                            # (a prefetch for another batch is simply dropped)
-        self._prefetched[slot] = None
-        ev.enqueue(aob, nroots, energy_only)
-        self._batch_done[slot].record(self.stream)
-        self._used[slot] = True
-        if next_aob is not None:
-            o = 1 - slot
-            if self._used[o]:
-                self.side.wait_event(self._batch_done[o])       # fork: that workspace is free once ITS batch is done
-            self.evs[o].phase_loewdin(next_aob, stream=self.side)
-            self._l_done[o].record(self.side)
-            self._prefetched[o] = next_aob
+        """Enqueue one batch; returns its slot (the ticket for ``results``)."""
+        slot = self._k % self.depth
         self._k += 1
+        st = self.streams[slot]
+        self._submitted[slot].record(self._cs())
+        st.wait_event(self._submitted[slot])                   # fork (the slot's previous batch precedes on `st` itself)
+        self.evs[slot].enqueue(aob, nroots, energy_only)
+        self._done[slot].record(st)
+        self._busy[slot] = True
         return slot
 
     def results(self, slot: int) -> "BatchedEvaluator":
+        """The evaluator holding the results of the batch submitted under this ticket; the caller's stream is made to
+        wait for it (join)."""
+        if self._busy[slot]:
+            self._cs().wait_event(self._done[slot])
+            self._busy[slot] = False
         return self.evs[slot]
 
     def synchronize(self) -> None:
-        self.stream.synchronize()
-        self.side.synchronize()
+        for st in self.streams:
+            st.synchronize()
+        self._cs().synchronize()
 
 
 class ContinuationEvaluator:
@@ -553,7 +569,7 @@ class ContinuationEvaluator:
         nbytes = self.lib.evc_workspace_bytes(C.byref(trdms.cstruct), self.natm)
         if nbytes == 0:
             raise _lib.EvcontHipError("evc_workspace_bytes: " + self.lib.evc_last_error().decode())
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+        self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=d)   # (zero-filled: see BatchedEvaluator)
         self.ws_bytes = nbytes
         self.energy = torch.zeros(T, dtype=F64, device=d)
         self.coeffs = torch.zeros((T, T), dtype=F64, device=d)
@@ -613,12 +629,13 @@ class ContinuationEvaluator:
     # -- phase API for the pair-sharded multi-GPU host (evcont_amd/distributed.py) -----------------
     def phase_hamiltonian(self, ao: DeviceAO) -> torch.Tensor:
         """Returns a view of this rank's scaled two-body rows (length rows_local) in the workspace."""
-        if ao.eri_s4:
-            raise _lib.EvcontHipError("the phase entry points take the full eri (no EVC_FLAG_ERI_S4)")
         g = ao.cstruct()
         p_rows, p_h1 = C.c_void_p(), C.c_void_p()
-        rc = self.lib.evc_phase_hamiltonian(C.byref(self.t.cstruct), C.byref(g), self.ws.data_ptr(), self.ws_bytes,
-                                            C.byref(p_rows), C.byref(p_h1), self._sp())
+        flags = _ip1_flag(self.t, ao) & _lib.FLAG_ERI_S4
+        if self.warm_start and self._primed:
+            flags |= _lib.FLAG_WARM_START
+        rc = self.lib.evc_phase_hamiltonian(C.byref(self.t.cstruct), C.byref(g), flags, self.ws.data_ptr(),
+                                            self.ws_bytes, C.byref(p_rows), C.byref(p_h1), self._sp())
         check(rc, "evc_phase_hamiltonian")
         off = p_rows.value - self.ws.data_ptr()
         return self.ws[off: off + 8 * self.t.rows_local].view(F64)
@@ -626,9 +643,11 @@ class ContinuationEvaluator:
     def phase_solve(self, ao: DeviceAO, rows_all: torch.Tensor, nroots: int = 1) -> None:
         g = ao.cstruct()
         assert rows_all.dtype == F64 and rows_all.numel() == self.t.rows_total and rows_all.is_contiguous()
+        flags = _lib.FLAG_WARM_START if (self.warm_start and self._primed) else 0
         rc = self.lib.evc_phase_solve(C.byref(self.t.cstruct), C.byref(g), rows_all.data_ptr(), C.byref(self.out),
-                                      int(nroots), self.ws.data_ptr(), self.ws_bytes, self._sp())
+                                      int(nroots), flags, self.ws.data_ptr(), self.ws_bytes, self._sp())
         check(rc, "evc_phase_solve")
+        self._primed = True
 
     def phase_set_coeffs(self, coeffs: torch.Tensor) -> None:
         """Row weights of the predicted RDMs from a caller-supplied coefficient vector (``evc_phase_set_coeffs``)."""
@@ -666,6 +685,8 @@ class ContinuationEvaluator:
         self._primed = False      # the workspace no longer holds a converged Hermitian solve
         g = self.grad[: self.natm].cpu().numpy().copy()
         if return_density_matrices:
+            if self.g_pred is None:
+                raise _lib.EvcontHipError("this evaluator was built with want_two_rdm=False")
             return e + ao.enuc, g, self.d_pred.cpu().numpy().copy(), self.g_pred.cpu().numpy().copy()
         return e + ao.enuc, g
 

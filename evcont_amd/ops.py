@@ -129,7 +129,10 @@ def subspace_solve(h1rows: torch.Tensor, h2rows: torch.Tensor, S: torch.Tensor, 
     w2 = torch.empty(h2rows.numel(), dtype=F64, device=d)
     w1 = torch.empty(T * T, dtype=F64, device=d)
     H = torch.empty((T, T), dtype=F64, device=d)
+    nws = lib.evc_subspace_solve_ws_bytes(T, 1)   # 0 for T <= 32
+    ws = torch.empty(nws, dtype=torch.uint8, device=d) if nws else None
     check(lib.evc_subspace_solve(h1rows.data_ptr(), h2rows.data_ptr(), S.data_ptr(), T, layout, nroots,
                                  float(e_shift), ev.data_ptr(), vec.data_ptr(), w2.data_ptr(), w1.data_ptr(),
-                                 H.data_ptr(), _s(S)), "evc_subspace_solve")
+                                 H.data_ptr(), ws.data_ptr() if ws is not None else None, nws, _s(S)),
+          "evc_subspace_solve")
     return ev, vec, w2, w1, H

@@ -29,9 +29,11 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 6 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
+#define EVC_ABI_VERSION 7 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
                              3: EVC_LAYOUT_SYM8; 4: evc_profile_stage/_select, EVC_FLAG_IP1_S2KL, EVC_FLAG_ERI_S4;
-                             5: evc_phase_set_coeffs; 6: evc_phase_loewdin_batch, EVC_FLAG_LOEWDIN_DONE */
+                             5: evc_phase_set_coeffs; 6: evc_phase_loewdin_batch, EVC_FLAG_LOEWDIN_DONE;
+                             7: training sets of up to 512 states (evc_subspace_solve[_batch] take a workspace,
+                                evc_subspace_solve_ws_bytes), `flags` argument of the phase A / B entry points */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
@@ -122,11 +124,17 @@ int evc_loewdin(const double *S, const double *hcore, int n, double *X, double *
  *   Outputs: evals[nroots] ascending (+ e_shift), evecs[nroots*T] (row k = k-th vector),
  *   w2[rows2] / w1[T*T]: weights of the two-/one-body t-RDM rows for the predicted RDMs of
  *   root 0 (ab_initio_gradients_loewdin.py:343-356), Hout[T*T] (may be NULL): the matrix handed
- *   to the eigensolver.  T <= 64.  Hermitian branch only.
+ *   to the eigensolver.  Hermitian branch only.
+ *   T <= 512 (the reference has no bound: its Zundel learning curve uses 80 and 100 training states,
+ *   scripts/MD/Zundel_thermodynamics/continuation/05_Zundel_test_potential_energy.py:182-210).  T <= 32 runs in the
+ *   registers / LDS of one 256-thread workgroup and needs no workspace (ws may be NULL); larger T run on a 1024-thread
+ *   workgroup with one T x T matrix in LDS (T <= 128; in global memory beyond) and need `ws` of
+ *   evc_subspace_solve_ws_bytes(T, count) bytes, 16-byte aligned.
  * --------------------------------------------------------------------------------- */
+size_t evc_subspace_solve_ws_bytes(int T, int count);
 int evc_subspace_solve(const double *h1rows, const double *h2rows, const double *S_train, int T,
                        int layout, int nroots, double e_shift, double *evals, double *evecs,
-                       double *w2, double *w1, double *Hout, void *stream);
+                       double *w2, double *w1, double *Hout, void *ws, size_t ws_bytes, void *stream);
 /* `count` independent problems H[g] c = E S[g] c of one size (one workgroup each): H (count,T,T) and
  * S (T,T) shared (s_stride = 0) or (count,T,T) (s_stride = T*T), lower triangles read.  Writes
  * evals (count,T) (first nroots of each row, + e_shift[g] if e_shift != NULL) and evecs (count,T,T).
@@ -135,7 +143,7 @@ int evc_subspace_solve(const double *h1rows, const double *h2rows, const double 
  * H(R) of the full set, so the t-RDM is contracted once per geometry, not once per subset. */
 int evc_subspace_solve_batch(const double *H, const double *S, int64_t s_stride, int T, int count,
                              int nroots, const double *e_shift, double *evals, double *evecs,
-                             void *stream);
+                             void *ws, size_t ws_bytes, void *stream);
 
 /* OAO integrals of `count` geometries (get_basis + get_integrals, electron_integral_utils.py:91-138):
  * X = S^-1/2, h1 = X^T hcore X (count,N,N), h2 = four-index rotation of eri (count,N,N,N,N); `trafo`
@@ -152,7 +160,7 @@ int evc_integrals_oao_batch(int n, int count, const double *S, const double *hco
  * --------------------------------------------------------------------------------- */
 typedef struct evc_trdm_set {
     int32_t n;           /* orbitals N */
-    int32_t ntrain;      /* training states T */
+    int32_t ntrain;      /* training states T (<= 512) */
     int32_t layout;      /* EVC_LAYOUT_* */
     int32_t reserved;
     int64_t rows2;       /* rows of the two-body matrix view held by THIS rank */
@@ -220,12 +228,13 @@ size_t evc_workspace_bytes(const evc_trdm_set *t, int natm);
 
 /* Phase A: Loewdin + integrals + H rows.  Writes h2rows_local[rows2] (scaled two-body rows of this
  * rank) and h1rows[T*T] into the workspace; pointers are returned through the out arguments so a
- * multi-GPU host can all-gather the rows between the phases. */
-int evc_phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, void *ws, size_t ws_bytes,
+ * multi-GPU host can all-gather the rows between the phases.
+ * flags: EVC_FLAG_ERI_S4 (g->eri packed), EVC_FLAG_WARM_START. */
+int evc_phase_hamiltonian(const evc_trdm_set *t, const evc_geometry *g, int flags, void *ws, size_t ws_bytes,
                           double **h2rows_local, double **h1rows, void *stream);
-/* Phase B: eigensolve from the complete row vector h2rows_all[rows2_total]. */
+/* Phase B: eigensolve from the complete row vector h2rows_all[rows2_total].  flags: EVC_FLAG_WARM_START. */
 int evc_phase_solve(const evc_trdm_set *t, const evc_geometry *g, const double *h2rows_all,
-                    const evc_outputs *out, int nroots, void *ws, size_t ws_bytes, void *stream);
+                    const evc_outputs *out, int nroots, int flags, void *ws, size_t ws_bytes, void *stream);
 /* Phase C: predicted RDMs of root 0 + Loewdin-response nuclear gradient. */
 int evc_phase_gradient(const evc_trdm_set *t, const evc_geometry *g, const evc_outputs *out,
                        int flags, void *ws, size_t ws_bytes, void *stream);
@@ -284,13 +293,16 @@ int evc_phase_loewdin_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
 
 /* The three phases of the pair-sharded evaluation for a batch (t may hold a row slice).
  * A: writes the scaled two-body rows of this rank to rows_out[g*ld_rows_out + r], r < t->rows2
- *    (caller's buffer: the send buffer of the all-gather).
+ *    (caller's buffer: the send buffer of the all-gather).  flags: EVC_FLAG_ERI_S4 (gb->eri packed: the phases then
+ *    run the same symmetric pipeline as the fused entry point), EVC_FLAG_LOEWDIN_DONE, EVC_FLAG_WARM_START.
  * B: h2rows_all[g*ld_rows_all + p], p < t->rows2_total, is the gathered row vector of geometry g.
- * C: as evc_phase_gradient; with EVC_FLAG_PARTIAL_RANK ob->grad receives only the two-body share. */
-int evc_phase_hamiltonian_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, double *rows_out,
+ *    flags: EVC_FLAG_WARM_START.
+ * C: as evc_phase_gradient; with EVC_FLAG_PARTIAL_RANK ob->grad receives only the two-body share;
+ *    EVC_FLAG_IP1_S2KL as for the fused entry point. */
+int evc_phase_hamiltonian_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, int flags, double *rows_out,
                                 int64_t ld_rows_out, void *ws, size_t ws_bytes, void *stream);
 int evc_phase_solve_batch(const evc_trdm_set *t, const evc_geometry_batch *gb, const double *h2rows_all,
-                          int64_t ld_rows_all, const evc_outputs_batch *ob, int nroots, void *ws,
+                          int64_t ld_rows_all, const evc_outputs_batch *ob, int nroots, int flags, void *ws,
                           size_t ws_bytes, void *stream);
 int evc_phase_gradient_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
                              const evc_outputs_batch *ob, int flags, void *ws, size_t ws_bytes,

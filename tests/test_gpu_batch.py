@@ -179,8 +179,11 @@ def test_phase_loewdin_then_flagged_call_equals_fused():
 
 
 def test_pipelined_batched_evaluator_matches_plain():
-    """Loewdin of the next batch on the library's side stream (PipelinedBatchedEvaluator): same numbers as the plain
-    evaluator for a sequence of different batches, including a dropped prefetch."""
+    """PipelinedBatchedEvaluator (one caller stream, `depth` batches in flight on the library's internal streams):
+    same numbers as the plain evaluator for a sequence of different batches, WITHOUT a host synchronisation between
+    submissions; results are read on the caller's stream behind ``results(ticket)`` only.  The inputs of the last
+    batches are produced asynchronously on the caller's stream right before their submission (a batch must not start
+    before what its caller had enqueued)."""
     import torch
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, BatchedEvaluator, PipelinedBatchedEvaluator
     from evcont_amd.synthetic import make_ao_arrays, make_trdms, pack_rows
@@ -192,14 +195,32 @@ def test_pipelined_batched_evaluator_matches_plain():
                                           for k in range(G)], dev, pack_ip1=True, pack_eri=True) for b in range(5)]
     ref = BatchedEvaluator(trd, A, G)
     want = [ref.energies_with_grads(b) for b in batches]
-    pe = PipelinedBatchedEvaluator(trd, A, G)
-    order = [0, 1, 2, 3, 4, 2]
-    for i, b in enumerate(order):
-        nxt = batches[order[i + 1]] if i + 1 < len(order) else None
-        if i == 2:
-            nxt = batches[0]                      # a wrong hint: the prefetch must be ignored by the next call
-        slot = pe.enqueue(batches[b], next_aob=nxt)
-        pe.synchronize()
-        r = pe.results(slot)
-        assert np.array_equal(r.energy[:, 0].cpu().numpy(), want[b][0])
-        assert np.array_equal(r.grad[:, :A].cpu().numpy(), want[b][1])
+    for depth in (1, 2, 3):
+        pe = PipelinedBatchedEvaluator(trd, A, G, depth=depth)
+        order = [0, 1, 2, 3, 4, 2, 0, 4, 1]
+        got, tickets, keep = {}, [], []      # keep: inputs stay allocated while their batch is in flight
+        caller = torch.cuda.Stream(dev)
+        with torch.cuda.stream(caller):
+            for i, b in enumerate(order):
+                if i >= depth:                     # consume the batch whose slot is about to be reused
+                    r = pe.results(tickets[i - depth])
+                    got[i - depth] = (r.energy[:, 0].clone(), r.grad[:, :A].clone())
+                src = batches[b]
+                if i >= 5:                         # inputs written by kernels still queued on the caller's stream
+                    src = DeviceAOBatch(S=torch.empty_like(src.S), hcore=src.hcore, eri=torch.empty_like(src.eri),
+                                        enuc=src.enuc, natm=src.natm, ipovlp=src.ipovlp, dhcore=src.dhcore,
+                                        eri_ip1=src.eri_ip1, gnuc=src.gnuc, aoslices=src.aoslices,
+                                        ip1_s2kl=src.ip1_s2kl, eri_s4=src.eri_s4)
+                    big = torch.randn(1 << 24, device=dev)          # something that takes a while in front of the copies
+                    big = (big * big).sum()
+                    src.S.copy_(batches[b].S, non_blocking=True)
+                    src.eri.copy_(batches[b].eri, non_blocking=True)
+                keep.append(src)
+                tickets.append(pe.enqueue(src))
+            for i in range(len(order) - depth, len(order)):
+                r = pe.results(tickets[i])
+                got[i] = (r.energy[:, 0].clone(), r.grad[:, :A].clone())
+        caller.synchronize()
+        for i, b in enumerate(order):
+            assert np.array_equal(got[i][0].cpu().numpy(), want[b][0]), (depth, i)
+            assert np.array_equal(got[i][1].cpu().numpy(), want[b][1]), (depth, i)
