@@ -54,6 +54,9 @@ WORKLOADS = {
     "H10": (10, 10, 5, None),             # configs[1]
     "H2O": (13, 3, 10, (9, 2, 2)),        # configs[3] (T assumed 10)
     "Zundel": (28, 7, 30, (9, 2, 2, 2, 9, 2, 2)),  # configs[4]
+    # the same molecule with the 100 training states of the reference's learning curve
+    # (scripts/MD/Zundel_thermodynamics/continuation/05_Zundel_test_potential_energy.py:182-210): 5050 pair rows
+    "Zundel100": (28, 7, 100, (9, 2, 2, 2, 9, 2, 2)),
 }
 LAYOUT_ND = {"full6": 6, "pair5": 5, "elec3": 3, "pack2": 2,
              "sym8": 8}   # sym8: 8-fold compressed device layout, built from the pack2 rows (include/evcont_hip.h)
@@ -72,6 +75,9 @@ def parse():
     p.add_argument("--geoms", type=int, default=64, help="distinct synthetic geometries resident on the device")
     p.add_argument("--batch", type=int, default=32, help="geometries per step (1 = one geometry per step, MD regime)")
     p.add_argument("--streams", type=int, default=3, help="batches in flight (one HIP stream + workspace each)")
+    p.add_argument("--repeats", type=int, default=5,
+                   help="the timed region of EXACTLY --steps steps is run this many times back to back (each bracketed "
+                        "by barrier + synchronize, max over ranks); `value` is the median, every repeat is listed")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-md-regime", action="store_true", help="skip the extra sequential (batch 1, 1 stream) leg")
     p.add_argument("--cpu-samples", type=int, default=0, help="geometries timed on the host (0 = auto)")
@@ -193,14 +199,27 @@ def main():
         # eri 8-fold symmetric and eri_ip1 symmetric in its last two indices, as real int2e / int2e_ip1 are
         return [make_device_ao(n, A, first_seed + k, dev, sizes, ip1_rs_symmetric=True) for k in range(a.geoms)]
 
+    solo_mode = [False]   # rank 0 measuring alone (the other ranks wait at a barrier behind it): no cross-rank fences
+
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1 and not solo_mode[0]:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def measure(trd, aos, G, nslots, steps, warmup, sharded_pairs, all_stages=False, pipelined=False):
-        """Time `steps` passes over batches of G geometries with `nslots` batches in flight on this rank.
+    def ensure_group():
+        """Pair sharding needs a process group even with one rank (RCCL with world size 1)."""
+        if not dist.is_initialized():
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            kw = {"device_id": dev} if backend == "nccl" else {}
+            dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
+
+    def measure(trd, aos, G, nslots, steps, warmup, sharded_pairs, all_stages=False, pipelined=False, repeats=1):
+        """Time `steps` passes over batches of G geometries with `nslots` batches in flight on this rank, `repeats` times.
         all_stages: time every instrumented stage (two event records per launch), not only K5 and K8."""
         mk_stream = lambda: (torch.cuda.Stream(dev) if nslots > 1 else None)
         if G > 1:
@@ -211,18 +230,23 @@ def main():
             inputs = aos
             evs = [ContinuationEvaluator(trd, A, stream=mk_stream(), want_two_rdm=False) for _ in range(nslots)]
         if sharded_pairs:
+            ensure_group()
             runners = [PairShardedContinuation(ev, rows) for ev in evs]
         else:
             runners = evs
         step = lambda k: runners[k % nslots].enqueue(inputs[k % len(inputs)], 1, a.energy_only)
         if pipelined:
-            # ONE caller stream, the Loewdin kernel of the next batch overlapped inside the library
+            # ONE caller stream; the library keeps three batches in flight on its own streams
             from evcont_amd.evaluator import PipelinedBatchedEvaluator
-            pe = PipelinedBatchedEvaluator(trd, A, G)
+            pe = PipelinedBatchedEvaluator(trd, A, G, depth=3)
             evs = pe.evs
             runners = [pe]
-            step = lambda k: pe.enqueue(inputs[k % len(inputs)], next_aob=inputs[(k + 1) % len(inputs)],
-                                        energy_only=a.energy_only)
+            tickets = []
+
+            def step(k):
+                if len(tickets) >= pe.depth:
+                    pe.results(tickets.pop(0))       # the caller's stream joins the batch whose slot is reused
+                tickets.append(pe.enqueue(inputs[k % len(inputs)], energy_only=a.energy_only))
         # set-up, not a step: every slot's evaluator is touched once (first-use kernel attributes, first touch of its
         # workspace), so that a small --warmup does not leave that inside the timed region of the other streams
         for k in range(nslots):
@@ -232,12 +256,24 @@ def main():
             step(k)
         fence()
         _lib.check(lib.evc_profile_select(0xFF if all_stages else 0x3), "evc_profile_select")
-        _lib.check(lib.evc_profile_begin(steps), "evc_profile_begin")
-        t0 = time.perf_counter()
-        for k in range(steps):
-            step(warmup + k)
-        fence()
-        dt = time.perf_counter() - t0
+        _lib.check(lib.evc_profile_begin(steps * repeats), "evc_profile_begin")
+        dts = []
+        for rep in range(repeats):
+            t0 = time.perf_counter()
+            for k in range(steps):
+                step(warmup + rep * steps + k)
+            fence()
+            dts.append(time.perf_counter() - t0)
+        if world > 1 and not solo_mode[0]:
+            # max over ranks, repeat by repeat
+            tt = torch.tensor(dts, dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(every, tt)
+            dts_rank = [[float(x) for x in e.tolist()] for e in every]
+            dts = [max(col) for col in zip(*dts_rank)]
+        else:
+            dts_rank = [list(dts)]
+        dt = float(np.median(dts))
         rows_ms, cols_ms = C.c_double(), C.c_double()
         rows_n, cols_n = C.c_int(), C.c_int()
         _lib.check(lib.evc_profile_end(C.byref(rows_ms), C.byref(rows_n), C.byref(cols_ms), C.byref(cols_n)),
@@ -259,14 +295,8 @@ def main():
             runners[0].enqueue(inputs[0], 1, a.energy_only)
             fence()
             e_check = float(evs[0].energy.reshape(-1)[0].item())
-        per_rank = [steps * G / dt]          # this rank's own rate (its G geometries per step over ITS wall time)
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            every = [torch.zeros_like(tt) for _ in range(world)]
-            dist.all_gather(every, tt)
-            per_rank = [steps * G / float(x.item()) for x in every]
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        # every rank's own rate (its G geometries per step over the median of ITS wall times)
+        per_rank = [steps * G / float(np.median(r)) for r in dts_rank]
         gl = min(G, MAX_G_PER_LAUNCH)                  # geometries per launch of the streaming kernels
         lps = -(-G // MAX_G_PER_LAUNCH)                # launches per step
         # ALGORITHMIC bytes of one K5 / K8 launch: the local two-body rows + the one-body t-RDM once,
@@ -275,8 +305,9 @@ def main():
         k5 = rows_ms.value / max(rows_n.value, 1) / lps
         k8 = cols_ms.value / max(cols_n.value, 1) / lps if cols_n.value else None
         # geometries evaluated by the whole job per step: G on every rank (distinct ones unless pair-sharded)
-        job_g = G if (sharded_pairs or world == 1) else G * world
+        job_g = G if (sharded_pairs or world == 1 or solo_mode[0]) else G * world
         return {"value": steps * job_g / dt, "ms_per_step": 1e3 * dt / steps, "batch": G, "streams": nslots,
+                "repeat_values": [steps * job_g / x for x in dts],
                 "k5_ms": k5, "k8_ms": k8, "bytes_per_launch": nbytes, "launches": rows_n.value * lps,
                 "geometries_per_launch": gl, "k5_GBs": nbytes / (k5 * 1e-3) / 1e9,
                 "k8_GBs": (nbytes / (k8 * 1e-3) / 1e9) if k8 else None, "last_energy": e_last, "check_energy": e_check,
@@ -310,11 +341,11 @@ def main():
     # what the sym8 legs are fed: the same integrals with int2e_ip1 packed in (r,s), gathered on the device here,
     # outside every timed region -- the form PySCF delivers with aosym="s2kl"
     packed_ip1 = a.layout == "sym8" and a.integrals == "packed" and n <= 32
-    # (pair sharding goes through the phase entry points, which take the full int2e)
-    run_view = ((lambda lst, phases=False: [x.packed_ip1(eri=not phases) for x in lst]) if packed_ip1
+    # (the phase entry points of the pair-sharded mode take the same packed arrays: flags since ABI 7)
+    run_view = ((lambda lst, phases=False: [x.packed_ip1(eri=True) for x in lst]) if packed_ip1
                 else (lambda lst, phases=False: lst))
     aos_run = run_view(aos, pairs_first)
-    m = measure(trd, aos_run, G, 1 if pairs_first else S, a.steps, a.warmup, pairs_first)
+    m = measure(trd, aos_run, G, 1 if pairs_first else S, a.steps, a.warmup, pairs_first, repeats=max(1, a.repeats))
 
     out = None
     if rank == 0:
@@ -356,8 +387,12 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": m["ms_per_step"],
+            "repeats": max(1, a.repeats),
+            "repeat_values": m["repeat_values"],
             "higher_is_better": True,
-            "scaling": "strong" if (pairs_first or world == 1) else "weak",
+            # geometry sharding: the work per GPU is fixed (its own batches) whatever N is -> weak, also at N = 1;
+            # pair sharding: one batch for the whole job -> strong
+            "scaling": "strong" if pairs_first else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -397,16 +432,43 @@ def main():
         # pair sharding needs identical geometries on all ranks, geometry sharding distinct ones
         aos2 = geometries(seed * 1000 + (0 if second_pairs else rank * a.geoms))
         aos_run = run_view(aos2, second_pairs)
-        m2 = measure(trd2, aos_run, G, 1 if second_pairs else S, a.steps, a.warmup, second_pairs)
+        m2 = measure(trd2, aos_run, G, 1 if second_pairs else S, a.steps, a.warmup, second_pairs,
+                     repeats=max(1, a.repeats))
         if rank == 0:
             out["pair_sharded" if second_pairs else "geometry_sharded"] = {
                 "value": m2["value"], "unit": "geometries/s", "ms_per_step": m2["ms_per_step"],
+                "repeat_values": m2["repeat_values"],
                 "scaling": "strong" if second_pairs else "weak", "geometries_per_step": m2["geometries_per_step"],
                 "batch_per_gpu": G, "streams": m2["streams"], "k5_rows_ms": m2["k5_ms"], "k5_GBs": m2["k5_GBs"],
                 "k5_frac": m2["k5_GBs"] / HBM_PEAK_GBS, "k8_cols_ms": m2["k8_ms"],
                 "rows_per_rank": (my_range[1] - my_range[0]) if second_pairs else rows,
                 "last_energy": m2["last_energy"]}
-        trd = trd2
+        # the same two jobs on ONE GPU of this node, measured by rank 0 alone while the other ranks wait: the N = 1
+        # reference each mode's efficiency is taken against (the driver computes its own from separate runs)
+        del trd2
+        torch.cuda.empty_cache()
+        solo = None
+        if rank == 0:
+            solo_mode[0] = True
+            trd1 = trdms(full_range)
+            v1 = run_view(geometries(seed * 1000), False)
+            g1 = measure(trd1, v1, G, S, a.steps, a.warmup, False, repeats=max(1, a.repeats))
+            solo = {"geometries": g1["value"]}
+            solo_mode[0] = False
+            geo_v = out["value"] if not pairs_first else out["geometry_sharded"]["value"]
+            pair_v = out["value"] if pairs_first else out["pair_sharded"]["value"]
+            out["n1_same_run"] = {
+                "value": g1["value"], "unit": "geometries/s", "repeat_values": g1["repeat_values"],
+                "note": "rank 0 alone (other ranks idle at a barrier): same batch size and streams on one GPU"}
+            out["efficiency_vs_n1"] = {"geometry_sharded": geo_v / (world * g1["value"]),
+                                       "pair_sharded": pair_v / (world * g1["value"]),
+                                       "note": "job rate / (N x the one-GPU rate of this run); pair sharding only "
+                                               "divides the two streaming kernels, the rest of a step is replicated "
+                                               "(DESIGN.md section 6)"}
+            del trd1, v1
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        trd = None
     if world == 1 and not a.no_md_regime and S > 1:
         # the same batches on ONE stream: the streaming kernels without another batch's kernels beside them
         # twice: `one` with only K5 / K8 bracketed by events (as the headline region; its rate is the leg's `value`),
@@ -418,9 +480,9 @@ def main():
             if pipe is not None:
                 out["single_stream_pipelined"] = {
                     "value": pipe["value"], "unit": "geometries/s", "ms_per_step": pipe["ms_per_step"],
-                    "note": "one caller stream; the Loewdin kernel of the NEXT batch runs on the library's internal side "
-                            "stream beside the current batch (evaluator.PipelinedBatchedEvaluator, "
-                            "evc_phase_loewdin_batch + EVC_FLAG_LOEWDIN_DONE)"}
+                    "note": "ONE caller stream; the library keeps three batches in flight on its internal streams and the "
+                            "caller's stream joins a batch when its results are asked for "
+                            "(evaluator.PipelinedBatchedEvaluator, depth 3)"}
             out["single_stream"] = {"value": one["value"], "unit": "geometries/s", "ms_per_step": one["ms_per_step"],
                                     "value_all_stages_timed": stg["value"],
                                     "note": "same batch size, one stream: kernels of one batch at a time; "
@@ -456,6 +518,25 @@ def main():
                                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                "bytes_per_launch": nb, "ms_per_launch": st["ip1_ms"]})
             out["roofline_other_kernels"] = others
+    if world == 1 and not a.no_md_regime and G > 1:
+        # the pair-sharded mode (phases + all-gather of the H rows + all-reduce of the gradient)
+        # with ONE rank: the same phases, the same two collectives through the same backend (RCCL), on this GPU
+        try:
+            ps1 = measure(trd, aos_run, G, 1, max(10, a.steps // 2), 3, True)
+            psS = measure(trd, aos_run, G, S, max(10, a.steps // 2), 3, True) if S > 1 else None
+            if rank == 0:
+                out["pair_sharded"] = {
+                    "value": ps1["value"], "unit": "geometries/s", "ms_per_step": ps1["ms_per_step"], "scaling": "strong",
+                    "world": 1, "backend": dist.get_backend(), "streams": 1, "k5_rows_ms": ps1["k5_ms"],
+                    "k8_cols_ms": ps1["k8_ms"], "check_energy": ps1["check_energy"],
+                    "energy_difference_vs_fused": abs(ps1["check_energy"] - m["check_energy"]),
+                    "value_streams": (psS["value"] if psS else None), "streams_in_flight": S,
+                    "note": "pair-sharded phases + both collectives with one rank, one stream: to be compared with "
+                            "`single_stream.value` (the fused entry point on one stream); `value_streams`: the same "
+                            "with several batches in flight, to be compared with `value`"}
+        except Exception as exc:   # a collectives backend that cannot start must not take the headline down
+            if rank == 0:
+                out["pair_sharded"] = {"value": None, "error": repr(exc)}
     if world == 1 and not a.no_md_regime and (G, S) != (1, 1):
         md = measure(trd, aos_run, 1, 1, max(20, min(a.steps * 2, 200)), 10, False)
         if rank == 0:
@@ -550,11 +631,12 @@ def main():
         nd_cpu = nd
     if rank == 0:
         if not a.no_cpu_baseline and world == 1 and not a.energy_only:
-            samples = a.cpu_samples or (8 if a.workload in ("H30", "Zundel") else 50)
+            samples = a.cpu_samples or (2 if a.workload == "Zundel100" else 8 if a.workload in ("H30", "Zundel") else 50)
             out["cpu_baseline"] = cpu_baseline(a.workload, nd_cpu, trd, aos, samples)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

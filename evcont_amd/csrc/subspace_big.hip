@@ -29,6 +29,23 @@ constexpr int kBT = 1024;   // threads of the workgroup
 constexpr int kBW = kBT / 64;
 typedef double d4b __attribute__((ext_vector_type(4)));
 
+// Phase stamps of workgroup 0 (tools/micro/subspace_time.py --stamps; library built with EVC_DEBUG_STAMPS=1)
+#ifdef EVC_DEBUG_STAMPS
+__device__ long long g_big_stamp[16];
+__device__ double g_big_val[16];
+#define EVC_BSTAMP(i_)                                                                  \
+    do {                                                                                \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_big_stamp[i_] = wall_clock64();      \
+    } while (0)
+#define EVC_BVAL(i_, v_)                                                                \
+    do {                                                                                \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_big_val[i_] = (double)(v_);          \
+    } while (0)
+#else
+#define EVC_BSTAMP(i_) do { } while (0)
+#define EVC_BVAL(i_, v_) do { } while (0)
+#endif
+
 __device__ __forceinline__ double sum8(double v) {    // over the 8 lanes of a half DPP row, every lane gets the total
     v += dpp_move<0xB1>(v);
     v += dpp_move<0x4E>(v);
@@ -202,6 +219,7 @@ __device__ __forceinline__ void big_jacobi(double *G, int m, int Pj, double *red
             }
             __syncthreads();
         }
+        EVC_BVAL(0, sweep + 1);
         if (!big_block_any(bad, red)) break;
     }
 }
@@ -275,6 +293,7 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
     const bool pairs = (a.layout == EVC_LAYOUT_PAIR5 || a.layout == EVC_LAYOUT_PACK2 || a.layout == EVC_LAYOUT_SYM8);
     const int64_t rows2 = pairs ? P : (int64_t)T * T;
 
+    EVC_BSTAMP(0);
     // (a) B = L^-1: from the cache when the overlap matrix it was computed from is bit-identical to this call's
     bool hit = false;
     if (a.bcache) {
@@ -300,6 +319,7 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
             for (int idx = tid; idx < T * T; idx += kBT) a.bcache[idx] = a.S[idx];
         __syncthreads();
     }
+    EVC_BSTAMP(1);
     // (b) H from the span partials (stored [span][row]), placed as the reference does (evcont.py:41-68)
     for (size_t idx = tid; idx < Tp2; idx += kBT) M[idx] = 0.0;
     __syncthreads();
@@ -343,11 +363,13 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
         if (j > i) M[(size_t)i * Tp + j] = M[(size_t)j * Tp + i];
     }
     __syncthreads();
+    EVC_BSTAMP(2);
     // (c) W = B Hs (W[i][k] = sum_l B[i][l] Hs[k][l]);  C = W B^T (C[i][j] = sum_k W[i][k] B[j][k])
     big_mm_rr(Tp, Bg, Tp, M, Tp, [&](int i, int k, double v) { Wg[(size_t)i * Tp + k] = v; });
     __syncthreads();
     big_mm_rr(Tp, Wg, Tp, Bg, Tp, [&](int i, int j, double v) { Cg[(size_t)i * Tp + j] = v; });
     __syncthreads();
+    EVC_BSTAMP(3);
     // exact symmetry (as the rotations assume) and the Gershgorin bound of the shift
     for (size_t idx = tid; idx < Tp2; idx += kBT) {
         const int i = (int)(idx / Tp), j = (int)(idx - (size_t)i * Tp);
@@ -366,6 +388,7 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
     }
     rmax = big_block_max(rmax, red);
     const double shift = 2.0 * rmax + 1.0e-300;   // eigenvalues of the shifted matrix within [1, 3] x the bound
+    EVC_BSTAMP(4);
     // (d) G0, column-major with pitch Pj
     bool warm = false;
     if (a.warm && a.vstd) {   // uniform: the previous eigenvectors (rows of vstd, pitch Tp) must be orthonormal
@@ -390,7 +413,9 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
         });
         __syncthreads();
     }
+    EVC_BSTAMP(5);
     big_jacobi(M, m, Pj, red);
+    EVC_BSTAMP(6);
     // column norms = eigenvalues + shift; normalised columns = eigenvectors
     for (int j = tid >> 4; j < m; j += kBT / 16) {
         const int s = tid & 15;
@@ -455,6 +480,7 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
             if (a.w2t) a.w2t[r * kMaxBatchG + (int)(blockIdx.x % kMaxBatchG)] = w;
         }
     }
+    EVC_BSTAMP(7);
 }
 
 static size_t big_aux_bytes(int T) {
@@ -490,3 +516,12 @@ int launch_subspace_big(const SolveArgs &a, int count, hipStream_t st) {
 }
 
 }  // namespace evc
+
+#ifdef EVC_DEBUG_STAMPS
+extern "C" int evc_debug_read_big(long long *stamps, double *vals, int n) {
+    if (n > 16) n = 16;
+    hipError_t e = hipMemcpyFromSymbol(stamps, HIP_SYMBOL(evc::g_big_stamp), sizeof(long long) * n);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(vals, HIP_SYMBOL(evc::g_big_val), sizeof(double) * n);
+    return (int)e;
+}
+#endif

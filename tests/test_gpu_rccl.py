@@ -1,0 +1,31 @@
+"""The pair-sharded evaluation through RCCL itself: a FRESH child process (one rank, WORLD_SIZE=1, backend "nccl")
+drives the real HIP phases with ``all_gather_into_tensor`` and ``all_reduce`` between them
+(evcont_amd/distributed.py) and compares with the CPU oracle.  More ranks need more GPUs than
+this box has; the sharding arithmetic for world sizes 2 and 3 is covered on gloo (tests/test_distributed_gloo.py) and
+with the real phases on emulated ranks (tests/test_gpu_batch.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_pair_sharded_phases_through_rccl_world1():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "rccl_child.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_CHILD ")][-1]
+    res = json.loads(line[len("RCCL_CHILD "):])
+    assert res["backend"] == "nccl" and res["world"] == 1
+    assert res["worst_dE"] < 1e-10 and res["worst_dgrad"] < 1e-9, res
