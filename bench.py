@@ -57,6 +57,8 @@ WORKLOADS = {
     # the same molecule with the 100 training states of the reference's learning curve
     # (scripts/MD/Zundel_thermodynamics/continuation/05_Zundel_test_potential_energy.py:182-210): 5050 pair rows
     "Zundel100": (28, 7, 100, (9, 2, 2, 2, 9, 2, 2)),
+    # cc-pVTZ water, the reference's largest orbital space (scripts/MD/H2O/md_H2O_vtz_CAS_continuation.py:31)
+    "H2Ovtz": (58, 3, 8, (30, 14, 14)),
 }
 LAYOUT_ND = {"full6": 6, "pair5": 5, "elec3": 3, "pack2": 2,
              "sym8": 8}   # sym8: 8-fold compressed device layout, built from the pack2 rows (include/evcont_hip.h)

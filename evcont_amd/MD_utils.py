@@ -95,13 +95,23 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="defaul
             if not have_data:
                 return energy_nuc(mol), grad_nuc(mol)
             if not hermitian:
-                en, grad, rdm_o, rdm_t = get_energy_with_grad(
-                    mol, one_rdm, two_rdm, overlap, hermitian=hermitian, return_density_matrices=True)
+                if device_trdms is not None and (one_rdm is None or two_rdm is None or overlap is None):
+                    # training data resident on the device only: the eig branch on ITS layout (not the compressed one)
+                    if self._full is None:
+                        self._full = ContinuationEvaluator(device_trdms, len(aoslices_of(mol)))
+                    ao = ao_arrays(mol, need_grad=True)
+                    en, grad, rdm_o, rdm_t = self._full.energy_with_grad_nonhermitian(
+                        DeviceAO.from_arrays(ao, device_trdms.device), True)
+                else:
+                    en, grad, rdm_o, rdm_t = get_energy_with_grad(
+                        mol, one_rdm, two_rdm, overlap, hermitian=hermitian, return_density_matrices=True)
                 self._last = [mol, rdm_o, rdm_t]
                 return en, grad
             # called once per MD step on slowly moving geometries: the scanner owns a hosted evaluator (pinned
-            # staging, one HIP graph per step, eigensolvers warm-started from the previous step; with the compressed
-            # layout the two large integral arrays are requested / staged packed: 12 instead of 26.6 MB at H30)
+            # staging, eager two-stream enqueue of uploads + kernels + download -- replaying the step as one HIP graph
+            # is an opt-in, EVCONT_AMD_HOSTED_GRAPH=1, measured slower --, eigensolvers warm-started from the previous
+            # step; with the compressed layout the two large integral arrays are requested / staged packed: 12 instead
+            # of 26.6 MB at H30)
             if self._hev is None:
                 t = device_trdms if device_trdms is not None else _trdms(one_rdm, two_rdm, overlap, compress)
                 sl = aoslices_of(mol)

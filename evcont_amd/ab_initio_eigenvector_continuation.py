@@ -62,19 +62,21 @@ def get_trdm_compression():
 
 def _trdms(one_RDM, two_RDM, S, compress=None) -> DeviceTRDMs:
     key = cache.key_of(one_RDM, two_RDM, S, ("trdms", compress))
-    t = cache.get(key)
+    arrays = (one_RDM, two_RDM, S)
+    t = cache.get(key, arrays)       # (block checksums of the host arrays are verified: cache.py)
     if t is None:
-        t = cache.put(key, DeviceTRDMs(one_RDM, two_RDM, S, _dev(), compress=compress))
+        t = cache.put(key, DeviceTRDMs(one_RDM, two_RDM, S, _dev(), compress=compress), arrays)
     return t
 
 
 def _evaluator(one_RDM, two_RDM, S, natm: int, compress="default") -> ContinuationEvaluator:
     if compress == "default":
         compress = _COMPRESS
-    key = cache.key_of(one_RDM, two_RDM, S, ("evaluator", int(natm), compress))
+    t = _trdms(one_RDM, two_RDM, S, compress)       # verified against the host arrays, or uploaded again
+    key = ("evaluator", id(t), int(natm))
     ev = cache.get(key)
-    if ev is None:
-        ev = cache.put(key, ContinuationEvaluator(_trdms(one_RDM, two_RDM, S, compress), natm))
+    if ev is None or ev.t is not t:
+        ev = cache.put(key, ContinuationEvaluator(t, natm))
     return ev
 
 

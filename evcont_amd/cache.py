@@ -3,24 +3,35 @@
 The reference API passes the (possibly multi-GB) t-RDM arrays to every call
 (``get_energy_with_grad(mol, one_RDM, two_RDM, S)`` once per MD step,
 ``MD_utils.py:43-50``).  The device path must not re-upload them each time, so the host
-arrays are fingerprinted (address, shape, strides, dtype + a strided content sample) and
-the corresponding ``DeviceTRDMs``/``ContinuationEvaluator`` are kept in a small LRU.
-Callers that mutate an array in place between calls should call :func:`clear` (the containers do so on
-``append_to_rdms`` / ``prune_datapoints``); ``EVCONT_AMD_CACHE_STRICT=1`` fingerprints the WHOLE array on every
-call instead of a sample (what the reference effectively does by re-reading it: exact, but a 2.6 GB t-RDM then costs
-a full host pass per call).
+arrays are fingerprinted and the corresponding ``DeviceTRDMs``/``ContinuationEvaluator`` are
+kept in a small LRU.  Two layers guard against a stale device copy after an IN-PLACE edit of
+a host array (the reference re-reads the arrays on every call):
+
+* the KEY holds the identity of each array (address, shape, strides, dtype) and a strided
+  content sample (~4096 elements);
+* every entry stores BLOCK CHECKSUMS of its arrays (4096 blocks each, computed in the pass
+  that uploads them).  ``get(key, arrays)`` verifies all of them on the first reuse of an entry
+  and a few randomly chosen blocks (<= 2 MB of host reads) on every later one; a mismatch drops
+  the entry and the caller uploads again.  An edit confined to a handful of elements can still
+  escape for some calls; ``EVCONT_AMD_CACHE_STRICT=1`` verifies every block on every call (what the
+  reference effectively does: exact, but a 2.6 GB t-RDM then costs a full host pass per call).
+
+The containers call :func:`clear` on ``append_to_rdms`` / ``prune_datapoints``.
 """
 from __future__ import annotations
 
 import os
 from collections import OrderedDict
-from typing import Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
 _MAX = int(os.environ.get("EVCONT_AMD_CACHE_ENTRIES", "4"))
 _STRICT = os.environ.get("EVCONT_AMD_CACHE_STRICT", "0") not in ("", "0")
-_cache: "OrderedDict[tuple, object]" = OrderedDict()
+_NBLK = 4096
+_SPOT_BYTES = 2 << 20
+_cache: "OrderedDict[tuple, list]" = OrderedDict()   # key -> [value, block sums per array or None, reuse count]
+_rng = np.random.default_rng(0x5EED)
 
 
 def _fingerprint(a: np.ndarray) -> tuple:
@@ -29,7 +40,7 @@ def _fingerprint(a: np.ndarray) -> tuple:
     if flat_len == 0:
         return (a.shape, a.dtype.str)
     # ~4096 samples spread over the array + both ends; cheap even for a 2.6 GB array
-    step = 1 if _STRICT else max(1, flat_len // 4096)
+    step = max(1, flat_len // 4096)
     if a.flags.c_contiguous:
         sample = a.reshape(-1)[::step]
     else:
@@ -43,15 +54,67 @@ def key_of(one_RDM, two_RDM, S, extra: Tuple = ()) -> tuple:
     return (_fingerprint(one_RDM), _fingerprint(two_RDM), _fingerprint(S)) + tuple(extra)
 
 
-def get(key):
-    if key in _cache:
-        _cache.move_to_end(key)
-        return _cache[key]
-    return None
+def _block_size(a: np.ndarray) -> int:
+    return max(1, -(-a.size // _NBLK))
 
 
-def put(key, value):
-    _cache[key] = value
+def _block_sum(a: np.ndarray, blk: int) -> float:
+    """Sum of block `blk` (elements [blk*bs, (blk+1)*bs) in C order)."""
+    bs = _block_size(a)
+    lo, hi = blk * bs, min(a.size, (blk + 1) * bs)
+    if a.flags.c_contiguous:
+        return float(np.sum(a.reshape(-1)[lo:hi], dtype=np.float64))
+    return float(np.sum(a[np.unravel_index(np.arange(lo, hi), a.shape)], dtype=np.float64))
+
+
+def _all_block_sums(a: np.ndarray) -> np.ndarray:
+    a = np.asarray(a)
+    if a.size == 0:
+        return np.zeros(0)
+    bs = _block_size(a)
+    flat = a.reshape(-1)          # (a copy for non-contiguous views: one pass, as the upload itself)
+    return np.add.reduceat(flat, np.arange(0, a.size, bs), dtype=np.float64)
+
+
+def _verify(arrays: Sequence[np.ndarray], sums, full: bool) -> bool:
+    for a, ref in zip(arrays, sums):
+        a = np.asarray(a)
+        if a.size == 0:
+            continue
+        if full:
+            if not np.array_equal(_all_block_sums(a), ref):
+                return False
+            continue
+        nblk = len(ref)
+        per_block = _block_size(a) * a.itemsize
+        k = int(min(16, max(1, _SPOT_BYTES // max(per_block, 1)), nblk))
+        if not a.flags.c_contiguous:
+            k = min(k, 2)
+        for blk in _rng.choice(nblk, size=k, replace=False):
+            if _block_sum(a, int(blk)) != float(ref[int(blk)]):
+                return False
+    return True
+
+
+def get(key, arrays: Optional[Sequence[np.ndarray]] = None):
+    """The cached object, or None.  ``arrays``: the host arrays the entry was built from -- their block checksums are
+    verified (all on the first reuse, a random few afterwards, all with EVCONT_AMD_CACHE_STRICT=1)."""
+    ent = _cache.get(key)
+    if ent is None:
+        return None
+    value, sums, reuse = ent
+    if arrays is not None and sums is not None:
+        if not _verify(arrays, sums, full=(_STRICT or reuse == 0)):
+            del _cache[key]
+            return None
+    ent[2] = reuse + 1
+    _cache.move_to_end(key)
+    return value
+
+
+def put(key, value, arrays: Optional[Sequence[np.ndarray]] = None):
+    sums = [_all_block_sums(np.asarray(a)) for a in arrays] if arrays is not None else None
+    _cache[key] = [value, sums, 0]
     _cache.move_to_end(key)
     while len(_cache) > _MAX:
         _cache.popitem(last=False)

@@ -1555,9 +1555,9 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
 }
 
 int launch_subspace_solve(const SolveArgs &a_in, int count, hipStream_t st) {
-    // EVC_SUBSPACE_OLD64=1 (A/B timing): 32 < T <= 64 through the two-sided LDS Jacobi of this file
-    static const bool old64 = getenv("EVC_SUBSPACE_OLD64") && atoi(getenv("EVC_SUBSPACE_OLD64")) != 0;
-    if (a_in.T > kSubspaceSmallT && !(old64 && a_in.T <= 64)) return launch_subspace_big(a_in, count, st);
+    // (measured: 0.26 / 0.42 / 0.61 ms at T = 33 / 48 / 64 against 0.62 / 1.14 / 1.89 ms for the two-sided LDS Jacobi
+    //  this file used up to T = 64 in round 2)
+    if (a_in.T > kSubspaceSmallT) return launch_subspace_big(a_in, count, st);
     SolveArgs a = a_in;
     a.fast = eigh_fast_enabled();
     const int m = (a.T + 1) & ~1;

@@ -273,85 +273,6 @@ __global__ __launch_bounds__(256, MINW) void gemv_rows_mfma_pipe_kernel(GemvRows
     EVC_K5_WG(2);
 }
 
-// Two geometry sets on EIGHT waves: waves 0-3 take geometries [g0, g0+16), waves 4-7 [g0+16, g0+32) of the same
-// (span, row group), every wave with the lean single-buffer body for ONE set.  A lone wave issues one FP64 MFMA per
-// ~140 cycles, two waves sharing a SIMD one per ~105 (tools/micro/mfma_f64_peak.hip): with one 512-register wave
-// per SIMD the 112 MFMAs of a chunk and its loads add up; here each SIMD holds two 256-register waves, one waiting
-// for its 32 loads while the other feeds the matrix pipe.  The partner set re-reads the matrix rows through L1/L2 (same
-// CU), HBM sees them once; the vectors are still read once per row group.
-template <int MAXT>
-__global__ __launch_bounds__(512, 2) void gemv_rows_mfma_split_kernel(GemvRowsLaunch L, int g0, int G) {
-    __shared__ double red[4][MAXT][4][64];  // [wave][tile][reg][lane], used by one set at a time
-    int b = blockIdx.x;
-    int which, span, rg;
-    if (b < L.nblk1) {
-        which = 1;
-        const int nrg1 = L.nrg[1];
-        span = b / nrg1;
-        rg = b - span * nrg1;
-        if (span >= L.p[1].nspans) return;
-    } else {
-        which = 0;
-        b -= L.nblk1;
-        const int nrg0 = L.nrg[0];
-        const int xcd = b & 7, idx = b >> 3;
-        const int j = idx / nrg0;
-        rg = idx - j * nrg0;
-        span = j * 8 + xcd;
-        if (span >= L.p[0].nspans) return;
-    }
-    const RowProblem &P = L.p[which];
-    const int64_t rows = P.rows;
-    const int tpg = L.tpg[which], trem = L.trem[which];
-    const int tid = threadIdx.x, lane = tid & 63, set = tid >> 8, wave = (tid >> 6) & 3;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int64_t row_base = (int64_t)(rg * tpg + min(rg, trem)) * 16;
-    const int ntile = tpg + (rg < trem ? 1 : 0);
-    const int64_t cbeg = (int64_t)span * P.span_cols;
-    const int64_t cend = min(P.cols, (int64_t)(span + 1) * P.span_cols);
-    const int gs0 = g0 + 16 * set, Gs = min(16, G - 16 * set);   // this wave's geometries (Gs <= 0: idle set)
-    const double *__restrict__ vr[1];
-    vr[0] = P.v + (int64_t)(Gs > 0 ? gs0 + (l15 < Gs ? l15 : 0) : g0) * P.vstride;
-    d4 acc[1][MAXT];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[0][t] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (Gs > 0) {   // wave-uniform
-#define EVC_ROWS_BODY(NT_) rows_lean_body<NT_, MAXT, 1>(P, row_base, cbeg, cend, vr, l15, l4, wave, acc);
-        if constexpr (MAXT >= 7) {
-            if (ntile == 7) EVC_ROWS_BODY(7)
-            if (ntile == 6) EVC_ROWS_BODY(6)
-            if (ntile == 5) EVC_ROWS_BODY(5)
-        }
-        if constexpr (MAXT >= 4) {
-            if (ntile == 4) EVC_ROWS_BODY(4)
-        }
-        if (ntile == 3) EVC_ROWS_BODY(3)
-        if (ntile == 2) EVC_ROWS_BODY(2)
-        if (ntile == 1) EVC_ROWS_BODY(1)
-#undef EVC_ROWS_BODY
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        __syncthreads();
-        if (set == s) {
-#pragma unroll
-            for (int tt = 0; tt < MAXT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave][tt][r][lane] = acc[0][tt][r];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < MAXT * 4 * 64; idx += 512) {
-            const int ln = idx & 63, r = (idx >> 6) & 3, tt = idx >> 8;
-            const int64_t row = row_base + tt * 16 + (ln >> 4) + 4 * r;
-            const int g = 16 * s + (ln & 15);
-            if (tt < ntile && row < rows && g < G) {
-                const double sum = (red[0][tt][r][ln] + red[1][tt][r][ln]) + (red[2][tt][r][ln] + red[3][tt][r][ln]);
-                P.partial[(int64_t)(g0 + g) * P.pstride + (int64_t)span * rows + row] = sum;
-            }
-        }
-    }
-}
-
 int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, hipStream_t st) {
     GemvRowsLaunch L = Lin;
     const int gs = G > 16 ? 2 : 1;
@@ -361,7 +282,7 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, h
     // narrow matrices (the 8-fold compressed layout, < 200 000 columns): the vectors of the 32 geometries weigh as
     // much as the matrix itself when five row groups re-read them; two groups of seven tiles on ONE wave per SIMD
     // (512 registers) read them twice: 66 against 76 us at 108 345 columns -- and 270 against 222 us at 405 450
-    // 722 / 422: the eight-wave split kernel above with row groups of <= 7 / <= 4 tiles
+    // (an eight-wave kernel with one geometry set per half, 722 / 422, measured 89 us against 57-66; removed in round 3)
     static const int sh2n = getenv("EVC_ROWS_SHAPE2_NARROW") ? atoi(getenv("EVC_ROWS_SHAPE2_NARROW")) : 711;
     const int shape = gs == 2 ? (Lin.p[0].cols <= 200000 ? sh2n : sh2) : sh1;
     const int kernel_maxt = shape / 100;
@@ -384,17 +305,11 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, h
         hipLaunchKernelGGL((gemv_rows_mfma_pipe_kernel<GS_, MAXT_, MINW_, PIPE_ != 0>), dim3(nb0 + nb1), \
                            dim3(256), 0, st, L, g0, G);                                                \
         break;
-    if (gs == 2 && (shape == 722 || shape == 422)) {
-        if (shape == 722)
-            hipLaunchKernelGGL((gemv_rows_mfma_split_kernel<7>), dim3(nb0 + nb1), dim3(512), 0, st, L, g0, G);
-        else
-            hipLaunchKernelGGL((gemv_rows_mfma_split_kernel<4>), dim3(nb0 + nb1), dim3(512), 0, st, L, g0, G);
-    } else if (gs == 2) {
+    if (gs == 2) {
         switch (shape) {
             // in situ, G=32: pipelined 321 -> 226 us; lean 330 -> 238, 230 -> 247, 240 -> 259, 150 -> 300; 711 -> 270
             EVC_ROWS_CASE(2, 3, 2, 1) EVC_ROWS_CASE(2, 3, 3, 0) EVC_ROWS_CASE(2, 2, 4, 0) EVC_ROWS_CASE(2, 7, 1, 1)
-            // one wave per SIMD with everything in ArchVGPRs (<= 256): fast-form MFMA, single-buffer body
-            EVC_ROWS_CASE(2, 6, 1, 0) EVC_ROWS_CASE(2, 5, 1, 0) EVC_ROWS_CASE(2, 7, 1, 0)
+            // (single-buffer one-wave shapes 710 / 610 / 510: 76 / 98 / 91 us against 57-66 for 711; removed in round 3)
             default: set_error("gemv_rows_mfma: unknown EVC_ROWS_SHAPE2=%d", shape); return -1;
         }
     } else {

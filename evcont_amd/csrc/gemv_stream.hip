@@ -231,19 +231,6 @@ void plan_rows(RowProblem &P, bool batched) {
     if (cps < min_cps) cps = nchunks < min_cps ? nchunks : min_cps;
     if (cps < 1) cps = 1;
     P.span_cols = cps * kChunk;
-    // EVC_ROWS_NARROW_WGS=W (experiment, off by default): cut the spans of a narrow matrix (the compressed layout, one
-    // 7-tile row group per workgroup and CU) in 32-column chunks so that about W workgroups result.  Measured on the
-    // 210 x 108345 matrix (tools/micro/k5_stamps.py): the main loops of 216 workgroups x 8 chunks per wave and of
-    // 252 x 7 both take 48-52 us -- the stream, not the share of a wave, sets the time -- and more than ~248 workgroups
-    // (the small second problem's blocks included) start a second round on the 256 CUs: 57 -> 81 us.
-    static const int narrow_wgs = env_int("EVC_ROWS_NARROW_WGS", 0);
-    if (batched && narrow_wgs > 0 && P.cols <= 200000) {
-        const int64_t nrg = ceil_div(ceil_div(P.rows, 16), 7);
-        const int64_t spans = narrow_wgs / nrg > 0 ? narrow_wgs / nrg : 1;
-        int64_t span32 = ceil_div(ceil_div(P.cols, 32), spans);
-        if (span32 < 16) span32 = 16;   // at least four chunks per wave
-        if (span32 * 32 < P.span_cols) P.span_cols = span32 * 32;
-    }
     P.nspans = (int)ceil_div(P.cols, P.span_cols);
     P.nblocks = (int)(nrb * P.nspans);
 }

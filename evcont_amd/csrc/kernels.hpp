@@ -70,12 +70,6 @@ struct PairTransformArgs {
     int out_pairs;      // (with lead_sym and rs_lower) `out` is the dense (pair, pair) matrix out[tri(r',s')][tri(p,q)]
                         // instead of rows of an N^4 tensor; 2: times the multiplicity (p != q ? 2 : 1)
     int in_pairs;       // (with lead_sym) `in` is such a matrix: in[tri(p,q)][tri(r,s)]
-    // Barrier-free kernel of the symmetric pipeline (lead_sym, in_lower, rs_lower, in_pairs all set): every wave owns
-    // whole leading pairs L and writes ITS results as contiguous rows -- out[L][tri(r',s')] (times the multiplicity of
-    // the RESULT pair with out_pairs = 2), packed[tri(L, v)] for v = tri(r',s') <= L -- so nothing is staged or
-    // transposed at write time; the transposition happens at read time instead:
-    int direct;         // use that kernel
-    int in_cols;        // its operand is such an output of a previous direct step: in[tri(r,s)][L] (column L)
 };
 constexpr int kPairTransformMaxN = 32;
 int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);

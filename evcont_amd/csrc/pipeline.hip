@@ -95,15 +95,6 @@ struct Ws {
 
 // n <= 32: the four-index rotations run as two fused pair steps (transform.hip pt_kernel); larger n
 // (or EVC_NO_PAIR_TRANSFORM=1, for A/B timing) as four quarter steps.
-// Barrier-free variant of the symmetric pair steps (transform.hip pt_sym_kernel), EVC_PT_DIRECT=1.  Off by default:
-// measured at H30, 32 geometries per launch, it takes 62.8 us against 58.0 us for the staged kernel (87 us when forced
-// to three waves per SIMD: 40 spilled registers) -- neither the staging barriers nor the operand gather are what
-// separates the pair transform from the FP64 matrix pipe's 36 us.
-static bool use_direct_pair_steps() {
-    static const bool on = getenv("EVC_PT_DIRECT") && atoi(getenv("EVC_PT_DIRECT")) != 0;
-    return on;
-}
-
 static bool use_pair_transform(int n) {
     static const bool off = getenv("EVC_NO_PAIR_TRANSFORM") != nullptr;
     return !off && n <= kPairTransformMaxN;
@@ -125,7 +116,7 @@ static bool is_sym8(int layout) { return layout == EVC_LAYOUT_SYM8; }
 // Y2 with the half-transformed integrals recomputed (transform.hip y2_fused_kernel): the energy phase then keeps the
 // dense (pair, pair) intermediate of its first pair step in the K3 buffer instead of writing K3 (EVC_Y2_FUSED=0: K3)
 static bool use_fused_y2(bool sym8, int n) {
-    return sym8 && use_pair_transform(n) && y2_fused_available(n) && !use_direct_pair_steps();
+    return sym8 && use_pair_transform(n) && y2_fused_available(n);
 }
 static bool is_packed(int layout) { return layout == EVC_LAYOUT_ELEC3 || layout == EVC_LAYOUT_PACK2 || is_sym8(layout); }
 static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout == EVC_LAYOUT_PACK2 || is_sym8(layout); }
@@ -305,16 +296,11 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
             pa.lead_sym = pa.in_lower = pa.rs_lower = is_sym8(t->layout) ? 1 : 0;
             pa.in_pairs = g.eri_s4;       // int2e handed over as the dense (pair, pair) matrix (EVC_FLAG_ERI_S4)
             pa.out_pairs = pa.lead_sym;   // the intermediate as a dense (pair, pair) matrix
-            const bool direct = is_sym8(t->layout) && use_direct_pair_steps();
-            const bool direct1 = direct && g.eri_s4;   // (a full int2e goes through the staged kernel's gather)
-            pa.direct = direct1 ? 1 : 0;
             int pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
             if ((rc = launch_pair_transform(pa, cc, st))) return rc;
             prof_stop(pr, st);
             pa.in_pairs = pa.out_pairs;
             pa.out_pairs = 0;
-            pa.direct = direct ? 1 : 0;
-            pa.in_cols = direct1 ? 1 : 0;   // a direct first step wrote rows by ITS leading pair
             // ... and the second step again only needs the q <= p half of ITS leading pair
             pa.in = mid;
             pa.sin = sw;
@@ -566,8 +552,6 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.lead_sym = pa.in_lower = pa.rs_lower = sym8;   // SB is fully symmetric
                 pa.in_pairs = (sym8 && !G) ? 1 : 0;
                 pa.out_pairs = sym8;
-                const bool directc = sym8 && !G && ip1_s2kl && use_direct_pair_steps();
-                pa.direct = directc ? 1 : 0;
                 pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
                 prof_stop(pr, st);
@@ -577,7 +561,6 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.out = w.B1 + o;
                 pa.in_pairs = pa.out_pairs;
                 pa.out_pairs = ip1_s2kl ? 2 : 0;   // the packed-ip1 dot wants the dense (pair, pair) form, weighted
-                pa.in_cols = directc ? 1 : 0;
                 pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
                 prof_stop(pr, st);

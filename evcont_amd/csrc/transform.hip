@@ -1086,183 +1086,6 @@ __global__ __launch_bounds__(256) void pt_pipe4_kernel(PairTransformArgs a) {
     iteration(std::false_type{}, niter);
 }
 
-// ------------------------------------------------------------------ barrier-free pair transform (symmetric pipeline)
-// Same arithmetic as pt_kernel for the fully symmetric case (dense (pair, pair) operands, q <= p leading pairs,
-// lower-triangle results), organised so that the waves never meet after X is staged: a wave fetches the matrix of its
-// leading pair L into its private LDS row -- a contiguous row (16-byte loads) or, when the operand was written by a
-// previous direct step, column L of it (8-byte loads at stride n(n+1)/2: the eight leading pairs a workgroup works
-// on at a time share their cache lines) --, runs the two products on the matrix cores and stores the lower triangle
-// of the result from its accumulators as one contiguous row: lanes l15 = consecutive s' give 128-byte runs.  The
-// staged kernel above spends its time around two workgroup barriers per eight pairs (LDS transpose, 64-byte store
-// runs); here the only LDS traffic is the wave's own operand row.
-template <int NPAD>
-__global__ __launch_bounds__(256) void pt_sym_kernel(PairTransformArgs a) {
-    constexpr int LDX = (NPAD % 32 == 0) ? NPAD + 16 : NPAD;
-    constexpr int KS = NPAD / 4;
-    constexpr int NT = NPAD / 16;
-    extern __shared__ __align__(16) double sm[];
-    double *Xs = sm;                                   // NPAD * LDX
-    const int n = a.n;
-    const int64_t g = blockIdx.y;
-    const double *__restrict__ in = a.in + g * a.sin;
-    const double *__restrict__ C = a.C + g * a.sC;
-    const int npairs = n * (n + 1) / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    double *mrow = Xs + NPAD * LDX + wave * kPtRowLen;
-    const int ppw = a.tiles_per_wg * 8;                // leading pairs per workgroup, dealt to its waves in turn
-    const int L0 = blockIdx.x * ppw, L1 = min(npairs, L0 + ppw);
-    if (L0 >= L1) return;
-    const bool cols = a.in_cols != 0;
-    const int nraw = cols ? (npairs + 63) / 64 : (npairs + 1 + 127) / 128;   // wave-uniform
-    double2 raw[kPtRawMax];
-    int dlt = 0, dlt_next = 0;
-    int foff[NT][KS];
-#pragma unroll
-    for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const int r = rt * 16 + l15, s = 4 * kk + l4;
-            const int hi = s > r ? s : r, lo = s > r ? r : s;
-            foff[rt][kk] = (r < n && s < n) ? hi * (hi + 1) / 2 + lo : kPtRawMax * 128;   // else: a zero slot
-        }
-    if (lane < 4) mrow[kPtRawMax * 128 + lane] = 0.0;
-    auto fetch = [&](bool ok, int L, int &d_) {
-        if (cols) {   // column L: element e = 64 u + lane (two per register pair: u even / odd)
-            d_ = 0;
-#pragma unroll
-            for (int u = 0; u < kPtRawMax; ++u) {
-                const int e0 = 128 * u + lane, e1 = e0 + 64;
-                double2 v = make_double2(0.0, 0.0);
-                if (2 * u < nraw && ok && e0 < npairs) v.x = in[(int64_t)e0 * npairs + L];
-                if (2 * u + 1 < nraw && ok && e1 < npairs) v.y = in[(int64_t)e1 * npairs + L];
-                raw[u] = v;
-            }
-        } else {
-            const double *row = in + (int64_t)(ok ? L : 0) * npairs;
-            d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
-            const double *w0 = row - d_;
-            const int lim = npairs + d_;
-#pragma unroll
-            for (int u = 0; u < kPtRawMax; ++u) {
-                if (u < nraw) {
-                    const int j = 128 * u + 2 * lane;
-                    double2 v = make_double2(0.0, 0.0);
-                    if (ok) {
-                        if (j + 1 < lim) v = *reinterpret_cast<const double2 *>(w0 + j);
-                        else if (j < lim) v.x = w0[j];
-                    }
-                    raw[u] = v;
-                }
-            }
-        }
-    };
-    auto to_fragments = [&](double (&m)[NT][KS], int d_) {
-        if (cols) {
-#pragma unroll
-            for (int u = 0; u < kPtRawMax; ++u) {
-                if (2 * u < nraw) mrow[128 * u + lane] = raw[u].x;
-                if (2 * u + 1 < nraw) mrow[128 * u + 64 + lane] = raw[u].y;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < kPtRawMax; ++u)
-                if (u < nraw) *reinterpret_cast<double2 *>(mrow + 128 * u + 2 * lane) = raw[u];
-        }
-#pragma unroll
-        for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) m[rt][kk] = mrow[foff[rt][kk] + d_];
-    };
-    double mf[NT][KS];
-    int L = L0 + wave;
-    bool have = L < L1;
-    fetch(have, L, dlt);
-    for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += 256) {
-        const int d = idx / NPAD, c = idx % NPAD;
-        double v = 0.0;
-        if (d < n && c < n) v = a.ct ? C[c * n + d] : C[d * n + c];
-        Xs[d * LDX + c] = v;
-    }
-    lds_barrier();
-    double xf[KS][NT];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) xf[kk][t] = Xs[(4 * kk + l4) * LDX + t * 16 + l15];
-    to_fragments(mf, dlt);
-    if (a.packed && blockIdx.x == 0) {   // zero the padding [M, packed_len) once per geometry
-        double *pk = a.packed + g * a.spacked;
-        const int64_t M = (int64_t)npairs * (npairs + 1) / 2;
-        for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
-    }
-    while (have) {   // wave-uniform
-        const int Ln = L + 4;
-        const bool have_next = Ln < L1;
-        fetch(have_next, Ln, dlt_next);
-        const int p = (int)tri_row(L), q = L - p * (p + 1) / 2;
-        // H = M X
-        d4 h[NT][NT];
-#pragma unroll
-        for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-            for (int st = 0; st < NT; ++st) h[rt][st] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                for (int st = 0; st < NT; ++st) h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], h[rt][st]);
-        if (a.k3) {   // K3[s'][tri(p,q)][r] = H[r][s'] times the multiplicity of (p,q)
-            double *K3 = a.k3 + g * a.sk3;
-            const double km = (p != q) ? 2.0 : 1.0;
-            const int64_t kcol = (int64_t)L * n, krow = (int64_t)npairs * n;
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                for (int st = 0; st < NT; ++st)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int r = rt * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
-                        if (r < n && s2 < n) K3[s2 * krow + kcol + r] = h[rt][st][reg] * km;
-                    }
-        }
-        // N = X^T H, lower tiles only
-        d4 nn[NT][NT];
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-#pragma unroll
-            for (int st = 0; st < NT; ++st) nn[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int it = 0; it < NT; ++it)
-#pragma unroll
-                for (int st = 0; st <= it; ++st) nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], nn[it][st]);
-        // results straight from the accumulators: row L, column v = tri(r', s')
-        double *orow = a.out ? a.out + g * a.sout + (int64_t)L * npairs : nullptr;
-        double *prow = a.packed ? a.packed + g * a.spacked + (int64_t)L * (L + 1) / 2 : nullptr;
-        const double mL = (p != q) ? 2.0 : 1.0;
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-#pragma unroll
-            for (int st = 0; st <= it; ++st)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int r2 = it * 16 + l4 + 4 * reg, s2 = st * 16 + l15;
-                    if (r2 < n && s2 <= r2) {
-                        const int v = r2 * (r2 + 1) / 2 + s2;
-                        const double val = nn[it][st][reg], mv = (r2 != s2) ? 2.0 : 1.0;
-                        if (orow) orow[v] = a.out_pairs > 1 ? val * mv : val;
-                        if (prow && v <= L) prow[v] = val * ((v == L ? a.diag_mult : 1.0) * mL * mv);
-                    }
-                }
-        to_fragments(mf, dlt_next);
-        have = have_next;
-        L = Ln;
-    }
-}
-
 int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t st) {
     PairTransformArgs a = a_in;
     const int n = a.n;
@@ -1274,27 +1097,6 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     const int ntiles = a.lead_sym ? (n * (n + 1) / 2 + 7) / 8 : n * ntq;
     const dim3 grid((unsigned)((ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
     const size_t stage_rows = a.rs_lower ? (size_t)n * (n + 1) / 2 : (size_t)n * n;
-    if (a.direct) {
-        if (!(a.lead_sym && a.in_lower && a.rs_lower && a.in_pairs) || (a.packed && !a.sym8) || (a.out && !a.out_pairs)) {
-            set_error("pair_transform: the direct kernel needs the fully symmetric (pair, pair) case");
-            return -1;
-        }
-        a.tiles_per_wg = (count < 4 || tpw_env < 1) ? 1 : tpw_env;
-        const int npairs = n * (n + 1) / 2, ppw = a.tiles_per_wg * 8;
-        const dim3 gridd((unsigned)((npairs + ppw - 1) / ppw), (unsigned)count);
-        if (npad == 16) {
-            const size_t lds = sizeof(double) * ((size_t)16 * 16 + (size_t)4 * kPtRowLen + 2);
-            hipLaunchKernelGGL(pt_sym_kernel<16>, gridd, dim3(256), lds, st, a);
-        } else if (npad == 32) {
-            const size_t lds = sizeof(double) * ((size_t)32 * 48 + (size_t)4 * kPtRowLen + 2);
-            hipLaunchKernelGGL(pt_sym_kernel<32>, gridd, dim3(256), lds, st, a);
-        } else {
-            set_error("pair_transform: n=%d not supported (1..32)", n);
-            return -1;
-        }
-        EVC_LAUNCH_CHECK("pair_transform_direct");
-        return 0;
-    }
     // fully symmetric step of the compressed layout's pipeline: the software-pipelined kernel, if two of its workgroups
     // fit a CU's LDS (n <= 30; EVC_PT_PIPE=0: the phase-alternating kernel below)
     static const bool pipe_on = !(getenv("EVC_PT_PIPE") && atoi(getenv("EVC_PT_PIPE")) == 0);

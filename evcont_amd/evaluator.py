@@ -13,6 +13,7 @@ PyTorch is used for device memory and streams only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -23,6 +24,64 @@ from . import _lib
 from ._lib import TrdmSet, Geometry, Outputs, check
 
 F64 = torch.float64
+
+# EVCONT_AMD_CHECK_SYM: the compressed layout (EVC_LAYOUT_SYM8) and the packed s4 / s2kl inputs are exact only for AO
+# integrals with the index symmetries of real two-electron integrals (include/evcont_hip.h).  "1" (default): every
+# evaluator on the compressed layout verifies them on its FIRST call (and every host-side packing helper on its first
+# use) and raises instead of returning wrong forces; "2": on every call; "0": never.
+_CHECK_SYM = os.environ.get("EVCONT_AMD_CHECK_SYM", "1")
+_host_checks_done = set()
+
+
+def check_integral_symmetry(eri, eri_ip1, n: int, tol: float = 1.0e-9, what: str = "") -> None:
+    """Raise ``EvcontHipError`` unless ``eri`` is 8-fold symmetric ((pq|rs) = (qp|rs) = (pq|sr) = (rs|pq)) and
+    ``eri_ip1[x,p,q,r,s] = eri_ip1[x,p,q,s,r]``, to ``tol`` relative to the largest element.  Arrays may be numpy or
+    torch, with any number of leading batch axes; ``eri`` may be the packed s4 matrix (Ms, Ms) (then only the
+    pair-exchange symmetry is left to check), ``eri_ip1`` packed s2kl (nothing left to check) or None."""
+    npr = n * (n + 1) // 2
+    is_t = torch.is_tensor(eri)
+    mx = (lambda x: float(x.abs().max().item())) if is_t else (lambda x: float(np.abs(x).max()))
+    bad = []
+    if eri is not None and n > 1:
+        if eri.shape[-1] == npr and eri.shape[-2] == npr and (eri.ndim < 4 or eri.shape[-3] != n):
+            e = eri.reshape(-1, npr, npr)
+            sw = (lambda x, a, b: x.transpose(a, b)) if is_t else (lambda x, a, b: np.swapaxes(x, a, b))
+            scale = max(mx(e), 1e-300)
+            if mx(e - sw(e, 1, 2)) > tol * scale:
+                bad.append("eri (packed s4): (pq|rs) != (rs|pq)")
+        else:
+            e = eri.reshape(-1, n, n, n, n)
+            sw = (lambda x, a, b: x.transpose(a, b)) if is_t else (lambda x, a, b: np.swapaxes(x, a, b))
+            scale = max(mx(e), 1e-300)
+            if mx(e - sw(e, 1, 2)) > tol * scale:
+                bad.append("eri: (pq|rs) != (qp|rs)")
+            if mx(e - sw(e, 3, 4)) > tol * scale:
+                bad.append("eri: (pq|rs) != (pq|sr)")
+            if mx(e - sw(sw(e, 1, 3), 2, 4)) > tol * scale:
+                bad.append("eri: (pq|rs) != (rs|pq)")
+    if eri_ip1 is not None and n > 1 and eri_ip1.shape[-1] == n and eri_ip1.ndim >= 5:
+        x = eri_ip1.reshape(-1, n, n, n, n)
+        sw = (lambda y, a, b: y.transpose(a, b)) if torch.is_tensor(x) else (lambda y, a, b: np.swapaxes(y, a, b))
+        mxx = (lambda y: float(y.abs().max().item())) if torch.is_tensor(x) else (lambda y: float(np.abs(y).max()))
+        scale = max(mxx(x), 1e-300)
+        if mxx(x - sw(x, 3, 4)) > tol * scale:
+            bad.append("eri_ip1[x,p,q,r,s] != eri_ip1[x,p,q,s,r]")
+    if bad:
+        raise _lib.EvcontHipError(
+            "AO integrals without the index symmetries of real two-electron integrals (" + "; ".join(bad) + ")"
+            + (f" in {what}" if what else "") + ": the 8-fold compressed t-RDM layout (compress='sym8') and the packed "
+            "s4 / s2kl inputs would give wrong energies / forces for them.  Use the reference layouts (compress=None) "
+            "for such tensors; EVCONT_AMD_CHECK_SYM=0 disables this check.")
+
+
+def _host_check_once(tag: str) -> bool:
+    """Whether a host-side packing helper should verify the symmetries now (EVCONT_AMD_CHECK_SYM)."""
+    if _CHECK_SYM == "0":
+        return False
+    if _CHECK_SYM == "2" or tag not in _host_checks_done:
+        _host_checks_done.add(tag)
+        return True
+    return False
 
 
 def _dev(device=None) -> torch.device:
@@ -267,6 +326,8 @@ class DeviceAO:
         npr = n * (n + 1) // 2
         eri = np.asarray(ao.eri)
         s4 = eri.ndim == 2 and eri.shape == (npr, npr) and n > 1
+        if (pack_eri or pack_ip1) and not energy_only and _host_check_once("DeviceAO.from_arrays"):
+            check_integral_symmetry(eri, np.asarray(ao.eri_ip1), n, what="DeviceAO.from_arrays(pack_...=True)")
         if pack_eri and not s4:
             iu, ju = np.tril_indices(n)
             eri = eri.reshape(n, n, n, n)[iu, ju][:, iu, ju]
@@ -360,6 +421,19 @@ class DeviceAOBatch:
                                   eri_ip1=p(self.eri_ip1), gnuc=p(self.gnuc), aoslices=p(self.aoslices))
 
 
+def _check_sym_first_call(ev, ao, energy_only: bool = False) -> None:
+    """First call of an evaluator on the compressed layout (every call with EVCONT_AMD_CHECK_SYM=2): verify on the
+    device, on the evaluator's stream, that the integrals have the symmetries the layout relies on."""
+    if ev.t.layout != _lib.LAYOUT_SYM8 or _CHECK_SYM == "0" or (_CHECK_SYM != "2" and getattr(ev, "_sym_checked", False)):
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    st = ev.stream if ev.stream is not None else torch.cuda.current_stream(ev.t.device)
+    with torch.cuda.stream(st):
+        check_integral_symmetry(ao.eri, None if energy_only else ao.eri_ip1, ev.t.n, what=type(ev).__name__)
+    ev._sym_checked = True
+
+
 def _ip1_flag(trdms: "DeviceTRDMs", ao) -> int:
     """EVC_FLAG_IP1_S2KL / EVC_FLAG_ERI_S4 for geometries whose integrals are handed over packed."""
     f = (_lib.FLAG_IP1_S2KL if getattr(ao, "ip1_s2kl", False) else 0) | \
@@ -427,6 +501,7 @@ class BatchedEvaluator:
 
     def enqueue(self, aob: DeviceAOBatch, nroots: int = 1, energy_only: bool = False) -> None:
         assert aob.count == self.count, "batch size is fixed at construction"
+        _check_sym_first_call(self, aob, energy_only)
         g = aob.cstruct()
         flags = (_lib.FLAG_ENERGY_ONLY if energy_only else 0) | _ip1_flag(self.t, aob)
         if getattr(self, "_loewdin_done", False):
@@ -453,6 +528,7 @@ class BatchedEvaluator:
         """Scaled two-body rows of this rank's pairs -> ``rows_out[g, :rows_local]`` (row stride = rows_out.stride(0))."""
         assert rows_out.dtype == F64 and rows_out.dim() == 2 and rows_out.shape[0] == self.count
         assert rows_out.stride(1) == 1 and rows_out.shape[1] >= self.t.rows_local
+        _check_sym_first_call(self, aob)
         g = aob.cstruct()
         flags = _ip1_flag(self.t, aob) & _lib.FLAG_ERI_S4
         if getattr(self, "_loewdin_done", False):
@@ -590,6 +666,7 @@ class ContinuationEvaluator:
     # -- single-device fused path -------------------------------------------------------------
     def enqueue(self, ao: DeviceAO, nroots: int = 1, energy_only: bool = False) -> None:
         """Enqueue one evaluation on torch's current stream; no synchronisation."""
+        _check_sym_first_call(self, ao, energy_only)
         g = ao.cstruct()
         flags = (_lib.FLAG_ENERGY_ONLY if energy_only else 0) | _ip1_flag(self.t, ao)
         if self.warm_start and self._primed:
@@ -629,6 +706,7 @@ class ContinuationEvaluator:
     # -- phase API for the pair-sharded multi-GPU host (evcont_amd/distributed.py) -----------------
     def phase_hamiltonian(self, ao: DeviceAO) -> torch.Tensor:
         """Returns a view of this rank's scaled two-body rows (length rows_local) in the workspace."""
+        _check_sym_first_call(self, ao)
         g = ao.cstruct()
         p_rows, p_h1 = C.c_void_p(), C.c_void_p()
         flags = _ip1_flag(self.t, ao) & _lib.FLAG_ERI_S4

@@ -9,13 +9,15 @@ produces the AO integrals of every step on the host and the continuation consume
   them, so a producer that can write into a caller-supplied array (``mol.intor(..., out=...)``) fills them without an
   extra copy;
 * static device buffers, workspace and outputs;
-* ONE HIP graph of the whole step: upload of the small early inputs (S, hcore, int2e, ...) -> Loewdin, integral
-  rotation, H build, eigensolve on the main branch, while a forked branch uploads the late, large inputs
+* the step as a two-stream enqueue: upload of the small early inputs (S, hcore, int2e, ...) -> Loewdin, integral
+  rotation, H build, eigensolve on the main stream, while a forked stream uploads the late, large inputs
   (``int2e_ip1``, ``dhcore``), which only the gradient tail reads -> join -> predicted RDMs and gradient -> download of
-  E and the forces into pinned memory.  A step is then one ``hipGraphLaunch`` instead of ~8 copies + 15 kernel
-  launches, and the PCIe transfer of the 10 MB array overlaps the first half of the device work.
+  E and the forces into pinned memory; the PCIe transfer of the 10 MB array overlaps the first half of the device
+  work.  DEFAULT: enqueued eagerly every step.  Opt-in (``use_graph=True`` / ``EVCONT_AMD_HOSTED_GRAPH=1``): the same
+  enqueue captured once and replayed as ONE HIP graph -- measured slower on MI355X / ROCm 7.2 (0.58 against 0.39 ms at
+  H30, no gain for the small systems), kept correct by ``tests/test_gpu_drivers.py``.
 
-No CPU fallback: the graph only contains HIP work of ``libevcont_hip.so`` and copies.
+No CPU fallback: the step only contains HIP work of ``libevcont_hip.so`` and copies.
 """
 from __future__ import annotations
 
@@ -96,6 +98,9 @@ class HostedEvaluator:
         st["enuc"][0] = float(ao.enuc)
         eri, ip1 = np.asarray(ao.eri), np.asarray(ao.eri_ip1)
         if self.packed:
+            from .evaluator import _host_check_once, check_integral_symmetry
+            if _host_check_once("HostedEvaluator.stage"):   # (packing below keeps one triangle: it must be THE triangle)
+                check_integral_symmetry(eri, ip1, n, what="HostedEvaluator.stage")
             iu, ju = np.tril_indices(n)
             if eri.size != st["eri"].size:
                 eri = eri.reshape(n, n, n, n)[iu, ju][:, iu, ju]

@@ -224,6 +224,9 @@ typedef struct evc_outputs {
                                    (hosted MD) or with the previous batch's streaming kernels (throughput).  Batch entry
                                    points only. */
 
+/* The workspace also caches the inverse Cholesky factor of t->s_train next to the matrix it was computed from; a call
+ * whose s_train is bit-identical to that copy reuses the factor.  ZERO-FILL a workspace once after allocating it (the
+ * Python layer does): a recycled allocation must not look like a hit. */
 size_t evc_workspace_bytes(const evc_trdm_set *t, int natm);
 
 /* Phase A: Loewdin + integrals + H rows.  Writes h2rows_local[rows2] (scaled two-body rows of this

@@ -117,6 +117,17 @@ def test_cache_fingerprint():
     assert cache.key_of(a, b, S) != k1                # in-place change seen by the content sample
     cache.put(k1, "x")
     assert cache.get(k1) == "x" and cache.get(("other",)) is None
+    # block checksums: an edit the strided sample of the key does not see is caught when the entry is reused
+    big = np.random.default_rng(2).standard_normal((4, 4, 6, 6, 6, 6))           # 82944 elements, sample stride 20
+    kb = cache.key_of(a, big, S)
+    cache.put(kb, "y", (a, big, S))
+    assert cache.get(kb, (a, big, S)) == "y"
+    big.reshape(-1)[7] += 1.0e-3                                                    # not a sampled element
+    assert cache.key_of(a, big, S) == kb
+    assert cache.get(kb, (a, big, S)) == "y" or cache.get(kb, (a, big, S)) is None   # a spot check may or may not see it
+    cache.put(kb, "z", (a, big, S))
+    big.reshape(-1)[7] -= 1.0e-3
+    assert cache.get(kb, (a, big, S)) is None                                       # first reuse verifies every block
     for i in range(10):
         cache.put(("k", i), i)
     assert cache.get(k1) is None                      # LRU eviction

@@ -128,9 +128,9 @@ def test_hosted_evaluator_matches_resident_path():
     two_p = pack_rows(two, True, True)
     a0 = make_ao_arrays(n, A, 31, ao_sizes=(9, 2, 2), ip1_rs_symmetric=True)
     a1 = make_ao_arrays(n, A, 32, ao_sizes=(9, 2, 2), ip1_rs_symmetric=True)
-    for comp in (None, "sym8"):
+    for comp, graph in ((None, True), ("sym8", False), ("sym8", True), (None, False)):
         trd = DeviceTRDMs(one, two_p, S, dev, compress=comp)
-        hev = HostedEvaluator(trd, A, a0.aoslices, use_graph=(comp is None))
+        hev = HostedEvaluator(trd, A, a0.aoslices, use_graph=graph)
         ref = ContinuationEvaluator(trd, A)
         assert hev.packed == (comp == "sym8")
         for k in range(7):
@@ -139,7 +139,7 @@ def test_hosted_evaluator_matches_resident_path():
             Er, gr = ref.energy_with_grad(DeviceAO.from_arrays(ao, dev, pack_ip1=hev.packed, pack_eri=hev.packed))
             assert abs(E - Er) < 1e-11, (comp, k)
             np.testing.assert_allclose(g, gr, rtol=0, atol=1e-10)
-        assert (hev.graph is not None) == (comp is None)
+        assert (hev.graph is not None) == graph
 
 
 @pytest.mark.parametrize("script,args", [

@@ -162,3 +162,29 @@ def test_zundel_shape_T100_against_oracle(G):
         de = max(abs(E[k] - want[k][0]) for k in slots)
         dg = max(float(np.abs(grad[k] - want[k][1]).max()) for k in slots)
         assert de < 1e-10 and dg < 1e-9, (leg, de, dg)
+
+
+@pytest.mark.parametrize("G", [1, 3])
+def test_h2o_vtz_shape_n58_against_oracle(G):
+    """cc-pVTZ water, the reference's largest orbital space (scripts/MD/H2O/md_H2O_vtz_CAS_continuation.py:31: N = 58,
+    AO slices 30/14/14), T = 8: the full pipeline beyond the 32-orbital fast path, pack2 and sym8, against the oracle on
+    the pack2 rows."""
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, BatchedEvaluator
+    from evcont_amd.synthetic import make_device_ao, make_device_trdm_rows
+    n, A, T, sizes = 58, 3, 8, (30, 14, 14)
+    dev = torch.device(DEV)
+    S, one, rows = make_device_trdm_rows(n, T, 2, 4500, dev)
+    aos = [make_device_ao(n, A, 4500000 + k, dev, sizes, ip1_rs_symmetric=True) for k in range(G)]
+    slots = sorted({0, G - 1})
+    one_h, two_h, S_h = one.cpu().numpy(), rows.cpu().numpy(), S.cpu().numpy()
+    want = {k: orc.energy_with_grad(_bundle_from_device(aos[k]), one_h, two_h, S_h) for k in slots}
+    del two_h
+    trd = DeviceTRDMs.from_device_rows(one, rows, S, 2)
+    got = {"pack2": BatchedEvaluator(trd, A, G).energies_with_grads(DeviceAOBatch.stack(aos))}
+    trd.compress_sym8_()
+    del rows
+    got["sym8"] = BatchedEvaluator(trd, A, G).energies_with_grads(DeviceAOBatch.stack(aos))
+    for leg, (E, grad) in got.items():
+        de = max(abs(E[k] - want[k][0]) for k in slots)
+        dg = max(float(np.abs(grad[k] - want[k][1]).max()) for k in slots)
+        assert de < 1e-10 and dg < 1e-9, (leg, de, dg)

@@ -85,21 +85,40 @@ def test_sym8_matches_reference_layouts(n, T, A, lname):
     np.testing.assert_allclose(e, np.asarray(eo) + ao.enuc, rtol=0, atol=1e-10)
 
 
-def test_sym8_needs_the_integral_symmetry():
-    """With a general (not r<->s symmetric) eri_ip1 the compressed layout must NOT be expected to agree:
-    documents the precondition (energies still agree, forces differ: the pipeline reads eri_ip1 and the
+def test_sym8_needs_the_integral_symmetry(monkeypatch):
+    """With a general (not r<->s symmetric) eri_ip1 the compressed layout is NOT exact.  By default the first call of
+    an evaluator verifies the symmetries on the device and raises (EVCONT_AMD_CHECK_SYM=1); with the check disabled
+    the documented behaviour shows: energies still agree, forces differ (the pipeline reads eri_ip1 and the
     intermediates of the two rotations in their lower triangles only)."""
-    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
+    from evcont_amd import evaluator as evm
+    from evcont_amd._lib import EvcontHipError
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, DeviceAOBatch, ContinuationEvaluator, BatchedEvaluator
     dev = torch.device("cuda:0")
     n, T, A = 6, 3, 3
     S, one, two = make_trdms(n, T, 5)
     ao = make_ao_arrays(n, A, 6)                       # general eri_ip1
-    ev = ContinuationEvaluator(DeviceTRDMs(one, two, S, dev, compress="sym8"), A)
+    trd = DeviceTRDMs(one, two, S, dev, compress="sym8")
+    with pytest.raises(EvcontHipError, match="eri_ip1"):
+        ContinuationEvaluator(trd, A).energy_with_grad(DeviceAO.from_arrays(ao, dev))
+    with pytest.raises(EvcontHipError, match="eri_ip1"):
+        BatchedEvaluator(trd, A, 2).energies_with_grads(DeviceAOBatch.from_arrays([ao, ao], dev))
+    monkeypatch.setattr(evm, "_host_checks_done", set())
+    with pytest.raises(EvcontHipError, match="eri_ip1"):          # the host-side packing helper checks as well
+        DeviceAO.from_arrays(ao, dev, pack_ip1=True, pack_eri=True)
+    bad = make_ao_arrays(n, A, 7, ip1_rs_symmetric=True)
+    bad.eri = bad.eri + 1e-3 * np.random.default_rng(1).standard_normal(bad.eri.shape)      # not 8-fold symmetric
+    with pytest.raises(EvcontHipError, match="eri:"):
+        ContinuationEvaluator(trd, A).energy_with_grad(DeviceAO.from_arrays(bad, dev))
+    # energy-only calls do not look at eri_ip1
+    ContinuationEvaluator(trd, A).energies(DeviceAO.from_arrays(ao, dev, energy_only=True), 1)
+    monkeypatch.setattr(evm, "_CHECK_SYM", "0")
+    ev = ContinuationEvaluator(trd, A)
     E, g = ev.energy_with_grad(DeviceAO.from_arrays(ao, dev))
     Eo, go = orc.energy_with_grad(bundle(ao), one, two, S)
     assert abs(E - Eo) < 1e-10
     assert np.abs(g - go).max() > 1e-4
-    # symmetrising eri_ip1 in its last two indices restores the agreement
+    monkeypatch.setattr(evm, "_CHECK_SYM", "2")
+    # symmetrising eri_ip1 in its last two indices restores the agreement (and passes the check on every call)
     ao.eri_ip1 = np.ascontiguousarray(0.5 * (ao.eri_ip1 + ao.eri_ip1.transpose(0, 1, 2, 4, 3)))
     E, g = ev.energy_with_grad(DeviceAO.from_arrays(ao, dev))
     Eo, go = orc.energy_with_grad(bundle(ao), one, two, S)

@@ -17,15 +17,11 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
 
 @pytest.mark.parametrize("env", [
     {"EVC_PT_PIPE": "0"},                     # phase-alternating pair transform (pt_kernel) instead of pt_pipe_kernel
-    {"EVC_PT_PIPE": "0", "EVC_PT_DIRECT": "1"},   # barrier-free pair transform (pt_sym_kernel)
     {"EVC_PT_PIPE": "0", "EVC_PT_ROWBUF": "0"},   # pt_kernel with the per-lane gather
     {"EVC_PT_PIPE4": "0"},                    # a few geometries through pt_pipe_kernel (8-pair tiles) instead of pt_pipe4_kernel
     {"EVC_PT_TILES": "1"},                    # pipelined pair transform, one tile per workgroup (two matrices per wave)
     {"EVC_PT_TILES": "3"},                    # ... an odd number of tiles (last workgroup ragged)
     {"EVC_Y2_FUSED": "0"},                    # K3 stored by the second pair step, split-K Y2 over it
-    {"EVC_ROWS_NARROW_WGS": "240"},           # K5 spans cut in 32-column chunks (span_cols not a multiple of 512)
-    {"EVC_ROWS_SHAPE2_NARROW": "722"},        # eight-wave split-set K5
-    {"EVC_ROWS_SHAPE2_NARROW": "422"},
     {"EVC_EIGH_F32": "0"},                    # FP64 Jacobi eigensolvers
     {"EVC_EIGH_F32": "1"},                    # FP32 Jacobi start + refinement
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
