@@ -1225,6 +1225,7 @@ static int eigh_fast_enabled() {
 }
 
 int launch_loewdin(const LoewdinArgs &a_in, int count, hipStream_t st) {
+    if (a_in.n > kJwMax && a_in.n <= 64) return launch_loewdin_big(a_in, count, st);
     LoewdinArgs a = a_in;
     a.fast = eigh_fast_enabled();
     const int m = (a.n + 1) & ~1;

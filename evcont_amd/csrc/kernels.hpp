@@ -146,6 +146,7 @@ struct LoewdinArgs {
     int fast;  // set by launch_loewdin: FP32 Jacobi + FP64 refinement for n <= 32 (EVC_EIGH_F32=0: FP64 Jacobi)
 };
 int launch_loewdin(const LoewdinArgs &a, int count, hipStream_t st);
+int launch_loewdin_big(const LoewdinArgs &a, int count, hipStream_t st);   // subspace_big.hip: 32 < n <= 64
 struct SolveArgs {
     const double *h1part;  // (nsp1, T*T) partial sums of the one-body rows      + g*sh1
     int nsp1;

@@ -483,6 +483,121 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
     EVC_BSTAMP(7);
 }
 
+// ------------------------------------------------------------------ Loewdin orthogonalisation, 32 < n <= 64
+// S = U diag(s) U^T by the same one-sided Jacobi (S is positive definite: no shift), X = U diag(s > 1e-15 ? s^-1/2 : 0) U^T,
+// h1 = X^T h X (electron_integral_utils.py:6-18,135; gradients_loewdin.py:336-338), three matrices in LDS.  Replaces the
+// two-sided LDS Jacobi of dense_small.hip for these sizes (1.4 ms at n = 58: cc-pVTZ water).
+__global__ __launch_bounds__(kBT) void loewdin_big_kernel(LoewdinArgs a) {
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n, m = (n + 1) & ~1, Tp = (n + 15) & ~15, Pj = (m + 31) & ~31;
+    const int64_t g = blockIdx.x;
+    const double *__restrict__ S = a.S + g * a.sS;
+    const double *__restrict__ h = a.h ? a.h + g * a.sh : nullptr;
+    double *__restrict__ X = a.X + g * a.sws;
+    double *__restrict__ U = a.U + g * a.sws;
+    double *__restrict__ sv = a.s + g * a.sws;
+    double *__restrict__ h1 = a.h1 ? a.h1 + g * a.sws : nullptr;
+    const size_t Tp2 = (size_t)Tp * Tp;
+    const size_t gsz = (size_t)m * Pj > Tp2 ? (size_t)m * Pj : Tp2;
+    double *G = sm, *A = G + gsz, *B = A + Tp2, *f = B + Tp2, *red = f + Tp;
+    const int tid = threadIdx.x;
+    // numpy.linalg.eigh reads the lower triangle
+    bool warm = false;
+    if (a.warm) {   // A = Vt (rows = previous eigenvectors), B = S symmetrised; G0 = Vt S
+        for (size_t idx = tid; idx < Tp2; idx += kBT) {
+            const int i = (int)(idx / Tp), j = (int)(idx - (size_t)i * Tp);
+            const bool in = i < n && j < n;
+            A[idx] = in ? U[(size_t)j * n + i] : 0.0;
+            B[idx] = in ? S[(size_t)(i > j ? i : j) * n + (i > j ? j : i)] : 0.0;
+        }
+        __syncthreads();
+        double dev = 0.0;
+        big_mm_rr(Tp, A, Tp, A, Tp, [&](int i, int j, double v) {
+            const double e = v - ((i == j && i < n) ? 1.0 : 0.0);
+            dev = fma(e, e, dev);
+        });
+        dev = big_block_sum(dev, red);
+        warm = dev < 1.0e-16;
+    }
+    for (size_t idx = tid; idx < (size_t)m * Pj; idx += kBT) {
+        const int j = (int)(idx / Pj), i = (int)(idx - (size_t)j * Pj);
+        G[idx] = (!warm && i < n && j < n) ? S[(size_t)(i > j ? i : j) * n + (i > j ? j : i)] : 0.0;
+    }
+    __syncthreads();
+    if (warm) {
+        big_mm_rr(Tp, A, Tp, B, Tp, [&](int j, int i, double v) {
+            if (j < n && i < n) G[(size_t)j * Pj + i] = v;
+        });
+        __syncthreads();
+    }
+    big_jacobi(G, m, Pj, red);
+    for (int j = tid >> 4; j < m; j += kBT / 16) {
+        const int s = tid & 15;
+        double nn = 0.0;
+        for (int i = 2 * s; i < Pj; i += 32) {
+            const double2 x = *reinterpret_cast<const double2 *>(G + (size_t)j * Pj + i);
+            nn = fma(x.x, x.x, fma(x.y, x.y, nn));
+        }
+        nn = sum16(nn);
+        const double l = sqrt(nn);
+        const double inv = l > 1.0e-300 ? 1.0 / l : 0.0;
+        for (int i = 2 * s; i < Pj; i += 32) {
+            double2 x = *reinterpret_cast<const double2 *>(G + (size_t)j * Pj + i);
+            x.x *= inv;
+            x.y *= inv;
+            *reinterpret_cast<double2 *>(G + (size_t)j * Pj + i) = x;
+        }
+        if (s == 0 && j < Tp) {
+            f[j] = (j < n && l > 1.0e-15) ? 1.0 / sqrt(l) : 0.0;
+            if (j < n) sv[j] = l;
+        }
+    }
+    __syncthreads();
+    // (a zero column -- the decoupled dummy dimension of an odd n -- stays zero and has f = 0)
+    for (size_t idx = tid; idx < Tp2; idx += kBT) {
+        const int i = (int)(idx / Tp), k = (int)(idx - (size_t)i * Tp);
+        const bool in = i < n && k < n;
+        const double v = in ? G[(size_t)k * Pj + i] : 0.0;
+        A[idx] = v;
+        B[idx] = in ? v * f[k] : 0.0;
+        if (in) U[(size_t)i * n + k] = v;
+    }
+    __syncthreads();
+    // X = (V f) V^T, kept at pitch Tp in the G region (free now)
+    for (size_t idx = tid; idx < Tp2; idx += kBT) G[idx] = 0.0;
+    __syncthreads();
+    big_mm_rr(Tp, B, Tp, A, Tp, [&](int i, int j, double v) {
+        if (i < n && j < n) {
+            G[(size_t)i * Tp + j] = v;
+            X[(size_t)i * n + j] = v;
+        }
+    });
+    if (!(h && h1)) return;
+    __syncthreads();
+    for (size_t idx = tid; idx < Tp2; idx += kBT) {
+        const int i = (int)(idx / Tp), j = (int)(idx - (size_t)i * Tp);
+        A[idx] = (i < n && j < n) ? h[(size_t)i * n + j] : 0.0;
+    }
+    __syncthreads();
+    // Tt[j][i] = (h X)[i][j] = sum_k X[j][k] h[i][k] (X symmetric);  h1[i][j] = sum_k X[i][k] Tt[j][k]
+    big_mm_rr(Tp, G, Tp, A, Tp, [&](int j, int i, double v) { B[(size_t)j * Tp + i] = v; });
+    __syncthreads();
+    big_mm_rr(Tp, G, Tp, B, Tp, [&](int i, int j, double v) {
+        if (i < n && j < n) h1[(size_t)i * n + j] = v;
+    });
+}
+
+int launch_loewdin_big(const LoewdinArgs &a, int count, hipStream_t st) {
+    const size_t n = a.n, m = (n + 1) & ~(size_t)1, Tp = (n + 15) & ~(size_t)15, Pj = (m + 31) & ~(size_t)31;
+    const size_t gsz = m * Pj > Tp * Tp ? m * Pj : Tp * Tp;
+    const size_t lds = sizeof(double) * (gsz + 2 * Tp * Tp + Tp + 2 * kBW) + 64;
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(loewdin_big_kernel, attr, 160 * 1024, "loewdin_big")) return rc;
+    hipLaunchKernelGGL(loewdin_big_kernel, dim3(count), dim3(kBT), lds, st, a);
+    EVC_LAUNCH_CHECK("loewdin_big");
+    return 0;
+}
+
 static size_t big_aux_bytes(int T) {
     const int Tp = (T + 15) & ~15;
     return sizeof(double) * ((size_t)4 * Tp + 2 * kBW) + sizeof(int) * (size_t)Tp + 64;

@@ -45,7 +45,7 @@ def with_spectrum(vals, rng):
 
 
 @pytest.mark.parametrize("kind", ["random", "degenerate", "triple", "cluster1e-6", "cluster1e-10", "graded"])
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 13, 16, 17, 24, 29, 30, 31, 32, 33, 40])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 13, 16, 17, 24, 29, 30, 31, 32, 33, 40, 47, 58, 63, 64, 70])
 def test_loewdin_spectra(kind, n):
     rng = np.random.default_rng(1000 + n)
     vals = spectrum(kind, n, rng) if n > 1 else np.array([1.7])

@@ -18,7 +18,8 @@ def blend(a0: AOArrays, a1: AOArrays, t: float) -> AOArrays:
                     float(mix(a0.enuc, a1.enuc)), mix(a0.gnuc, a1.gnuc))
 
 
-@pytest.mark.parametrize("n,T,A,lname", [(13, 5, 3, "pack2"), (30, 6, 30, "pack2"), (8, 4, 2, "full6")])
+@pytest.mark.parametrize("n,T,A,lname", [(13, 5, 3, "pack2"), (30, 6, 30, "pack2"), (8, 4, 2, "full6"),
+                                          (37, 40, 3, "pack2")])   # large-n Loewdin + large-T subspace kernels
 def test_warm_start_matches_cold_start(n, T, A, lname):
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
     dev = torch.device("cuda:0")
@@ -43,11 +44,12 @@ def test_warm_start_matches_cold_start(n, T, A, lname):
         np.testing.assert_allclose(ew, ec, rtol=0, atol=1e-11)
 
 
+@pytest.mark.parametrize("n,T", [(9, 4), (35, 40)])
 @pytest.mark.parametrize("fill", ["zeros", "nan", "random"])
-def test_warm_flag_on_stale_workspace_falls_back(fill):
+def test_warm_flag_on_stale_workspace_falls_back(fill, n, T):
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
     dev = torch.device("cuda:0")
-    n, T, A = 9, 4, 3
+    A = 3
     S, one, two = make_trdms(n, T, 5)
     trd = DeviceTRDMs(one, pack_rows(two, True, True), S, dev)
     dao = DeviceAO.from_arrays(make_ao_arrays(n, A, 11), dev)
@@ -65,7 +67,7 @@ def test_warm_flag_on_stale_workspace_falls_back(fill):
     np.testing.assert_allclose(gw, gc, rtol=0, atol=1e-10)
 
 
-@pytest.mark.parametrize("n,T,A", [(13, 5, 3), (10, 20, 4)])
+@pytest.mark.parametrize("n,T,A", [(13, 5, 3), (10, 20, 4), (6, 70, 2)])
 def test_cached_overlap_factorisation_follows_the_training_set(n, T, A):
     """The inverse Cholesky factor of S_train is cached in the workspace (it does not depend on the geometry) next to
     the matrix it was computed from: a workspace that is reused with ANOTHER training set of the same shape (the C ABI
