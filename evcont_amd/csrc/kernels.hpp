@@ -173,6 +173,7 @@ struct SolveArgs {
                                   // B = L^-1 (second block) was computed from -- S_train does not depend on the
                                   // geometry, so every call after the first finds its factorisation here
                                   // (T > kSubspaceSmallT: two blocks of Tp^2, Tp = T rounded up to 16, B at pitch Tp)
+    int few;                      // set by launch_subspace_big: nroots <= 4 through the tridiagonal route (EVC_SUBSPACE_FEW)
     double *scratch;              // T > kSubspaceSmallT: subspace_big_scratch_doubles(T) doubles + g*sscratch
     int64_t sscratch;
 };

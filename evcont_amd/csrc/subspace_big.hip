@@ -224,6 +224,286 @@ __device__ __forceinline__ void big_jacobi(double *G, int m, int Pj, double *red
     }
 }
 
+// ------------------------------------------------------------------ a FEW lowest eigenpairs (nroots <= kFewRoots)
+// The energy + force path asks for ONE root of the T x T standard-form matrix, approximate_multistate for a handful; the
+// Jacobi sweeps above compute all T eigenpairs in ~9 (T - 1) latency-bound steps.  For nroots <= kFewRoots the matrix is
+// instead (i) reduced to tridiagonal form by T - 2 Householder reflections in LDS (LAPACK dsytd2: 4 barriers per step, the
+// symmetric matrix kept in full so that a column is a contiguous row; the reflectors stay in the rows they annihilated),
+// (ii) its lowest eigenvalues are located by multisection on the Sturm count (256 abscissae per root and round, IEEE
+// division: the count is monotone, so the bracket -- and the result -- is deterministic), (iii) each eigenvector of the
+// tridiagonal matrix comes from a twisted factorisation (two lanes run it from both ends at once), is carried back
+// through the reflectors by one wave with the vector in registers (wave_sum, no barrier), and (iv) is CHECKED: residual
+// and mutual orthogonality in the original matrix.  Anything short of that (a tight cluster among the requested roots,
+// an overflow in the recurrences) makes the caller fall back to the Jacobi path.
+constexpr int kFewRoots = 4;
+
+struct BigFew {   // LDS scratch (doubles of length Tp unless noted)
+    double *d, *e, *tau, *vv, *pv, *ww;   // diagonal, sub-diagonal, reflector scalars; Householder work vectors
+    double *dp, *dm, *Y;                  // [kFewRoots][Tp]: forward / backward pivots, eigenvectors
+    unsigned short *cnt;                  // [kBT] Sturm counts of a multisection round
+    double *iv;                           // [2 kFewRoots + 4] brackets, scalars
+    double *lam;                          // [kFewRoots]
+};
+
+__device__ __forceinline__ int big_sturm(const double *d, const double *e2, int n, double x, double pivmin) {
+    double q = d[0] - x;
+    int c = q < 0.0 ? 1 : 0;
+    for (int i = 1; i < n; ++i) {
+        if (fabs(q) < pivmin) q = -pivmin;
+        q = (d[i] - x) - e2[i - 1] / q;
+        c += q < 0.0 ? 1 : 0;
+    }
+    return c;
+}
+
+// A: symmetric n x n matrix at pitch P in LDS (destroyed).  Returns true (uniform) when lam[r], Y[r * P + i], r < nroots, hold
+// verified eigenpairs of the matrix C (global, pitch P, symmetric) the caller loaded into A; `scale`: a bound on |C|.
+__device__ __forceinline__ bool big_few_roots(double *A, const double *Cg, int n, int P, int nroots, double scale,
+                                              const BigFew &w, double *red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l8 = tid & 7, r8 = tid >> 3;
+    // (i) Householder tridiagonalisation
+    {
+        double part = 0.0;
+        for (int j = 2 + tid; j < n; j += kBT) part = fma(A[j], A[j], part);
+        part = big_block_sum(part, red);
+        if (tid == 0) w.iv[0] = part;   // |x[1:]|^2 of the first column
+        __syncthreads();
+    }
+    for (int k = 0; k + 1 < n; ++k) {
+        const double xn2 = w.iv[0], alpha = A[(size_t)k * P + k + 1];
+        double tau = 0.0, beta = alpha, sc = 0.0;
+        if (xn2 > 0.0) {
+            beta = -copysign(sqrt(fma(alpha, alpha, xn2)), alpha);
+            tau = (beta - alpha) / beta;
+            sc = 1.0 / (alpha - beta);
+        }
+        // live columns k+1 .. n-1 sit in the 16-column chunks cb .. cb + nch - 1 (nch <= 8); v and w are kept ZERO on the
+        // other columns of those chunks, so the row loops below need no guards (rows are zero beyond n)
+        const int cb = (k + 1) >> 4, nch = ((n - 1) >> 4) - cb + 1;
+        for (int j = 16 * cb + tid; j < 16 * (cb + nch); j += kBT) {
+            const bool live = j > k && j < n;
+            const double v = !live ? 0.0 : (j == k + 1 ? 1.0 : A[(size_t)k * P + j] * sc);
+            w.vv[j] = v;
+            // the reflector stays in row k; its leading 1 is implicit (A[k][k+1] is `alpha`, which the other waves may
+            // still be reading)
+            if (live && j > k + 1) A[(size_t)k * P + j] = v;
+        }
+        if (tid == 0) {
+            w.d[k] = A[(size_t)k * P + k];
+            w.e[k] = beta;
+            w.tau[k] = tau;
+        }
+        __syncthreads();
+        if (tau != 0.0) {   // uniform
+            // p = tau A22 v: 8 lanes per row, 16 bytes per lane and chunk (odd rows take the chunks in swapped pairs: the
+            // rows of an LDS phase spread over the banks), and p . v in the same pass
+            double pd = 0.0;
+            for (int i = k + 1 + r8; i < n; i += kBT / 8) {
+                const double *row = A + (size_t)i * P + 16 * cb + 2 * l8;
+                const double *vp = w.vv + 16 * cb + 2 * l8;
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < nch) {
+                        int uu = u ^ (i & 1);
+                        if (uu >= nch) uu = u;
+                        const double2 av = *reinterpret_cast<const double2 *>(row + 16 * uu);
+                        const double2 vv2 = *reinterpret_cast<const double2 *>(vp + 16 * uu);
+                        t0 = fma(av.x, vv2.x, t0);
+                        t1 = fma(av.y, vv2.y, t1);
+                    }
+                const double t = sum8(t0 + t1) * tau;
+                if (l8 == 0) {
+                    w.pv[i] = t;
+                    pd = fma(t, w.vv[i], pd);
+                }
+            }
+            pd = wave_sum(pd);
+            if (lane == 0) red[wave] = pd;
+            __syncthreads();
+            double pvd = 0.0;
+#pragma unroll
+            for (int q = 0; q < kBW; ++q) pvd += red[q];
+            const double K = 0.5 * tau * pvd;
+            for (int j = 16 * cb + tid; j < 16 * (cb + nch); j += kBT) w.ww[j] = (j > k && j < n) ? w.pv[j] - K * w.vv[j] : 0.0;
+            __syncthreads();
+            // A22 -= v w^T + w v^T; the group that owns row k + 1 also leaves |x[1:]|^2 of the next column
+            for (int i = k + 1 + r8; i < n; i += kBT / 8) {
+                double *row = A + (size_t)i * P + 16 * cb + 2 * l8;
+                const double *vp = w.vv + 16 * cb + 2 * l8, *wp = w.ww + 16 * cb + 2 * l8;
+                const double vi = w.vv[i], wi = w.ww[i];
+                double nx = 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < nch) {
+                        int uu = u ^ (i & 1);
+                        if (uu >= nch) uu = u;
+                        double2 av = *reinterpret_cast<const double2 *>(row + 16 * uu);
+                        const double2 vv2 = *reinterpret_cast<const double2 *>(vp + 16 * uu);
+                        const double2 ww2 = *reinterpret_cast<const double2 *>(wp + 16 * uu);
+                        av.x -= vi * ww2.x + wi * vv2.x;
+                        av.y -= vi * ww2.y + wi * vv2.y;
+                        *reinterpret_cast<double2 *>(row + 16 * uu) = av;
+                        const int j = 16 * (cb + uu) + 2 * l8;
+                        if (j > k + 2) nx = fma(av.x, av.x, nx);
+                        if (j + 1 > k + 2) nx = fma(av.y, av.y, nx);
+                    }
+                if (i == k + 1) {   // uniform over the group (columns beyond n are zero)
+                    nx = sum8(nx);
+                    if (l8 == 0) w.iv[0] = nx;
+                }
+            }
+        } else {
+            // no reflection: the next column's norm from the untouched matrix
+            if (tid < 64) {
+                double nx = 0.0;
+                for (int j = k + 3 + lane; j < n; j += 64) nx = fma(A[(size_t)(k + 1) * P + j], A[(size_t)(k + 1) * P + j], nx);
+                nx = wave_sum(nx);
+                if (lane == 0) w.iv[0] = nx;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) w.d[n - 1] = A[(size_t)(n - 1) * P + n - 1];
+    __syncthreads();
+    EVC_BSTAMP(8);
+    // (ii) multisection: e2 -> vv, Gershgorin bracket, 256 abscissae per root and round
+    double gl = 1.0e300, gu = -1.0e300, emax = 0.0;
+    for (int i = tid; i < n; i += kBT) {
+        const double el = i > 0 ? fabs(w.e[i - 1]) : 0.0, er = i + 1 < n ? fabs(w.e[i]) : 0.0;
+        gl = fmin(gl, w.d[i] - el - er);
+        gu = fmax(gu, w.d[i] + el + er);
+        emax = fmax(emax, er);
+        if (i + 1 < n) w.vv[i] = w.e[i] * w.e[i];
+    }
+    gl = -big_block_max(-gl, red);
+    gu = big_block_max(gu, red);
+    emax = big_block_max(emax, red);
+    const double tnorm = fmax(fabs(gl), fabs(gu));
+    if (!(tnorm < 1.0e300)) return false;   // NaN / Inf input (uniform)
+    const double pivmin = fmax(1.0e-290, 1.0e-290 * emax * emax);
+    const int root = tid >> 8, t = tid & 255;
+    if (tid < 2 * kFewRoots) w.iv[2 + tid] = (tid & 1) ? gu + 2.3e-16 * tnorm * n : gl - 2.3e-16 * tnorm * n;
+    __syncthreads();
+    for (int round = 0; round < 7; ++round) {   // 257^7 = 7e16 > 2^53 x the guard factor
+        double lo = 0.0, hi = 0.0, x = 0.0;
+        if (root < nroots) {
+            lo = w.iv[2 + 2 * root];
+            hi = w.iv[3 + 2 * root];
+            x = lo + (hi - lo) * ((double)(t + 1) * (1.0 / 257.0));
+            w.cnt[tid] = (unsigned short)big_sturm(w.d, w.vv, n, x, pivmin);
+        }
+        __syncthreads();
+        if (root < nroots) {
+            const int need = root + 1, c = w.cnt[tid], cprev = t > 0 ? w.cnt[tid - 1] : 0;
+            if (c >= need && (t == 0 || cprev < need)) {   // exactly one thread (the count is monotone), or none
+                w.iv[3 + 2 * root] = x;
+                if (t > 0) w.iv[2 + 2 * root] = lo + (hi - lo) * ((double)t * (1.0 / 257.0));
+            } else if (t == 255 && c < need) {
+                w.iv[2 + 2 * root] = x;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < nroots) w.lam[tid] = 0.5 * (w.iv[2 + 2 * tid] + w.iv[3 + 2 * tid]);
+    __syncthreads();
+    EVC_BSTAMP(9);
+    // (iii) eigenvectors: wave r takes root r
+    if (wave < nroots) {
+        const double lamr = w.lam[wave];
+        double *dp = w.dp + (size_t)wave * P, *dm = w.dm + (size_t)wave * P, *Y = w.Y + (size_t)wave * P;
+        if (lane < 2) {   // lane 0: pivots from the top, lane 1: from the bottom
+            const int dir = lane;
+            int i = dir ? n - 1 : 0;
+            double q = w.d[i] - lamr;
+            for (int step = 0; step < n; ++step) {
+                if (fabs(q) < pivmin) q = -pivmin;
+                (dir ? dm : dp)[i] = q;
+                const int in = dir ? i - 1 : i + 1;
+                if (in < 0 || in >= n) break;
+                const double ee = w.e[dir ? in : i];
+                q = (w.d[in] - lamr) - (ee / q) * ee;
+                i = in;
+            }
+        }
+        // (LDS operations of one wave complete in order)
+        double g0 = 1.0e300, g1 = 1.0e300;
+        if (lane < n) g0 = fabs(dp[lane] + dm[lane] - (w.d[lane] - lamr));
+        if (lane + 64 < n) g1 = fabs(dp[lane + 64] + dm[lane + 64] - (w.d[lane + 64] - lamr));
+        double gm = fmin(g0, g1);
+        gm = fmin(gm, dpp_move<0xB1>(gm));
+        gm = fmin(gm, dpp_move<0x4E>(gm));
+        gm = fmin(gm, dpp_move<0x141>(gm));
+        gm = fmin(gm, dpp_move<0x140>(gm));
+        gm = fmin(fmin(readlane_f64(gm, 0), readlane_f64(gm, 16)), fmin(readlane_f64(gm, 32), readlane_f64(gm, 48)));
+        const unsigned long long b0 = __ballot(g0 == gm), b1 = __ballot(g1 == gm);
+        const int kt = b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : 0);   // (NaNs: 0, caught by the check)
+        if (lane < 2) {   // lane 0 walks up from the twist index, lane 1 down
+            double z = 1.0;
+            if (lane == 0) {
+                Y[kt] = 1.0;
+                for (int j = kt; j > 0; --j) {
+                    z = -(w.e[j - 1] / dp[j - 1]) * z;
+                    Y[j - 1] = z;
+                }
+            } else {
+                for (int j = kt; j + 1 < n; ++j) {
+                    z = -(w.e[j] / dm[j + 1]) * z;
+                    Y[j + 1] = z;
+                }
+            }
+        }
+        double z0 = lane < n ? Y[lane] : 0.0, z1 = lane + 64 < n ? Y[lane + 64] : 0.0;
+        {
+            const double nn = wave_sum(fma(z0, z0, z1 * z1));
+            const double inv = 1.0 / sqrt(nn);
+            z0 *= inv;
+            z1 *= inv;
+        }
+        // back through the reflectors: z <- H_0 H_1 ... H_{n-3} z (H_k acts on indices k+1 .. n-1; row k of A holds v_k)
+        for (int k = n - 3; k >= 0; --k) {
+            const double tk = w.tau[k];
+            const double *vr = A + (size_t)k * P;
+            const double v0 = lane == k + 1 ? 1.0 : ((lane > k + 1 && lane < n) ? vr[lane] : 0.0);
+            const double v1 = lane + 64 == k + 1 ? 1.0 : ((lane + 64 > k + 1 && lane + 64 < n) ? vr[lane + 64] : 0.0);
+            const double sdot = wave_sum(fma(v0, z0, v1 * z1)) * tk;
+            z0 = fma(-sdot, v0, z0);
+            z1 = fma(-sdot, v1, z1);
+        }
+        if (lane < n) Y[lane] = z0;
+        if (lane + 64 < n) Y[lane + 64] = z1;
+    }
+    __syncthreads();
+    EVC_BSTAMP(10);
+    // (iv) check in the original matrix: residuals and mutual orthogonality
+    double worst = 0.0;
+    for (int r = 0; r < nroots; ++r) {
+        const double *Y = w.Y + (size_t)r * P;
+        const double lamr = w.lam[r];
+        for (int i = r8; i < n; i += kBT / 8) {
+            double t2 = 0.0;
+            for (int j = l8; j < n; j += 8) t2 = fma(Cg[(size_t)i * P + j], Y[j], t2);
+            t2 = sum8(t2);
+            worst = big_nanmax(worst, fabs(t2 - lamr * Y[i]));
+        }
+        for (int r2 = 0; r2 < r; ++r2) {
+            if (wave == 0) {
+                const double *Y2 = w.Y + (size_t)r2 * P;
+                double dd = 0.0;
+                for (int j = lane; j < n; j += 64) dd = fma(Y[j], Y2[j], dd);
+                dd = wave_sum(dd);
+                worst = big_nanmax(worst, fabs(dd) * 10.0 * scale);   // |y_r . y_r'| <= 1e-12 (close roots: eps / gap)
+            }
+        }
+    }
+    worst = big_block_max(worst, red);
+    EVC_BSTAMP(11);
+    EVC_BVAL(2, worst / scale);
+    EVC_BVAL(3, w.lam[0]);
+    EVC_BVAL(4, w.iv[3] - w.iv[2]);
+    return worst <= 1.0e-11 * scale;   // (NaN: false)
+}
+
 // In-place Cholesky factor of the lower triangle in M (pitch Tp) followed by its in-place inverse: on return the lower
 // triangle of M holds B = L^-1.  A matrix that is not positive definite yields NaNs.  dinv, tmp: T doubles each.
 __device__ __forceinline__ void big_chol_inverse(double *M, int T, int Tp, double *dinv, double *tmp) {
@@ -288,6 +568,19 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
     double *aux = kLds ? sm + msz : sm;
     double *ev = aux, *tmp = ev + Tp, *c0 = tmp + Tp, *dinv = c0 + Tp, *red = dinv + Tp;
     int *order = reinterpret_cast<int *>(red + 2 * kBW);
+    BigFew fw;   // (the Householder work vectors share the buffers of the phases that are over / not yet reached)
+    fw.d = ev;
+    fw.vv = tmp;
+    fw.pv = dinv;
+    fw.ww = c0;
+    fw.e = reinterpret_cast<double *>(order + Tp + (Tp & 1));
+    fw.tau = fw.e + Tp;
+    fw.dp = fw.tau + Tp;
+    fw.dm = fw.dp + (size_t)kFewRoots * Tp;
+    fw.Y = fw.dm + (size_t)kFewRoots * Tp;
+    fw.iv = fw.Y + (size_t)kFewRoots * Tp;
+    fw.lam = fw.iv + 2 * kFewRoots + 4;
+    fw.cnt = reinterpret_cast<unsigned short *>(fw.lam + kFewRoots);
     const int tid = threadIdx.x;
     const int64_t P = (int64_t)T * (T + 1) / 2;
     const bool pairs = (a.layout == EVC_LAYOUT_PAIR5 || a.layout == EVC_LAYOUT_PACK2 || a.layout == EVC_LAYOUT_SYM8);
@@ -389,6 +682,17 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
     rmax = big_block_max(rmax, red);
     const double shift = 2.0 * rmax + 1.0e-300;   // eigenvalues of the shifted matrix within [1, 3] x the bound
     EVC_BSTAMP(4);
+    // (d') a few roots: tridiagonal route, verified; anything else (or a failed check): all eigenpairs by Jacobi
+    bool few = false;
+    if (kLds && a.few && a.nroots <= kFewRoots && T <= 128) {   // uniform
+        for (size_t idx = tid; idx < Tp2; idx += kBT) M[idx] = Cg[idx];
+        __syncthreads();
+        few = big_few_roots(M, Cg, T, Tp, a.nroots, rmax + 1.0e-300, fw, red);
+        EVC_BVAL(1, few ? 1.0 : 0.0);
+        __syncthreads();
+    }
+    EVC_BSTAMP(5);
+    if (!few) {
     // (d) G0, column-major with pitch Pj
     bool warm = false;
     if (a.warm && a.vstd) {   // uniform: the previous eigenvectors (rows of vstd, pitch Tp) must be orthonormal
@@ -413,9 +717,7 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
         });
         __syncthreads();
     }
-    EVC_BSTAMP(5);
     big_jacobi(M, m, Pj, red);
-    EVC_BSTAMP(6);
     // column norms = eigenvalues + shift; normalised columns = eigenvectors
     for (int j = tid >> 4; j < m; j += kBT / 16) {
         const int s = tid & 15;
@@ -449,15 +751,20 @@ __global__ __launch_bounds__(kBT) void subspace_big_kernel(SolveArgs a) {
         order[rank] = j;
     }
     __syncthreads();
+    }   // !few
+    EVC_BSTAMP(6);
     // back-transformation c_i = sum_{k >= i} B[k][i] y_k for the requested roots
     for (int idx = tid; idx < a.nroots * T; idx += kBT) {
-        const int root = idx / T, i = idx - root * T, col = order[root];
+        const int root = idx / T, i = idx - root * T;
+        const double *y = few ? fw.Y + (size_t)root * Tp : M + (size_t)order[root] * Pj;
         double c = 0.0;
-        for (int k = i; k < T; ++k) c = fma(Bg[(size_t)k * Tp + i], M[(size_t)col * Pj + k], c);
+        for (int k = i; k < T; ++k) c = fma(Bg[(size_t)k * Tp + i], y[k], c);
         a.evecs[idx] = c;
-        if (root == 0) c0[i] = c;
+        if (root == 0) tmp[i] = c;   // (c0 may still hold Householder work: staged in tmp, copied below)
     }
-    for (int r = tid; r < a.nroots; r += kBT) a.evals[r] = ev[order[r]] + a.e_shift;
+    for (int r = tid; r < a.nroots; r += kBT) a.evals[r] = (few ? fw.lam[r] : ev[order[r]]) + a.e_shift;
+    __syncthreads();
+    for (int i = tid; i < T; i += kBT) c0[i] = tmp[i];
     __syncthreads();
     // weights of root 0 for the predicted RDMs (gradients_loewdin.py:343-356)
     if (a.w1)
@@ -600,7 +907,8 @@ int launch_loewdin_big(const LoewdinArgs &a, int count, hipStream_t st) {
 
 static size_t big_aux_bytes(int T) {
     const int Tp = (T + 15) & ~15;
-    return sizeof(double) * ((size_t)4 * Tp + 2 * kBW) + sizeof(int) * (size_t)Tp + 64;
+    return sizeof(double) * ((size_t)4 * Tp + 2 * kBW) + sizeof(int) * (size_t)(Tp + 2) +
+           sizeof(double) * ((size_t)(2 + 3 * kFewRoots) * Tp + 3 * kFewRoots + 8) + sizeof(unsigned short) * kBT + 64;
 }
 static size_t big_matrix_doubles(int T) {
     const size_t m = (T + 1) & ~1, Tp = (T + 15) & ~15, Pj = (m + 31) & ~(size_t)31;
@@ -613,7 +921,11 @@ size_t subspace_big_scratch_doubles(int T) {
     return 3 * Tp * Tp + (big_fits_lds(T) ? 0 : big_matrix_doubles(T));
 }
 
-int launch_subspace_big(const SolveArgs &a, int count, hipStream_t st) {
+int launch_subspace_big(const SolveArgs &a_in, int count, hipStream_t st) {
+    SolveArgs a = a_in;
+    // EVC_SUBSPACE_FEW=0: every call through the Jacobi sweeps (A/B timing, tests of that path)
+    static const int few_on = getenv("EVC_SUBSPACE_FEW") ? atoi(getenv("EVC_SUBSPACE_FEW")) : 1;
+    a.few = few_on;
     if (!a.scratch) {
         set_error("subspace solve: T=%d needs a scratch buffer (evc_subspace_solve_ws_bytes)", a.T);
         return -1;

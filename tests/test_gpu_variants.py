@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.py::test_sym8_batched",
+          "tests/test_gpu_large_T.py::test_small_n_batched", "tests/test_gpu_large_T.py::test_warm_start_T100",
           "tests/test_gpu_bench_config.py::test_h2o_shape_t10_against_oracle",
           "tests/test_gpu_bench_config.py::test_k5_every_row_group_body"]
 
@@ -22,6 +23,7 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
     {"EVC_PT_TILES": "1"},                    # pipelined pair transform, one tile per workgroup (two matrices per wave)
     {"EVC_PT_TILES": "3"},                    # ... an odd number of tiles (last workgroup ragged)
     {"EVC_Y2_FUSED": "0"},                    # K3 stored by the second pair step, split-K Y2 over it
+    {"EVC_SUBSPACE_FEW": "0"},                # large-T subspace kernel: every call through the Jacobi sweeps
     {"EVC_EIGH_F32": "0"},                    # FP64 Jacobi eigensolvers
     {"EVC_EIGH_F32": "1"},                    # FP32 Jacobi start + refinement
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))

@@ -31,6 +31,9 @@ for T in Ts:
             lib = _lib.load(); st = (C.c_longlong * 16)(); va = (C.c_double * 16)()
             fn = lib.evc_debug_read_big; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
             fn(st, va, 16)
-            names = ["chol+inv", "assemble H", "W, C", "sym+shift", "G0", "jacobi", "tail"]
-            print("   ", ", ".join(f"{nm} {(st[i + 1] - st[i]) / 100.0:.1f}" for i, nm in enumerate(names)), f"us; sweeps {va[0]:.0f}")
+            names = ["chol+inv", "assemble H", "W, C", "sym+shift", "few roots", "jacobi", "tail"]
+            print("   ", ", ".join(f"{nm} {(st[i + 1] - st[i]) / 100.0:.1f}" for i, nm in enumerate(names)), f"us; sweeps {va[0]:.0f} few_ok {va[1]:.0f}")
+            print("    few: tridiag %.1f bisect %.1f vectors %.1f check %.1f us; worst/scale %.2e lam0 %.12f (scipy %.12f) bracket %.1e" % (
+                (st[8] - st[4]) / 100.0, (st[9] - st[8]) / 100.0, (st[10] - st[9]) / 100.0, (st[11] - st[10]) / 100.0, va[2], va[3],
+                __import__("scipy.linalg").linalg.eigh(Hs[0], S, eigvals_only=True)[0], va[4]))
         print(f"T={T:4d} count={count:3d}: {t0.elapsed_time(t1) / reps * 1e3:9.1f} us per launch   |dE0|={abs(float(e[0,0]) - w[0]):.2e}", flush=True)
