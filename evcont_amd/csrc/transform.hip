@@ -5,6 +5,8 @@
 //   K13     Gs^T symmetrisation + Y2 = K3 . Gs contraction      gradients_loewdin.py:210-222
 //   K15     int2e_ip1 diagonal contraction                      gradients_loewdin.py:234-252
 // blockIdx.y = geometry of the batch (kernels.hpp).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include <type_traits>
@@ -96,13 +98,20 @@ __global__ __launch_bounds__(256) void qt_kernel(const double *__restrict__ in, 
     }
 }
 
+// Grid: every workgroup stages X (up to 41 KB of LDS) before its first tile, so the launch wants PERSISTENT workgroups --
+// one resident round of the chip (the register budget of these kernels allows one wave per SIMD from 64 padded columns
+// on, two at 48, four below), each walking many tiles with the next tile's rows in flight -- not one workgroup per four
+// tiles (measured per quarter step, one geometry: n = 58 93 -> 48 us, n = 64 133 -> 66 us; a two-tile variant with
+// 16-byte operand loads added nothing on top and was dropped).
 template <int NPAD>
 static int qt_launch(const double *in, int64_t sin, const double *C, int64_t sC, int ct, int n, double *out,
                      int64_t sout, int count, hipStream_t st) {
     const int64_t rows = (int64_t)n * n * n;
+    constexpr int kResident = 256 * (NPAD >= 64 ? 1 : NPAD >= 48 ? 2 : 4);   // workgroups of one round
+    const int64_t share = (kResident + count - 1) / count;                   // per geometry of the batch
     const int64_t ntiles = (rows + 15) / 16;
     int64_t blocks = (ntiles + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > share) blocks = share;
     hipLaunchKernelGGL(qt_kernel<NPAD>, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, in, sin, C, sC, ct,
                        n, rows, out, sout);
     EVC_LAUNCH_CHECK("quarter_transform");
