@@ -10,8 +10,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+LARGE_T = ["tests/test_gpu_large_T.py::test_small_n_batched", "tests/test_gpu_large_T.py::test_warm_start_T100"]
 SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.py::test_sym8_batched",
-          "tests/test_gpu_large_T.py::test_small_n_batched", "tests/test_gpu_large_T.py::test_warm_start_T100",
           "tests/test_gpu_bench_config.py::test_h2o_shape_t10_against_oracle",
           "tests/test_gpu_bench_config.py::test_k5_every_row_group_body"]
 
@@ -30,6 +30,7 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
 def test_variant_passes_parity_subset(env):
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + SUBSET,
+    subset = LARGE_T if "EVC_SUBSPACE_FEW" in env else SUBSET
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + subset,
                        cwd=REPO, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
