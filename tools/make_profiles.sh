@@ -12,12 +12,15 @@ run() {  # tag, rocprof args..., -- bench args
   tag=$1; shift
   rocprofv3 "$@" > $O/$tag.log 2>&1
 }
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-md-regime --steps 20 --warmup 4"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-md-regime --steps 20 --warmup 4 --repeats 1"
 run stats_default      --kernel-trace --stats --output-format csv -d $O/stats_default -- $BENCH
 run stats_sym8_b32s1   --kernel-trace --stats --output-format csv -d $O/stats_sym8_b32s1 -- $BENCH --streams 1
 run stats_pack2_b32s1  --kernel-trace --stats --output-format csv -d $O/stats_pack2_b32s1 -- $BENCH --layout pack2 --streams 1
 run stats_sym8_md      --kernel-trace --stats --output-format csv -d $O/stats_sym8_md -- $BENCH --batch 1 --streams 1 --steps 60
 run stats_pack2_md     --kernel-trace --stats --output-format csv -d $O/stats_pack2_md -- $BENCH --layout pack2 --batch 1 --streams 1 --steps 60
+run stats_zundel100_b32s1 --kernel-trace --stats --output-format csv -d $O/stats_zundel100_b32s1 -- $BENCH --workload Zundel100 --streams 1 --steps 6 --warmup 2
+run stats_zundel100_md --kernel-trace --stats --output-format csv -d $O/stats_zundel100_md -- $BENCH --workload Zundel100 --batch 1 --streams 1 --steps 20 --warmup 2
+run stats_h2ovtz_b4s1  --kernel-trace --stats --output-format csv -d $O/stats_h2ovtz_b4s1 -- $BENCH --workload H2Ovtz --batch 4 --streams 1 --geoms 8 --steps 6 --warmup 2
 for lay in sym8 pack2; do
 run pmc_fetch_${lay}_b32 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_${lay}_b32 -- $BENCH --layout $lay --streams 1 --steps 8
 run pmc_write_${lay}_b32 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_${lay}_b32 -- $BENCH --layout $lay --streams 1 --steps 8
