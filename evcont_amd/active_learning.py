@@ -68,12 +68,17 @@ def subspace_energies(H: torch.Tensor, S: torch.Tensor, e_shift: Optional[torch.
     evals = torch.empty((count, T), dtype=F64, device=H.device)
     evecs = torch.empty((count, T, T), dtype=F64, device=H.device)
     es = e_shift.contiguous() if e_shift is not None else None
-    nws = lib.evc_subspace_solve_ws_bytes(T, count)   # 0 for T <= 32
-    ws = torch.empty(nws, dtype=torch.uint8, device=H.device) if nws else None
-    check(lib.evc_subspace_solve_batch(H.data_ptr(), S.data_ptr(), 0 if shared else T * T, T, count, int(nroots),
-                                       es.data_ptr() if es is not None else None, evals.data_ptr(),
-                                       evecs.data_ptr(), ws.data_ptr() if ws is not None else None, nws,
-                                       _stream_ptr(H.device)), "evc_subspace_solve_batch")
+    # T > 32: the kernel needs scratch per problem (evc_subspace_solve_ws_bytes); many problems go in chunks of <= 1 GiB
+    per = lib.evc_subspace_solve_ws_bytes(T, 1)
+    chunk = count if per == 0 else max(1, min(count, (1 << 30) // per))
+    ws = torch.empty(per * chunk, dtype=torch.uint8, device=H.device) if per else None
+    for c0 in range(0, count, chunk):
+        c1 = min(count, c0 + chunk)
+        check(lib.evc_subspace_solve_batch(H[c0:c1].data_ptr(), S.data_ptr() if shared else S[c0:c1].data_ptr(),
+                                           0 if shared else T * T, T, c1 - c0, int(nroots),
+                                           es[c0:c1].data_ptr() if es is not None else None, evals[c0:c1].data_ptr(),
+                                           evecs[c0:c1].data_ptr(), ws.data_ptr() if ws is not None else None,
+                                           per * (c1 - c0), _stream_ptr(H.device)), "evc_subspace_solve_batch")
     return evals[:, :nroots]
 
 

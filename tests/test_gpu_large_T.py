@@ -188,3 +188,26 @@ def test_h2o_vtz_shape_n58_against_oracle(G):
         de = max(abs(E[k] - want[k][0]) for k in slots)
         dg = max(float(np.abs(grad[k] - want[k][1]).max()) for k in slots)
         assert de < 1e-10 and dg < 1e-9, (leg, de, dg)
+
+
+def test_leave_one_out_energies_T40():
+    """The active-learning re-evaluations (MD_utils.py:264-299,448-483) at T = 40: the energies of every leave-one-out
+    subset (39 states: per-problem overlap matrices through the large-T subspace kernel, in chunks) and of the full set,
+    from ONE contraction per geometry, against scipy.linalg.eigh on the sub-matrices."""
+    import scipy.linalg as sla
+    from evcont_amd.active_learning import subset_energies
+    T, B = 40, 3
+    rng = np.random.default_rng(3801)
+    A = rng.standard_normal((T, T))
+    S = A @ A.T / T + np.eye(T)
+    H = rng.standard_normal((B, T, T))
+    H = 0.5 * (H + H.transpose(0, 2, 1)) - 3.0 * np.eye(T)
+    enuc = rng.standard_normal(B)
+    subsets = [[i for i in range(T) if i != j] for j in range(T)] + [list(range(T))]
+    got = subset_energies(torch.from_numpy(H).to(DEV), torch.from_numpy(S).to(DEV), torch.from_numpy(enuc).to(DEV),
+                          subsets).cpu().numpy()
+    for b in range(B):
+        for k, ids in enumerate(subsets):
+            ix = np.ix_(ids, ids)
+            want = sla.eigh(H[b][ix], S[ix], eigvals_only=True)[0] + enuc[b]
+            assert abs(got[b, k] - want) < 1e-10, (b, k, got[b, k], want)
