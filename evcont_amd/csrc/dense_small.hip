@@ -1225,7 +1225,8 @@ static int eigh_fast_enabled() {
 }
 
 int launch_loewdin(const LoewdinArgs &a_in, int count, hipStream_t st) {
-    if (a_in.n > kJwMax && a_in.n <= 64) return launch_loewdin_big(a_in, count, st);
+    // 32 < n <= 64: three matrices in LDS; up to 96 with two of them in the caller's scratch (a_in.scratch)
+    if (a_in.n > kJwMax && (a_in.n <= 64 || a_in.scratch)) return launch_loewdin_big(a_in, count, st);
     LoewdinArgs a = a_in;
     a.fast = eigh_fast_enabled();
     const int m = (a.n + 1) & ~1;
@@ -1647,6 +1648,23 @@ __global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) {
         });
         return;
     }
+    if (n > 64) {
+        // four n x n matrices no longer fit LDS: one product buffer, the operands through the caches
+        double *Ts = sm;   // n*n
+        mm16(n, [&](int i, int k) { return a.X[i * n + k]; }, [&](int k, int j) { return a.D[k * n + j]; },
+             [&](int i, int j, double v) { Ts[i * n + j] = v; });
+        __syncthreads();
+        mm16(n, [&](int i, int k) { return Ts[i * n + k]; }, [&](int k, int j) { return a.X[j * n + k]; },
+             [&](int i, int j, double v) { a.Pao[i * n + j] = v; });
+        __syncthreads();
+        mm16(n, [&](int i, int k) { return a.X[i * n + k]; },
+             [&](int k, int j) { return a.D[k * n + j] + a.D[j * n + k]; },
+             [&](int i, int j, double v) { Ts[i * n + j] = v; });
+        __syncthreads();
+        mm16(n, [&](int i, int k) { return a.hcore[i * n + k]; }, [&](int k, int j) { return Ts[k * n + j]; },
+             [&](int i, int j, double v) { a.Y1[i * n + j] = a.scale1 * v; });
+        return;
+    }
     double *Xs = sm;            // n*n
     double *Ds = Xs + n * n;    // n*n
     double *Hs = Ds + n * n;    // n*n
@@ -1670,7 +1688,8 @@ __global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) {
 }
 
 int launch_grad_prep(const GradPrepArgs &a, int count, hipStream_t st) {
-    const size_t lds = a.n <= 32 ? sizeof(double) * (size_t)6 * kRsz : sizeof(double) * (size_t)4 * a.n * a.n;
+    const size_t lds = a.n <= 32 ? sizeof(double) * (size_t)6 * kRsz
+                                 : sizeof(double) * (size_t)(a.n > 64 ? 1 : 4) * a.n * a.n;
     static LdsAttr attr;
     if (int rc = allow_dynamic_lds(grad_prep_kernel, attr, 160 * 1024, "grad_prep")) return rc;
     hipLaunchKernelGGL(grad_prep_kernel, dim3(count), dim3(kThreads), lds, st, a);
@@ -1697,11 +1716,13 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
         if (a.gnuc) a.gnuc += g * a.sgn;
         a.grad += g * a.sgrad;
     }
-    double *Y = sm;            // n*n
-    double *Q = Y + n * n;     // n*n
-    double *W = Q + n * n;     // n*n
-    double *Us = W + n * n;    // n*n
-    double *rs = Us + n * n;   // n   sqrt(s) (0 where guarded)
+    // n > 64: four n x n matrices do not fit LDS -- Y and U are then read through the caches (`wide`), Q and W stay
+    const bool wide = n > 64;
+    double *Y = sm;                          // n*n   (wide: unused, zero-sized)
+    double *Q = wide ? sm : Y + n * n;       // n*n
+    double *W = Q + n * n;                   // n*n
+    double *Us = wide ? W : W + n * n;       // n*n   (wide: unused, zero-sized)
+    double *rs = (wide ? W : Us) + n * n;    // n   sqrt(s) (0 where guarded)
     double *fs = rs + n;       // n   f(s)
     double *ss = fs + n;       // n   s
     double *t2 = ss + n;       // 3*n
@@ -1729,11 +1750,15 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
         }
         add[idx] = g;
     }
-    copy_to_lds(Us, a.U, n * n);
-    for (int idx = tid; idx < n * n; idx += kThreads) {
-        const int ai = idx / n, i = idx - ai * n;  // Y[a][i]; y2 is stored [i][a]
-        Y[idx] = a.Y1[idx] + 0.5 * a.y2[i * n + ai];
+    if (!wide) {
+        copy_to_lds(Us, a.U, n * n);
+        for (int idx = tid; idx < n * n; idx += kThreads) {
+            const int ai = idx / n, i = idx - ai * n;  // Y[a][i]; y2 is stored [i][a]
+            Y[idx] = a.Y1[idx] + 0.5 * a.y2[i * n + ai];
+        }
     }
+    auto Uv = [&](int i, int j) { return wide ? a.U[i * n + j] : Us[i * n + j]; };
+    auto Yv = [&](int k, int j) { return wide ? a.Y1[k * n + j] + 0.5 * a.y2[j * n + k] : Y[k * n + j]; };
     if (tid < n) {
         const double s = a.s[tid];
         const bool ok = s > 1.0e-15;
@@ -1755,11 +1780,11 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     }
     __syncthreads();
     // Q = U^T Y
-    mm16(n, [&](int i, int k) { return Us[k * n + i]; }, [&](int k, int j) { return Y[k * n + j]; },
+    mm16(n, [&](int i, int k) { return Uv(k, i); }, [&](int k, int j) { return Yv(k, j); },
          [&](int i, int j, double v) { Q[i * n + j] = v; });
     __syncthreads();
     // W = (Q U) o F
-    mm16(n, [&](int i, int k) { return Q[i * n + k]; }, [&](int k, int j) { return Us[k * n + j]; },
+    mm16(n, [&](int i, int k) { return Q[i * n + k]; }, [&](int k, int j) { return Uv(k, j); },
          [&](int i, int j, double v) {
              double F;
              if (rs[i] > 0.0 && rs[j] > 0.0) F = -1.0 / (rs[i] * rs[j] * (rs[i] + rs[j]));
@@ -1769,11 +1794,11 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
          });
     __syncthreads();
     // Q = U W
-    mm16(n, [&](int i, int k) { return Us[i * n + k]; }, [&](int k, int j) { return W[k * n + j]; },
+    mm16(n, [&](int i, int k) { return Uv(i, k); }, [&](int k, int j) { return W[k * n + j]; },
          [&](int i, int j, double v) { Q[i * n + j] = v; });
     __syncthreads();
     // W = Q U^T
-    mm16(n, [&](int i, int k) { return Q[i * n + k]; }, [&](int k, int j) { return Us[j * n + k]; },
+    mm16(n, [&](int i, int k) { return Q[i * n + k]; }, [&](int k, int j) { return Uv(j, k); },
          [&](int i, int j, double v) { W[i * n + j] = v; });
     __syncthreads();
     // grad[A,x] = - sum_{mu in A} sum_nu ip[x,mu,nu] (W[mu,nu] + W[nu,mu])
@@ -1819,7 +1844,7 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
 }
 
 int launch_grad_final(const GradFinalArgs &a, int count, hipStream_t st) {
-    const size_t lds = sizeof(double) * ((size_t)4 * a.n * a.n + 6 * a.n + 3 * (size_t)a.natm) +
+    const size_t lds = sizeof(double) * ((size_t)(a.n > 64 ? 2 : 4) * a.n * a.n + 6 * a.n + 3 * (size_t)a.natm) +
                        sizeof(int) * 2 * (size_t)a.natm + 16;
     static LdsAttr attr;
     if (int rc = allow_dynamic_lds(grad_final_kernel, attr, 160 * 1024, "grad_final")) return rc;

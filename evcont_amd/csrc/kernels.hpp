@@ -9,6 +9,7 @@
 
 namespace evc {
 
+constexpr int kMaxOrbitals = 96;   // N of the fused pipeline (quarter transforms: 16-wide tiles up to 96 padded columns)
 constexpr int kMaxBatchG = 32;  // geometries contracted per pass of the streaming kernels (matrix-core variants)
 
 // ---- gemv_stream.hip ---------------------------------------------------------------
@@ -144,6 +145,8 @@ struct LoewdinArgs {
     int n;
     int warm;  // U holds the eigenvectors of a previous, nearby S: start the Jacobi sweeps from them
     int fast;  // set by launch_loewdin: FP32 Jacobi + FP64 refinement for n <= 32 (EVC_EIGH_F32=0: FP64 Jacobi)
+    double *scratch;   // n > 64: 2 Tp^2 doubles (Tp = n rounded up to 16) + g*sscratch for two of the three work matrices
+    int64_t sscratch;  // (NULL: the LDS-only kernels, n <= 80)
 };
 int launch_loewdin(const LoewdinArgs &a, int count, hipStream_t st);
 int launch_loewdin_big(const LoewdinArgs &a, int count, hipStream_t st);   // subspace_big.hip: 32 < n <= 64

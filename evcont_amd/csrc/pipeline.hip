@@ -123,7 +123,7 @@ static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout =
 
 static int check_set(const evc_trdm_set *t) {
     EVC_REQUIRE(t != nullptr, "trdm_set is NULL");
-    EVC_REQUIRE(t->n >= 1 && t->n <= 64, "trdm_set: n=%d out of range 1..64", t->n);
+    EVC_REQUIRE(t->n >= 1 && t->n <= kMaxOrbitals, "trdm_set: n=%d out of range 1..%d", t->n, kMaxOrbitals);
     EVC_REQUIRE(t->ntrain >= 1 && t->ntrain <= kSubspaceMaxT, "trdm_set: ntrain=%d out of range 1..%d", t->ntrain,
                 kSubspaceMaxT);
     EVC_REQUIRE(t->layout == 6 || t->layout == 5 || t->layout == 3 || t->layout == 2 || t->layout == EVC_LAYOUT_SYM8,
@@ -262,6 +262,8 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
     la.sws = sw;
     la.n = n;
     la.warm = w.warm ? 1 : 0;
+    la.scratch = w.B1;   // (free until the integral rotation; n > 64 only)
+    la.sscratch = sw;
     if (!w.loewdin_done) {
         const int pr = prof_start(EVC_PROF_LOEWDIN, st);
         if ((rc = launch_loewdin(la, cnt, st))) return rc;
@@ -962,6 +964,8 @@ extern "C" int evc_phase_loewdin_batch(const evc_trdm_set *t, const evc_geometry
     la.sws = w.stride;
     la.n = t->n;
     la.warm = (flags & EVC_FLAG_WARM_START) ? 1 : 0;
+    la.scratch = w.B1;
+    la.sscratch = w.stride;
     return launch_loewdin(la, gb->count, as_stream(stream));
 }
 
@@ -1091,7 +1095,7 @@ static int64_t integrals_ws_stride(int n) {
 }
 
 extern "C" size_t evc_integrals_oao_ws_bytes(int n, int count) {
-    if (n < 1 || n > 96 || count < 1) return 0;
+    if (n < 1 || n > kMaxOrbitals || count < 1) return 0;
     return sizeof(double) * (size_t)integrals_ws_stride(n) * (size_t)count;
 }
 
@@ -1099,7 +1103,7 @@ extern "C" int evc_integrals_oao_batch(int n, int count, const double *S, const 
                                        double *h1, double *h2, double *trafo, void *ws, size_t ws_bytes,
                                        void *stream) {
     EVC_REQUIRE(S && hcore && eri && h1 && h2 && ws, "evc_integrals_oao_batch: null pointer");
-    EVC_REQUIRE(n >= 1 && n <= 80, "evc_integrals_oao_batch: n=%d out of range 1..80", n);
+    EVC_REQUIRE(n >= 1 && n <= kMaxOrbitals, "evc_integrals_oao_batch: n=%d out of range 1..%d", n, kMaxOrbitals);
     EVC_REQUIRE(count >= 1 && count <= 65535, "evc_integrals_oao_batch: count=%d out of range", count);
     EVC_REQUIRE(aligned16(ws) && ws_bytes >= evc_integrals_oao_ws_bytes(n, count),
                 "evc_integrals_oao_batch: workspace misaligned or too small");
@@ -1119,6 +1123,8 @@ extern "C" int evc_integrals_oao_batch(int n, int count, const double *S, const 
     la.sh = n2;
     la.sws = sw;
     la.n = n;
+    la.scratch = B1;   // (the N^4 buffer is free until the rotation)
+    la.sscratch = sw;
     if ((rc = launch_loewdin(la, count, st))) return rc;
     if (use_pair_transform(n)) {
         PairTransformArgs pa;
@@ -1166,7 +1172,7 @@ static void fake_set(evc_trdm_set &t, int n) {
 }
 
 extern "C" size_t evc_grad_elec_ws_bytes(int n, int natm) {
-    if (n < 1 || n > 64) return 0;
+    if (n < 1 || n > kMaxOrbitals) return 0;
     evc_trdm_set t;
     fake_set(t, n);
     Ws w;
@@ -1176,7 +1182,7 @@ extern "C" size_t evc_grad_elec_ws_bytes(int n, int natm) {
 
 extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *trafo, const double *one_rdm,
                                  const double *two_rdm, double *grad, void *ws, size_t ws_bytes, void *stream) {
-    EVC_REQUIRE(n >= 1 && n <= 64, "evc_grad_elec_oao: n=%d out of range 1..64", n);
+    EVC_REQUIRE(n >= 1 && n <= kMaxOrbitals, "evc_grad_elec_oao: n=%d out of range 1..%d", n, kMaxOrbitals);
     if (check_geometry(g, true)) return -1;
     EVC_REQUIRE(one_rdm && two_rdm && grad && ws && aligned16(ws), "evc_grad_elec_oao: null/misaligned pointer");
     evc_trdm_set t;
@@ -1195,6 +1201,7 @@ extern "C" int evc_grad_elec_oao(int n, const evc_geometry *g, const double *tra
     la.s = w.s;
     la.h1 = w.h1;
     la.n = n;
+    la.scratch = w.B1;
     if ((rc = launch_loewdin(la, 1, st))) return rc;
     if (trafo) {
         // caller-supplied ao_mo_trafo (gradients_loewdin.py:271-272); its derivative is still the

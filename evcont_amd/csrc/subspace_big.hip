@@ -806,7 +806,11 @@ __global__ __launch_bounds__(kBT) void loewdin_big_kernel(LoewdinArgs a) {
     double *__restrict__ h1 = a.h1 ? a.h1 + g * a.sws : nullptr;
     const size_t Tp2 = (size_t)Tp * Tp;
     const size_t gsz = (size_t)m * Pj > Tp2 ? (size_t)m * Pj : Tp2;
-    double *G = sm, *A = G + gsz, *B = A + Tp2, *f = B + Tp2, *red = f + Tp;
+    // n <= 64: G, A, B in LDS; beyond: A and B in the caller's scratch (global memory, L2 resident)
+    const bool ext = n > 64;
+    double *G = sm;
+    double *A = ext ? a.scratch + g * a.sscratch : G + gsz, *B = A + Tp2;
+    double *f = ext ? G + gsz : B + Tp2, *red = f + Tp;
     const int tid = threadIdx.x;
     // numpy.linalg.eigh reads the lower triangle
     bool warm = false;
@@ -897,7 +901,11 @@ __global__ __launch_bounds__(kBT) void loewdin_big_kernel(LoewdinArgs a) {
 int launch_loewdin_big(const LoewdinArgs &a, int count, hipStream_t st) {
     const size_t n = a.n, m = (n + 1) & ~(size_t)1, Tp = (n + 15) & ~(size_t)15, Pj = (m + 31) & ~(size_t)31;
     const size_t gsz = m * Pj > Tp * Tp ? m * Pj : Tp * Tp;
-    const size_t lds = sizeof(double) * (gsz + 2 * Tp * Tp + Tp + 2 * kBW) + 64;
+    if (n > 64 && !a.scratch) {
+        set_error("loewdin: n=%d needs a scratch buffer", a.n);
+        return -1;
+    }
+    const size_t lds = sizeof(double) * (gsz + (n > 64 ? 0 : 2 * Tp * Tp) + Tp + 2 * kBW) + 64;
     static LdsAttr attr;
     if (int rc = allow_dynamic_lds(loewdin_big_kernel, attr, 160 * 1024, "loewdin_big")) return rc;
     hipLaunchKernelGGL(loewdin_big_kernel, dim3(count), dim3(kBT), lds, st, a);

@@ -1488,6 +1488,8 @@ __global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT,
     const int64_t per = (ksteps + nw - 1) / nw;
     const int64_t w = (int64_t)blockIdx.x * 4 + wave;
     const int64_t ks0 = w * per, ks1 = min(ksteps, ks0 + per);
+    // n > 64: the (n, n) result is produced in 64 x 64 quadrants, one per blockIdx.z
+    const int ioff = (int)(blockIdx.z >> 1) * 64, aoff = (int)(blockIdx.z & 1) * 64;
     d4 acc[NT][NT];
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
@@ -1500,9 +1502,8 @@ __global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT,
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int c = t * 16 + l15;
-            const bool ok = kok && c < n;
-            af[t] = ok ? GsT[k * n + c] : 0.0;
-            bf[t] = ok ? K3[k * n + c] : 0.0;
+            af[t] = (kok && ioff + c < n) ? GsT[k * n + ioff + c] : 0.0;
+            bf[t] = (kok && aoff + c < n) ? K3[k * n + aoff + c] : 0.0;
         }
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
@@ -1517,9 +1518,10 @@ __global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT,
             for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
     __syncthreads();
     double *dst = partial + (int64_t)blockIdx.x * n * n;
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int i = idx / n, a = idx % n;
-        dst[idx] = (red[0][i][a] + red[1][i][a]) + (red[2][i][a] + red[3][i][a]);
+    for (int idx = threadIdx.x; idx < NT * 16 * NT * 16; idx += 256) {
+        const int il = idx / (NT * 16), al = idx % (NT * 16);
+        const int i = ioff + il, a = aoff + al;
+        if (i < n && a < n) dst[(int64_t)i * n + a] = (red[0][il][al] + red[1][il][al]) + (red[2][il][al] + red[3][il][al]);
     }
 }
 
@@ -1542,13 +1544,16 @@ __global__ __launch_bounds__(256) void y2_sb_kernel(const double *__restrict__ S
     const int64_t w = (int64_t)blockIdx.x * 4 + wave;
     const int64_t ks0 = w * per, ks1 = min(ksteps, ks0 + per);
     const bool even = (ktot & 1) == 0;  // rows of SB start 16-byte aligned
+    // n > 64: the (n, n) result is produced in 64 x 64 quadrants, one per blockIdx.z
+    const int ioff = (int)(blockIdx.z >> 1) * 64, aoff = (int)(blockIdx.z & 1) * 64;
     const double *__restrict__ arow[NT];
-    bool cok[NT];
+    bool cok[NT], bok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int c = t * 16 + l15;
-        cok[t] = c < n;
-        arow[t] = SB + (int64_t)(cok[t] ? c : 0) * ktot;
+        cok[t] = ioff + c < n;
+        bok[t] = aoff + c < n;
+        arow[t] = SB + (int64_t)(cok[t] ? ioff + c : 0) * ktot;
     }
     d4 acc[NT][NT];
 #pragma unroll
@@ -1566,9 +1571,9 @@ __global__ __launch_bounds__(256) void y2_sb_kernel(const double *__restrict__ S
                 af[t] = (cok[t] && k0ok) ? *reinterpret_cast<const double2 *>(arow[t] + k) : make_double2(0.0, 0.0);
             else
                 af[t] = make_double2((cok[t] && k0ok) ? arow[t][k] : 0.0, (cok[t] && k1ok) ? arow[t][k + 1] : 0.0);
-            const int c = t * 16 + l15;
-            b0[t] = (cok[t] && k0ok) ? K3[k * n + c] : 0.0;
-            b1[t] = (cok[t] && k1ok) ? K3[(k + 1) * n + c] : 0.0;
+            const int c = aoff + t * 16 + l15;
+            b0[t] = (bok[t] && k0ok) ? K3[k * n + c] : 0.0;
+            b1[t] = (bok[t] && k1ok) ? K3[(k + 1) * n + c] : 0.0;
         }
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
@@ -1587,9 +1592,10 @@ __global__ __launch_bounds__(256) void y2_sb_kernel(const double *__restrict__ S
             for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
     __syncthreads();
     double *dst = partial + (int64_t)blockIdx.x * n * n;
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int i = idx / n, a = idx % n;
-        dst[idx] = (red[0][i][a] + red[1][i][a]) + (red[2][i][a] + red[3][i][a]);
+    for (int idx = threadIdx.x; idx < NT * 16 * NT * 16; idx += 256) {
+        const int il = idx / (NT * 16), al = idx % (NT * 16);
+        const int i = ioff + il, a = aoff + al;
+        if (i < n && a < n) dst[(int64_t)i * n + a] = (red[0][il][al] + red[1][il][al]) + (red[2][il][al] + red[3][il][al]);
     }
 }
 
@@ -1959,13 +1965,14 @@ int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t
 int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
     const int64_t ktot = (int64_t)n * n * n;
     const int nt = (n + 15) / 16;
-    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count);
+    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count, nt > 4 ? 4u : 1u);   // n > 64: four 64 x 64 quadrants
     switch (nt) {
         case 1: hipLaunchKernelGGL(y2_sb_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
         case 2: hipLaunchKernelGGL(y2_sb_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
         case 3: hipLaunchKernelGGL(y2_sb_kernel<3>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
-        case 4: hipLaunchKernelGGL(y2_sb_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
-        default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
+        case 4: case 5: case 6: case 7: case 8:
+            hipLaunchKernelGGL(y2_sb_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
+        default: set_error("y2: n=%d not supported by the gradient path (1..128)", n); return -1;
     }
     EVC_LAUNCH_CHECK("y2_sb");
     return 0;
@@ -1974,13 +1981,14 @@ int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int
 int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
     const int64_t ktot = (int64_t)n * n * n;
     const int nt = (n + 15) / 16;
-    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count);
+    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count, nt > 4 ? 4u : 1u);   // n > 64: four 64 x 64 quadrants
     switch (nt) {
         case 1: hipLaunchKernelGGL(y2_kernel<1>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
         case 2: hipLaunchKernelGGL(y2_kernel<2>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
         case 3: hipLaunchKernelGGL(y2_kernel<3>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
-        case 4: hipLaunchKernelGGL(y2_kernel<4>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
-        default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
+        case 4: case 5: case 6: case 7: case 8:
+            hipLaunchKernelGGL(y2_kernel<4>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
+        default: set_error("y2: n=%d not supported by the gradient path (1..128)", n); return -1;
     }
     EVC_LAUNCH_CHECK("y2");
     return 0;

@@ -110,7 +110,8 @@ int evc_four_index_transform(const double *in, const double *C, int c_transposed
  * K1/K2  Loewdin orthogonalisation on one workgroup (parallel cyclic Jacobi in LDS)
  *   S = U diag(s) U^T ; X = U diag(s>1e-15 ? s^-1/2 : 0) U^T ; h1 = X^T hcore X
  *   replaces get_loewdin_trafo (electron_integral_utils.py:6-18) and the h1 rotation
- *   (:135, ab_initio_gradients_loewdin.py:338).  hcore/h1 may be NULL.  n <= 80.
+ *   (:135, ab_initio_gradients_loewdin.py:338).  hcore/h1 may be NULL.  n <= 80 (96 inside the fused pipeline, which lends
+ *   the kernel scratch from its workspace).
  * --------------------------------------------------------------------------------- */
 int evc_loewdin(const double *S, const double *hcore, int n, double *X, double *U, double *s,
                 double *h1, void *stream);
@@ -148,7 +149,7 @@ int evc_subspace_solve_batch(const double *H, const double *S, int64_t s_stride,
 /* OAO integrals of `count` geometries (get_basis + get_integrals, electron_integral_utils.py:91-138):
  * X = S^-1/2, h1 = X^T hcore X (count,N,N), h2 = four-index rotation of eri (count,N,N,N,N); `trafo`
  * (count,N,N) receives X if non-NULL.  Inputs stacked along the leading axis.  Used by the
- * "farthest_point_ham" selection metric (MD_utils.py:363-405).  n <= 80. */
+ * "farthest_point_ham" selection metric (MD_utils.py:363-405).  n <= 96. */
 size_t evc_integrals_oao_ws_bytes(int n, int count);
 int evc_integrals_oao_batch(int n, int count, const double *S, const double *hcore, const double *eri,
                             double *h1, double *h2, double *trafo, void *ws, size_t ws_bytes,
@@ -159,7 +160,7 @@ int evc_integrals_oao_batch(int n, int count, const double *S, const double *hco
  * ab_initio_eigenvector_continuation.py:178-250 *_OAO)
  * --------------------------------------------------------------------------------- */
 typedef struct evc_trdm_set {
-    int32_t n;           /* orbitals N */
+    int32_t n;           /* orbitals N (<= 96; the reference's largest orbital space is 58) */
     int32_t ntrain;      /* training states T (<= 512) */
     int32_t layout;      /* EVC_LAYOUT_* */
     int32_t reserved;

@@ -211,3 +211,47 @@ def test_leave_one_out_energies_T40():
             ix = np.ix_(ids, ids)
             want = sla.eigh(H[b][ix], S[ix], eigvals_only=True)[0] + enuc[b]
             assert abs(got[b, k] - want) < 1e-10, (b, k, got[b, k], want)
+
+
+@pytest.mark.parametrize("n,sizes,T", [(70, (40, 30), 3), (96, (50, 46), 2)])
+def test_more_than_64_orbitals_against_oracle(n, sizes, T):
+    """Orbital spaces beyond 64 (the reference has no bound; its largest is cc-pVTZ water, N = 58): Loewdin on the
+    1024-thread Jacobi with two work matrices in the workspace, quarter transforms up to 96 padded columns, Y2 in 64 x 64
+    quadrants, gradient tail with its operands read through the caches.  pack2, sym8 and the unpacked full6 layout against
+    the oracle."""
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, BatchedEvaluator
+    from evcont_amd.synthetic import make_device_ao, make_device_trdm_rows
+    A, G = len(sizes), (2 if n <= 70 else 1)
+    dev = torch.device(DEV)
+    S, one, rows = make_device_trdm_rows(n, T, 2, 4700 + n, dev)
+    aos = [make_device_ao(n, A, 4700000 + 10 * n + k, dev, sizes, ip1_rs_symmetric=True) for k in range(G)]
+    one_h, two_h, S_h = one.cpu().numpy(), rows.cpu().numpy(), S.cpu().numpy()
+    want = [orc.energy_with_grad(_bundle_from_device(a), one_h, two_h, S_h) for a in aos]
+    trd = DeviceTRDMs.from_device_rows(one, rows, S, 2)
+    got = {"pack2": BatchedEvaluator(trd, A, G).energies_with_grads(DeviceAOBatch.stack(aos))}
+    if n <= 70:   # the (T,T,N^4) layout: through the unpacked path (sym_oao_t, y2_kernel)
+        nn = n * n
+        r, c = np.tril_indices(nn)
+        full = np.zeros((T, T, nn, nn))
+        a_, b_ = np.tril_indices(T)
+        for p_, (ia, ib) in enumerate(zip(a_, b_)):
+            m = np.zeros((nn, nn))
+            m[r, c] = two_h[p_]
+            m = m + m.T - np.diag(np.diag(m))
+            full[ia, ib] = m
+            full[ib, ia] = m.reshape(n, n, n, n).transpose(1, 0, 3, 2).reshape(nn, nn)
+        # (bra <-> ket exchange of a pair goes with p <-> q, r <-> s; the oracle on THIS array is the reference here)
+        full = full.reshape(T, T, n, n, n, n)
+        want6 = [orc.energy_with_grad(_bundle_from_device(a), one_h, full, S_h) for a in aos]
+        E6, g6 = BatchedEvaluator(DeviceTRDMs(one_h, full, S_h, dev), A, G).energies_with_grads(DeviceAOBatch.stack(aos))
+        for k in range(G):
+            assert abs(E6[k] - want6[k][0]) < 1e-9 and np.abs(g6[k] - want6[k][1]).max() < 1e-8, ("full6", k)
+        del full
+    del two_h
+    trd.compress_sym8_()
+    del rows
+    got["sym8"] = BatchedEvaluator(trd, A, G).energies_with_grads(DeviceAOBatch.stack(aos))
+    for leg, (E, grad) in got.items():
+        de = max(abs(E[k] - want[k][0]) for k in range(G))
+        dg = max(float(np.abs(grad[k] - want[k][1]).max()) for k in range(G))
+        assert de < 1e-9 and dg < 1e-8, (leg, de, dg)
