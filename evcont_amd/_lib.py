@@ -132,6 +132,12 @@ def load(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    try:
+        # PyTorch-ROCm ships its own HIP runtime: load it FIRST so that this library binds to the same runtime instance
+        # (a second, separately initialised libamdhip64 does not see the device torch is driving)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     p = path or os.environ.get("EVCONT_HIP_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise EvcontHipError(
