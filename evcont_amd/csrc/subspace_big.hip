@@ -11,13 +11,17 @@
 //   (b) H assembled from the span partials in LDS, symmetrised from its lower triangle;
 //   (c) W = B Hs and C = W B^T as "row . row" products on the FP64 matrix cores (16 x 16 tiles dealt to the 16 waves,
 //       operands read with 16-byte loads from L2-resident global scratch / LDS);
-//   (d) eigen-decomposition of C + sigma I (sigma: Gershgorin bound, makes it positive definite) by one-sided
-//       (Hestenes) Jacobi on its columns in LDS: 16 lanes per column pair, 16-byte conflict-free LDS rows, the three dot
-//       products reduced over a DPP row, one barrier per round-robin step; at convergence column j is
-//       (lambda_j + sigma) v_j, so no eigenvector matrix is carried through the rotations;
+//   (d) nroots <= 4 (the energy + force path asks for ONE root): Householder tridiagonalisation in LDS, Sturm multisection,
+//       twisted factorisation, back-transformation through the reflectors, and a residual / orthogonality check in the
+//       original matrix (big_few_roots); otherwise, or when that check fails: eigen-decomposition of C + sigma I (sigma:
+//       Gershgorin bound, makes it positive definite) by one-sided (Hestenes) Jacobi on its columns in LDS: 16 lanes per
+//       column pair, 16-byte conflict-free LDS rows, the three dot products reduced over a DPP row, one barrier per
+//       round-robin step; at convergence column j is (lambda_j + sigma) v_j, so no eigenvector matrix is carried through
+//       the rotations;
 //   (e) ascending order, back-transformation c = B^T y, weights.
-// With EVC_FLAG_WARM_START the sweeps start from G0 = (C + sigma I) V_prev (V_prev checked for orthonormality).
-// The same code runs with the matrix in global memory (template parameter) for T beyond what LDS holds.
+// With EVC_FLAG_WARM_START the Jacobi sweeps start from G0 = (C + sigma I) V_prev (V_prev checked for orthonormality).
+// The same code runs with the matrix in global memory (template parameter) for T beyond what LDS holds (Jacobi route).
+// Also here: the Loewdin orthogonalisation for 32 < n <= 96 on the same Jacobi (loewdin_big_kernel).
 #include <stdlib.h>
 
 #include "common.hpp"
