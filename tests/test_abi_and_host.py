@@ -209,3 +209,54 @@ def test_sym8_column_images_reproduce_the_symmetrised_tensor(n):
     packed_row = pack_rows(two, True, True)[1]      # pairs in np.tril_indices order: (0,0), (1,0), (1,1)
     got2 = sum(packed_row[ix] for ix in sym8_column_images(2, n)) / 8.0
     np.testing.assert_allclose(got2, want, rtol=0, atol=1e-15)
+
+
+def test_size_limits_of_round3(lib):
+    """Training sets up to 512 states and orbital spaces up to 96 are accepted (the reference bounds neither; its
+    scripts go to T = 100 and N = 58); the large-T subspace kernel sizes its own workspace."""
+    from evcont_amd._lib import TrdmSet
+
+    def ws(n, T):
+        P, n2 = T * (T + 1) // 2, n * n
+        M = n2 * (n2 + 1) // 2
+        t = TrdmSet(n=n, ntrain=T, layout=2, rows2=P, row_offset=0, rows2_total=P, cols2=M, ld2=(M + 15) // 16 * 16,
+                    ld1=n2 + (n2 & 1), two_rdm=256, one_rdm=256, s_train=256)
+        return lib.evc_workspace_bytes(C.byref(t), 3)
+
+    assert ws(8, 100) > 0 and ws(8, 512) > 0
+    assert ws(8, 513) == 0 and b"ntrain" in lib.evc_last_error()
+    assert ws(96, 2) > 4 * 96 ** 4 * 8
+    assert ws(97, 2) == 0 and b"n=97" in lib.evc_last_error()
+    assert lib.evc_subspace_solve_ws_bytes(32, 1) == 0          # register / LDS kernel: no workspace
+    tp = lambda T: (T + 15) // 16 * 16
+    assert lib.evc_subspace_solve_ws_bytes(100, 1) == 3 * tp(100) ** 2 * 8
+    assert lib.evc_subspace_solve_ws_bytes(100, 7) == 7 * 3 * tp(100) ** 2 * 8
+    assert lib.evc_subspace_solve_ws_bytes(200, 1) > 3 * tp(200) ** 2 * 8    # + the matrix itself (does not fit LDS)
+    assert lib.evc_subspace_solve_ws_bytes(513, 1) == 0
+    # T > 32 without a workspace is an argument error, not a launch
+    assert lib.evc_subspace_solve(16, 16, 16, 40, 2, 1, 0.0, 16, 16, None, None, None, None, 0, None) < 0
+    assert b"workspace" in lib.evc_last_error()
+
+
+def test_integral_symmetry_check_on_host():
+    """evaluator.check_integral_symmetry (the guard of the compressed layout / packed inputs) on numpy arrays."""
+    from evcont_amd.evaluator import check_integral_symmetry
+    from evcont_amd._lib import EvcontHipError
+    from evcont_amd.synthetic import make_ao_arrays
+    n = 5
+    good = make_ao_arrays(n, 2, 1, ip1_rs_symmetric=True)
+    check_integral_symmetry(good.eri, good.eri_ip1, n)
+    iu, ju = np.tril_indices(n)
+    check_integral_symmetry(good.eri[iu, ju][:, iu, ju], good.eri_ip1[:, :, :, iu, ju], n)     # packed s4 / s2kl
+    check_integral_symmetry(np.stack([good.eri, good.eri]), np.stack([good.eri_ip1] * 2), n)  # batch axis
+    bad = make_ao_arrays(n, 2, 2)                                                              # general eri_ip1
+    with pytest.raises(EvcontHipError, match="eri_ip1"):
+        check_integral_symmetry(bad.eri, bad.eri_ip1, n)
+    e = good.eri.copy()
+    e[0, 1, 2, 3] += 1e-4
+    with pytest.raises(EvcontHipError, match="eri"):
+        check_integral_symmetry(e, None, n)
+    m = good.eri[iu, ju][:, iu, ju].copy()
+    m[0, 3] += 1e-4
+    with pytest.raises(EvcontHipError, match="packed s4"):
+        check_integral_symmetry(m, None, n)
