@@ -474,7 +474,88 @@ static void cols_launch(const GemvColsLaunch &Lin, int total, int g0, hipStream_
     hipLaunchKernelGGL((gemv_cols_kernel<G>), dim3(total), dim3(256), 0, st, L, g0);
 }
 
+// Row-slab form for a NARROW matrix with MANY rows -- the one-body t-RDM of a large training set, (T^2, N^2): 10 000 x 784
+// at the Zundel shape with 100 training states.  The column-tiled kernels above give such a matrix two to seven
+// workgroups that walk all its rows (0.3 ms at 0.2 TB/s, the tail of the whole K8 launch); here a workgroup takes a slab
+// of rows x 512 columns (whole rows: 4-6 KB contiguous per row), eight geometries at a time, and leaves a partial row;
+// a second, tiny launch adds the slabs in fixed order.
+__global__ __launch_bounds__(256) void gemv_cols_slab_kernel(ColProblem P, int count, int nslab) {
+    const int slab = blockIdx.x;
+    const int64_t c = (int64_t)blockIdx.y * kChunk + threadIdx.x * 2;
+    const bool active = c < P.cols, two = c + 1 < P.cols;
+    const int64_t rps = (P.rows + nslab - 1) / nslab, r0 = (int64_t)slab * rps, r1 = min(P.rows, r0 + rps);
+    const double *__restrict__ A = P.A + (active ? c : 0);
+    for (int gb = 0; gb < count; gb += 8) {
+        const int ng = min(8, count - gb);
+        double2 acc[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc[g] = make_double2(0.0, 0.0);
+        if (active) {
+            int64_t r = r0;
+            for (; r + 8 <= r1; r += 8) {   // eight independent row loads in flight
+                double2 a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = two ? ld_stream(A + (r + u) * P.ld) : make_double2(A[(r + u) * P.ld], 0.0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    if (g < ng) {
+                        const double *wp = P.w + (int64_t)(gb + g) * P.wstride + r;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            acc[g].x = fma(wp[u], a[u].x, acc[g].x);
+                            acc[g].y = fma(wp[u], a[u].y, acc[g].y);
+                        }
+                    }
+            }
+            for (; r < r1; ++r) {
+                const double2 a = two ? ld_stream(A + r * P.ld) : make_double2(A[r * P.ld], 0.0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    if (g < ng) {
+                        const double wr = P.w[(int64_t)(gb + g) * P.wstride + r];
+                        acc[g].x = fma(wr, a.x, acc[g].x);
+                        acc[g].y = fma(wr, a.y, acc[g].y);
+                    }
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (g < ng) {
+                    double *o = P.part + (int64_t)(gb + g) * P.pstride + (int64_t)slab * P.ld + c;
+                    if (two) *reinterpret_cast<double2 *>(o) = acc[g];
+                    else *o = acc[g].x;
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemv_cols_slab_reduce_kernel(ColProblem P, int nslab) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= P.cols) return;
+    const double *p = P.part + (int64_t)blockIdx.y * P.pstride + c;
+    double s0 = 0.0, s1 = 0.0;
+    int k = 0;
+    for (; k + 2 <= nslab; k += 2) {
+        s0 += p[(int64_t)k * P.ld];
+        s1 += p[(int64_t)(k + 1) * P.ld];
+    }
+    if (k < nslab) s0 += p[(int64_t)k * P.ld];
+    P.out[(int64_t)blockIdx.y * P.ostride + c] = s0 + s1;
+}
+
 int launch_gemv_cols(ColProblem p0, ColProblem p1, int count, hipStream_t st) {
+    static const int mfma_min_g = env_int("EVC_MFMA_MIN_G", 12);
+    if (p1.part && p1.cols > 0 && p1.rows >= 1024 && p1.cols <= 16384 && count > 0 && count < mfma_min_g) {
+        // (groups of >= 12 geometries go through the matrix-core kernel, whose four waves split the rows of a tile)
+        // the narrow second problem in row slabs (its own two launches), the wide one alone below
+        const int nslab = (int)(p1.rows / 64 < kColSlabs ? p1.rows / 64 : kColSlabs);
+        hipLaunchKernelGGL(gemv_cols_slab_kernel, dim3((unsigned)nslab, (unsigned)ceil_div(p1.cols, kChunk)), dim3(256), 0,
+                           st, p1, count, nslab);
+        EVC_LAUNCH_CHECK("gemv_cols_slab");
+        hipLaunchKernelGGL(gemv_cols_slab_reduce_kernel, dim3((unsigned)ceil_div(p1.cols, 256), (unsigned)count),
+                           dim3(256), 0, st, p1, nslab);
+        EVC_LAUNCH_CHECK("gemv_cols_slab_reduce");
+        p1.cols = 0;
+    }
     GemvColsLaunch L;
     L.p[0] = p0;
     L.p[1] = p1;

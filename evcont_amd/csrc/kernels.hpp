@@ -36,7 +36,10 @@ struct ColProblem {
                       // transposed (geometry g in column g % kMaxBatchG), or NULL
     double *out;      // (cols)             + g*ostride
     int64_t rows, cols, ld, wstride, ostride;
+    double *part;     // (kColSlabs, ld) + g*pstride or NULL: scratch for the row-slab form of a NARROW problem with many
+    int64_t pstride;  // rows (the one-body t-RDM of a large training set: T^2 rows of N^2 columns)
 };
+constexpr int kColSlabs = 64;   // row slabs of that form
 struct GemvColsLaunch {
     ColProblem p[2];
     int nblk0;

@@ -78,6 +78,7 @@ struct Ws {
     double *vec2;  // ld2-long vector: packed h2 (phase A) / packed predicted 2-RDM (phase C)
     // t-RDM contraction
     double *h2part, *h1part, *h2rows, *w2, *w1, *w2t;
+    double *d1part;   // row-slab partials of the predicted 1-RDM (large training sets: gemv_cols_slab_kernel)
     // gradient partials
     double *y2part, *y2, *t2part, *term3;
     // scratch outputs when the caller passes NULL
@@ -183,6 +184,7 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.w2 = take((size_t)t->rows2 + 1);
     w.w2t = take((size_t)t->rows2 * kMaxBatchG + 1);
     w.w1 = take(T * T);
+    w.d1part = take(T * T >= 1024 ? (size_t)kColSlabs * t->ld1 : 0);
     w.y2part = take((size_t)y2_slab_capacity((int)n) * n2);
     w.y2 = take(n2);
     w.t2part = take((size_t)n * 3 * ip1_chunks((int)n));
@@ -654,6 +656,8 @@ static int phase_gradient(const evc_trdm_set *t, const Geo &g_in, const Out &out
     c1.ld = t->ld1;
     c1.out = D;
     c1.ostride = sD;
+    c1.part = (int64_t)t->ntrain * t->ntrain >= 1024 ? w.d1part : nullptr;
+    c1.pstride = sw;
     const int pr = prof_start(EVC_PROF_COLS, st);
     if ((rc = launch_gemv_cols(c2, c1, cnt, st))) return rc;
     prof_stop(pr, st);
