@@ -98,3 +98,52 @@ class PairShardedContinuation:
         if self.count is None:
             return float(self.ev.energy[0].item()), self.ev.grad.cpu().numpy().copy()
         return self.ev.energy[:, 0].cpu().numpy().copy(), self.ev.grad.cpu().numpy().copy()
+
+
+class PipelinedPairSharded:
+    """Pair-sharded batches submitted one after another by a caller that uses ONE stream, ``depth`` of them in flight
+    (the counterpart of ``evaluator.PipelinedBatchedEvaluator``): every batch runs its three phases and two collectives
+    on one of ``depth`` internal streams, forked from the caller's stream at submission and joined when its results are
+    asked for, so the latency-bound single-workgroup kernels of one batch (Loewdin, subspace solve, gradient tail) and
+    the two small collectives overlap the chip-filling kernels of its neighbours.  The collectives of all batches are
+    issued in program order on every rank (one communicator, different streams).
+
+        pp = PipelinedPairSharded(trdms_slice, natm, G, rows_total)
+        tickets = [pp.enqueue(aob) for aob in batches[:3]]
+        ev = pp.results(tickets[0])          # caller's stream waits for THAT batch; ev.energy (G,T), ev.grad (G,A,3)
+    """
+
+    def __init__(self, trdms, natm: int, count: int, rows_total: int, depth: int = 3,
+                 group: Optional[dist.ProcessGroup] = None, **kw):
+        from .evaluator import BatchedEvaluator
+        dev = trdms.device
+        self.device, self.depth = dev, max(1, int(depth))
+        self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)]
+        self.runners = [PairShardedContinuation(BatchedEvaluator(trdms, natm, count, stream=st, **kw), rows_total, group)
+                        for st in self.streams]
+        self._submitted = [torch.cuda.Event() for _ in range(self.depth)]
+        self._done = [torch.cuda.Event() for _ in range(self.depth)]
+        self._busy = [False] * self.depth
+        self._k = 0
+
+    def enqueue(self, aob, nroots: int = 1, energy_only: bool = False) -> int:
+        slot = self._k % self.depth
+        self._k += 1
+        st = self.streams[slot]
+        self._submitted[slot].record(torch.cuda.current_stream(self.device))
+        st.wait_event(self._submitted[slot])
+        self.runners[slot].enqueue(aob, nroots, energy_only)
+        self._done[slot].record(st)
+        self._busy[slot] = True
+        return slot
+
+    def results(self, slot: int):
+        if self._busy[slot]:
+            torch.cuda.current_stream(self.device).wait_event(self._done[slot])
+            self._busy[slot] = False
+        return self.runners[slot].ev
+
+    def synchronize(self) -> None:
+        for st in self.streams:
+            st.synchronize()
+        torch.cuda.current_stream(self.device).synchronize()

@@ -17,7 +17,7 @@ import torch.distributed as dist
 def main():
     from evcont_amd.synthetic import make_ao_arrays, make_trdms, pack_rows
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, DeviceAOBatch, BatchedEvaluator, ContinuationEvaluator
-    from evcont_amd.distributed import PairShardedContinuation
+    from evcont_amd.distributed import PairShardedContinuation, PipelinedPairSharded
     from oracle import evcont_oracle as orc
 
     dev = torch.device("cuda", 0)
@@ -60,6 +60,18 @@ def main():
             gk = r.ev.grad.cpu().numpy()
             worst_e = max(worst_e, max(abs(Ek[k] - want[k][0]) for k in range(G)))
             worst_g = max(worst_g, max(float(np.abs(gk[k] - want[k][1]).max()) for k in range(G)))
+        # the same through the library's own pipeline: one caller stream, three batches in flight
+        pp = PipelinedPairSharded(trd, A, G, rows)
+        tickets = [pp.enqueue(aob) for _ in range(3)]
+        for k in range(4):
+            ev = pp.results(tickets[k])
+            Ek, gk = ev.energy[:, 0].clone(), ev.grad.clone()
+            tickets.append(pp.enqueue(aob))
+            torch.cuda.current_stream(dev).synchronize()
+            Ek, gk = Ek.cpu().numpy(), gk.cpu().numpy()
+            worst_e = max(worst_e, max(abs(Ek[j] - want[j][0]) for j in range(G)))
+            worst_g = max(worst_g, max(float(np.abs(gk[j] - want[j][1]).max()) for j in range(G)))
+        pp.synchronize()
     out.update(worst_dE=worst_e, worst_dgrad=worst_g)
     dist.barrier()
     dist.destroy_process_group()
