@@ -255,3 +255,31 @@ def test_more_than_64_orbitals_against_oracle(n, sizes, T):
         de = max(abs(E[k] - want[k][0]) for k in range(G))
         dg = max(float(np.abs(grad[k] - want[k][1]).max()) for k in range(G))
         assert de < 1e-9 and dg < 1e-8, (leg, de, dg)
+
+
+def test_reference_golden_T40():
+    """T = 40 against vectors the REFERENCE itself produced (tests/golden/make_golden_large_T.py): energies, forces,
+    predicted RDMs on the pack2 layout; energies and forces on the compressed one; the six lowest roots."""
+    import os
+    from conftest import GOLDEN_DIR
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
+    from evcont_amd.synthetic import AOArrays
+    with np.load(os.path.join(GOLDEN_DIR, "largeT_n3t40a2.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    ao = AOArrays(S=g["S"], hcore=g["hcore"], eri=g["eri"], ipovlp=g["ipovlp"], dhcore=g["dhcore"], eri_ip1=g["eri_ip1"],
+                  aoslices=g["aoslices"], enuc=float(g["enuc"]), gnuc=g["gnuc"])
+    A = int(g["aoslices"].shape[0])
+    ev = ContinuationEvaluator(DeviceTRDMs(g["one_RDM"], g["two_RDM_pack2"], g["S_train"], DEV), A)
+    E, grad, D, G = ev.energy_with_grad(DeviceAO.from_arrays(ao, DEV), True)
+    assert abs(E - float(g["ewg_E_pack2"])) < 1e-10
+    np.testing.assert_allclose(grad, g["ewg_grad_pack2"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(D, g["ewg_D_pack2"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(G, g["ewg_G_pack2"].reshape(G.shape), rtol=0, atol=1e-10)
+    e6, _ = ev.energies(DeviceAO.from_arrays(ao, DEV, energy_only=True), nroots=6)       # > 4 roots: the Jacobi route
+    np.testing.assert_allclose(e6, g["ms_E_pack2"] + float(g["enuc"]), rtol=0, atol=1e-10)
+    e3, _ = ev.energies(DeviceAO.from_arrays(ao, DEV, energy_only=True), nroots=3)       # few-roots route
+    np.testing.assert_allclose(e3, g["ms_E_pack2"][:3] + float(g["enuc"]), rtol=0, atol=1e-10)
+    ev8 = ContinuationEvaluator(DeviceTRDMs(g["one_RDM"], g["two_RDM_pack2"], g["S_train"], DEV, compress="sym8"), A)
+    E8, g8 = ev8.energy_with_grad(DeviceAO.from_arrays(ao, DEV, pack_ip1=True, pack_eri=True))
+    assert abs(E8 - float(g["ewg_E_pack2"])) < 1e-10
+    np.testing.assert_allclose(g8, g["ewg_grad_pack2"], rtol=0, atol=1e-9)

@@ -139,3 +139,23 @@ def test_grow_and_prune():
         assert np.array_equal(d[-1, 0], d[0, -1])      # untransposed copy, as in the reference
     o2, d2, t2 = orc.prune_trdms(o, d, t, [0, 2])
     assert o2.shape == (2, 2) and np.array_equal(t2[1, 0], t[2, 0])
+
+
+def test_oracle_against_reference_large_training_set():
+    """T = 40 (the regime of the large-T subspace kernel): the oracle against vectors the REFERENCE produced
+    (tests/golden/make_golden_large_T.py: get_energy_with_grad and approximate_multistate on the pack2 layout)."""
+    import os
+    from conftest import GOLDEN_DIR
+    with np.load(os.path.join(GOLDEN_DIR, "largeT_n3t40a2.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    b = orc.AOBundle(S=g["S"], hcore=g["hcore"], eri=g["eri"], ipovlp=g["ipovlp"], dhcore=g["dhcore"],
+                     eri_ip1=g["eri_ip1"], aoslices=g["aoslices"], enuc=float(g["enuc"]), gnuc=g["gnuc"])
+    E, grad, D, G = orc.energy_with_grad(b, g["one_RDM"], g["two_RDM_pack2"], g["S_train"], True, True)
+    assert abs(E - float(g["ewg_E_pack2"])) < 1e-11
+    np.testing.assert_allclose(grad, g["ewg_grad_pack2"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(D, g["ewg_D_pack2"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(np.asarray(G).reshape(g["ewg_G_pack2"].shape), g["ewg_G_pack2"], rtol=0, atol=1e-11)
+    X = orc.loewdin_trafo(b.S)
+    h1, h2 = orc.integrals_oao(b, X)
+    em, cm = orc.approximate_multistate(h1, h2, g["one_RDM"], g["two_RDM_pack2"], g["S_train"], nroots=6)
+    np.testing.assert_allclose(em, g["ms_E_pack2"], rtol=0, atol=1e-11)
