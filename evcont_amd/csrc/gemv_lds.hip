@@ -1,0 +1,429 @@
+// K5 for 17..32 geometries per pass, the t-RDM streamed through LDS by LDS-DMA (global_load_lds_dwordx4):
+//   Y[row][g] = sum_c A[row][c] v[g][c]      (reference: ab_initio_eigenvector_continuation.py:57-64, the
+//   np.einsum / np.sum contractions of the stored transition RDMs with the rotated integrals)
+//
+// Why a second rows kernel (round 3, tools/micro/rows_pattern.hip with the caches flushed by a READ of 2 GB before
+// every launch): the fragment-shaped loads of gemv_rows_mfma_pipe_kernel (a load instruction = 16 rows x 64 bytes)
+// read the 210 x 108 345 matrix COLD at 4.0 TB/s, whole-line pieces at 5.0 TB/s -- the earlier comparison (5.5 against
+// 5.9 TB/s) had the 182 MB matrix sitting in the 256 MB memory-side cache between the repeats, which the kernel in
+// situ never sees (a batch moves 1.4 GB between two passes over the matrix).  Here every load instruction moves
+// 8 rows x 128 bytes (whole cache lines) straight into LDS, no VGPRs in between, so one wave per SIMD keeps a whole
+// chunk image (32 instructions = 32 KB) in flight, and the MFMA fragments come out of LDS with ds_read_b128.
+//
+// Decomposition: block = (column span, row group of <= NT 16-row tiles); H30 / T = 20: ONE row group of 14 tiles, so
+// the geometry vectors are read once per span (the pipe kernel reads them once per row group).  The four waves
+// interleave the 16-column chunks of the span (128 bytes per row: one cache line) and are completely independent
+// until the epilogue: no barrier in the stream.  A wave's LDS image holds one chunk: GS tiles of geometry vectors
+// (16 geometries x 16 columns) followed by NT tiles of matrix rows, 2 KB each.  Slot p of the image is refilled for
+// the NEXT chunk one position after it was read, so the image is a sliding window over two chunks and
+// (NS - 1) tiles = 2 (NS - 1) instructions are in flight all the time; LDS-DMA completes in order, so the wait in
+// front of the reads of slot p is the constant vmcnt(2 (NS - 2)).
+//
+// LDS image of a tile (rule "linear destination, swizzled SOURCE, same swizzle on the read"): instruction j of a
+// tile writes 1 KB = rows 8j..8j+7 x 128 bytes, lane i -> row 8j + (i >> 3), 16-byte position i & 7; the position
+// holds piece q = pos ^ ((row >> 1) & 7) of the row.  A fragment read (ds_read_b128: lane (l15, l4) takes piece
+// 4u + l4 of row l15) is then conflict free in every 16-lane group of the instruction.
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace evc {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kLW = 16;           // columns per wave chunk
+constexpr int kTileBytes = 2048;  // 16 rows x 16 columns
+
+__device__ __forceinline__ d4 mfma64(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// LDS-DMA, 16 bytes per lane: LDS address = M0 + 16 * lane.  The compiler neither counts these loads nor knows that
+// they write LDS: every wait below is explicit, and the "memory" clobbers keep its own LDS reads on their side.
+__device__ __forceinline__ void glds_s(unsigned voff, const void *sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ void glds_v(const void *vaddr, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(vaddr), "s"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+// (n is a constant after unrolling: the switch folds to one instruction)
+__device__ __forceinline__ void wait_vm_n(int n) {
+#define EVC_VM_CASE(k) case k: wait_vm<k>(); break;
+    switch (n) {
+        EVC_VM_CASE(0) EVC_VM_CASE(2) EVC_VM_CASE(4) EVC_VM_CASE(6) EVC_VM_CASE(8) EVC_VM_CASE(10) EVC_VM_CASE(12)
+        EVC_VM_CASE(14) EVC_VM_CASE(16) EVC_VM_CASE(18) EVC_VM_CASE(20) EVC_VM_CASE(22) EVC_VM_CASE(24)
+        EVC_VM_CASE(26) EVC_VM_CASE(28) EVC_VM_CASE(30) EVC_VM_CASE(32) EVC_VM_CASE(34) EVC_VM_CASE(36)
+        EVC_VM_CASE(38) EVC_VM_CASE(40) EVC_VM_CASE(42) EVC_VM_CASE(44) EVC_VM_CASE(46) EVC_VM_CASE(48)
+        EVC_VM_CASE(50) EVC_VM_CASE(52) EVC_VM_CASE(54) EVC_VM_CASE(56) EVC_VM_CASE(58) EVC_VM_CASE(60)
+        default: wait_vm<0>(); break;
+    }
+#undef EVC_VM_CASE
+}
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
+
+__device__ __forceinline__ double2 ld2g(const double *row, int64_t c, int64_t cols) {
+    if (c + 1 < cols) return *reinterpret_cast<const double2 *>(row + c);
+    return make_double2(c < cols ? row[c] : 0.0, 0.0);
+}
+
+}  // namespace
+
+// Timing experiments (tools/micro/k5_stamps.py; build with EVC_DEBUG_STAMPS=1), compiled out of the product library.
+#ifdef EVC_DEBUG_STAMPS
+__device__ long long g_k5l_wg[1024 * 8];   // per workgroup: entry, main loop done (wave 0), exit, hw id, 4 epilogue stamps
+#define EVC_K5L_WG(i_)                                                                 \
+    do {                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                   \
+            long long t_;                                                              \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            g_k5l_wg[8 * blockIdx.x + (i_)] = t_;                                      \
+            if ((i_) == 0) {                                                           \
+                unsigned hw_, xcc_;                                                    \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));      \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));    \
+                g_k5l_wg[8 * blockIdx.x + 3] = ((long long)(xcc_ & 0xF) << 32) | hw_;  \
+            }                                                                          \
+        }                                                                              \
+    } while (0)
+#else
+#define EVC_K5L_WG(i_) do { } while (0)
+#endif
+
+// One wave's state: everything the unrolled chunk body needs.
+template <int GS, int NT>
+struct LdsRowsWave {
+    static constexpr int NS = NT + GS;
+    const char *abase;       // first row of the row group, column 0 (wave-uniform)
+    int64_t tile_stride;     // 16 rows in bytes
+    int64_t rows_left;       // rows of the matrix from the row group's first row on (>= 1)
+    int64_t ld;
+    const char *vb[GS][2];   // per lane: its 16 bytes of its geometry's vector at column 0, both instructions of a tile
+    unsigned voff[2];        // per lane: its 16 bytes relative to the tile's first row, column 0 (full tiles)
+    unsigned lbase;          // LDS byte address of this wave's image
+    int prow, ppiece;        // producer: row within the 8-row piece (lane >> 3) and 16-byte position (lane & 7)
+    unsigned raddr[2];       // consumer: byte offset of (row l15, k pair u) within a tile
+
+    // refill slot S with the columns [cc, cc + 16)
+    template <int S>
+    __device__ __forceinline__ void issue(int64_t cc) const {
+        const unsigned la = lbase + S * kTileBytes;
+        if constexpr (S < GS) {
+            glds_v(vb[S][0] + cc * 8, la);
+            glds_v(vb[S][1] + cc * 8, la + 1024);
+        } else {
+            constexpr int t = S - GS;
+            const int64_t left = rows_left - 16 * t;   // rows of the matrix in and below this tile (wave-uniform)
+            if (left >= 16) {
+                const char *sb = abase + t * tile_stride + cc * 8;
+                glds_s(voff[0], sb, la);
+                glds_s(voff[1], sb, la + 1024);
+            } else {
+                // ragged or empty tile: rows beyond the matrix re-read its last row (their results are discarded)
+                const int64_t first = left >= 1 ? 16 * t : rows_left - 1;   // first row fetched, relative to the group
+                const int last = left >= 1 ? (int)left - 1 : 0;             // last valid row relative to `first`
+                const char *sb = abase + first * ld * 8 + cc * 8;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = 8 * j + prow;
+                    const int q = ppiece ^ ((r >> 1) & 7);
+                    const int rc = r < last ? r : last;
+                    glds_s((unsigned)(((int64_t)rc * ld + 2 * q) * 8), sb, la + 1024 * j);
+                }
+            }
+        }
+    }
+};
+
+// slot index known after unrolling: the chain folds to the one call
+template <int GS, int NT, int S = 0>
+__device__ __forceinline__ void lds_issue_dyn(const LdsRowsWave<GS, NT> &w, int s, int64_t cc) {
+    if constexpr (S < NT + GS) {
+        if (s == S) w.template issue<S>(cc);
+        else lds_issue_dyn<GS, NT, S + 1>(w, s, cc);
+    }
+}
+// slots 0 .. NS-2 (the prologue: slot NS-1 is requested by position 0 of the chunk itself)
+template <int GS, int NT, int S = 0>
+__device__ __forceinline__ void lds_issue_range(const LdsRowsWave<GS, NT> &w, int64_t cc) {
+    if constexpr (S < NT + GS - 1) {
+        w.template issue<S>(cc);
+        lds_issue_range<GS, NT, S + 1>(w, cc);
+    }
+}
+
+// GS sets of 16 geometries [g0, g0 + G), 16 (GS - 1) < G <= 16 GS; NT = most tiles per row group.
+template <int GS, int NT>
+__global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L, int g0, int G) {
+    extern __shared__ __align__(16) double lds_img[];
+    using W = LdsRowsWave<GS, NT>;
+    constexpr int NS = W::NS;
+    constexpr int IMG = NS * kTileBytes;   // bytes per wave
+    int b = blockIdx.x;
+    int which, span, rg;
+    if (b < L.nblk1) {  // the few blocks of the small second problem are dispatched first
+        which = 1;
+        const int nrg1 = L.nrg[1];
+        span = b / nrg1;
+        rg = b - span * nrg1;
+        if (span >= L.p[1].nspans) return;
+    } else {
+        which = 0;
+        b -= L.nblk1;  // nblk1 is a multiple of 8: b & 7 is still the XCD this block was dealt to
+        const int nrg0 = L.nrg[0];
+        const int xcd = b & 7, idx = b >> 3;
+        const int j = idx / nrg0;
+        rg = idx - j * nrg0;
+        span = j * 8 + xcd;
+        if (span >= L.p[0].nspans) return;
+    }
+    EVC_K5L_WG(0);
+    const RowProblem &P = L.p[which];
+    const int64_t rows = P.rows, cols = P.cols, ld = P.ld;
+    const int tpg = L.tpg[which], trem = L.trem[which];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t row_base = (int64_t)(rg * tpg + min(rg, trem)) * 16;
+    const int ntile = tpg + (rg < trem ? 1 : 0);  // tiles of this row group (the last one may be ragged)
+    const int64_t cbeg = (int64_t)span * P.span_cols;
+    const int64_t cend = min(cols, (int64_t)(span + 1) * P.span_cols);
+
+    W w;
+    w.abase = reinterpret_cast<const char *>(P.A + row_base * ld);
+    w.tile_stride = 16 * ld * 8;
+    w.rows_left = rows - row_base;
+    w.ld = ld;
+    w.prow = lane >> 3;
+    w.ppiece = lane & 7;
+    w.lbase = (unsigned)(wave * IMG);   // the dynamic array is the only LDS of this kernel: it starts at address 0
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * j + w.prow;
+        const int q = w.ppiece ^ ((r >> 1) & 7);
+        w.voff[j] = (unsigned)(((int64_t)r * ld + 2 * q) * 8);
+#pragma unroll
+        for (int gs = 0; gs < GS; ++gs) {
+            const int slot = 16 * gs + r;
+            const int gg = g0 + (slot < G ? slot : 0);   // slots beyond G read geometry g0 (a valid address)
+            w.vb[gs][j] = reinterpret_cast<const char *>(P.v + (int64_t)gg * P.vstride + 2 * q);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        w.raddr[u] = (unsigned)((l15 >> 3) * 1024 + (l15 & 7) * 128 + (((4 * u + l4) ^ ((l15 >> 1) & 7)) * 16));
+
+    d4 acc[GS][NT];
+#pragma unroll
+    for (int gs = 0; gs < GS; ++gs)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[gs][t] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const char *img = reinterpret_cast<const char *>(lds_img) + wave * IMG;
+    const int64_t cfull = min(cend, cols & ~(int64_t)(kLW - 1));   // chunks starting below this are complete
+    int64_t c = cbeg + wave * kLW;
+    const int64_t nmy = c < cfull ? (cfull - c + 4 * kLW - 1) / (4 * kLW) : 0;   // complete chunks of this wave
+
+    double2 bf[GS][2];
+    double2 af[2][2];
+#define EVC_LDS_MMA(T_, AF_)                                                                    \
+    {                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                         \
+            _Pragma("unroll") for (int gs = 0; gs < GS; ++gs)                                   \
+                acc[gs][T_] = mfma64(AF_[u].x, bf[gs][u].x, acc[gs][T_]);                       \
+            _Pragma("unroll") for (int gs = 0; gs < GS; ++gs)                                   \
+                acc[gs][T_] = mfma64(AF_[u].y, bf[gs][u].y, acc[gs][T_]);                       \
+        }                                                                                       \
+    }
+// One chunk at columns CC_; NEXT_: the wave has another chunk at CN_ (refilled slot by slot behind the reads).
+#define EVC_LDS_CHUNK(NEXT_, CC_, CN_)                                                                      \
+    {                                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                    \
+            wait_vm_n((NEXT_) || p == 0 ? 2 * (NS - 2) : (p < NS - 1 ? 2 * (NS - 1 - p) : 0));              \
+            const char *tp = img + p * kTileBytes;                                                          \
+            if (p < GS) {                                                                                   \
+                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                               \
+                    bf[p < GS ? p : 0][u] = *reinterpret_cast<const double2 *>(tp + w.raddr[u]);            \
+            } else {                                                                                        \
+                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                               \
+                    af[p & 1][u] = *reinterpret_cast<const double2 *>(tp + w.raddr[u]);                     \
+            }                                                                                               \
+            if (p >= GS + 1) EVC_LDS_MMA(p - GS - 1 >= 0 ? p - GS - 1 : 0, af[(p - 1) & 1])                 \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            wait_lds();   /* the reads of slot p - 1 (and of slot p) have left LDS: the slot may be refilled */ \
+            if (p == 0) w.template issue<NS - 1>(CC_);                                                      \
+            else if (NEXT_) lds_issue_dyn<GS, NT>(w, p - 1, CN_);                                           \
+        }                                                                                                   \
+        EVC_LDS_MMA(NT - 1, af[(NS - 1) & 1])                                                               \
+    }
+    if (nmy > 0) {
+        lds_issue_range<GS, NT>(w, c);   // slots 0 .. NS-2 of the first chunk
+        for (int64_t i = 0; i + 1 < nmy; ++i) {
+            EVC_LDS_CHUNK(true, c, c + 4 * kLW)
+            c += 4 * kLW;
+        }
+        EVC_LDS_CHUNK(false, c, c)
+    }
+#undef EVC_LDS_CHUNK
+    // the ragged last chunk of the matrix (fewer than 16 columns): the wave whose turn it is, with guarded loads
+    const int64_t ctail = cols & ~(int64_t)(kLW - 1);
+    if (ctail < cols && ctail >= cbeg && ctail < cend && (int)(((ctail - cbeg) / kLW) & 3) == wave) {
+        wait_vm<0>();
+#pragma unroll
+        for (int gs = 0; gs < GS; ++gs) {
+            const int slot = 16 * gs + l15;
+            const double *vr = P.v + (int64_t)(g0 + (slot < G ? slot : 0)) * P.vstride;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bf[gs][u] = ld2g(vr, ctail + 8 * u + 2 * l4, cols);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double *ar = P.A + min(row_base + 16 * t + l15, rows - 1) * ld;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) af[0][u] = ld2g(ar, ctail + 8 * u + 2 * l4, cols);
+            EVC_LDS_MMA(t, af[0])
+        }
+    }
+#undef EVC_LDS_MMA
+    EVC_K5L_WG(1);
+    // Cross-wave sum through the (now idle) images, one geometry set per pass, as a reduce-scatter: tile tt belongs to
+    // wave tt & 3; the other three waves file their accumulators of it in the accumulator's own layout
+    // ([tile][copy][lane][4 doubles]: 16-byte LDS accesses, no conflicts), the owner adds the four in wave order --
+    // (w0 + w1) + (w2 + w3), whoever owns the tile -- and stores the tile straight from its registers.
+    wait_vm<0>();
+    d4 *red = reinterpret_cast<d4 *>(lds_img);
+#pragma unroll
+    for (int gs = 0; gs < GS; ++gs) {
+        __syncthreads();
+        if (gs == 0) EVC_K5L_WG(4);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            if ((tt & 3) != wave) {
+                const int k = (wave - (tt & 3) - 1) & 3;   // 0..2: wave owner+1+k
+                red[(tt * 3 + k) * 64 + lane] = acc[gs][tt];
+            }
+        }
+        if (gs == 0) EVC_K5L_WG(5);
+        __syncthreads();
+        if (gs == 0) EVC_K5L_WG(6);
+        const int g = 16 * gs + l15;
+        double *dst = P.partial + (int64_t)(g0 + g) * P.pstride + (int64_t)span * rows + row_base + l4;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            if ((tt & 3) == wave && tt < ntile) {
+                d4 v[4];
+                v[tt & 3] = acc[gs][tt];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[((tt & 3) + 1 + k) & 3] = red[(tt * 3 + k) * 64 + lane];
+                const d4 sum = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row_base + tt * 16 + l4 + 4 * r;
+#ifdef EVC_K5L_NOSTORE   // timing experiment: the sums are formed, (almost) nothing is stored
+                    if (row < rows && g < G && sum[r] == 1.2345) dst[tt * 16 + 4 * r] = sum[r];
+#else
+                    if (row < rows && g < G) dst[tt * 16 + 4 * r] = sum[r];
+#endif
+                }
+            }
+        }
+        if (gs == 0) EVC_K5L_WG(7);
+    }
+    EVC_K5L_WG(2);
+}
+
+// ---------------------------------------------------------------------------------- host side
+constexpr int kLdsNT = 14;          // tiles per row group (GS = 2: 28 accumulator tiles = 224 registers)
+constexpr int kLdsBlocks = 242;     // workgroups of the large problem: one per CU (the images fill the LDS), one round
+constexpr int kLdsBlocksSmall = 8;  // ... of the small (one-body) problem
+
+static bool rows_lds_enabled() {
+    static const bool on = !(getenv("EVC_ROWS_LDS") && atoi(getenv("EVC_ROWS_LDS")) == 0);
+    return on;
+}
+
+static int lds_row_groups(int64_t rows) { return (int)ceil_div(ceil_div(rows > 0 ? rows : 1, 16), kLdsNT); }
+
+// Span plan of the LDS-staged kernel: spans of 64 m columns (m 16-column chunks for each of the four waves), as many
+// as fit `budget` workgroups in one round.
+static void plan_one_lds(RowProblem &P, int budget) {
+    const int nrg = lds_row_groups(P.rows);
+    int spans = budget / nrg;
+    if (spans < 1) spans = 1;
+    const int64_t chunks = ceil_div(P.cols, kLW);
+    int64_t m = ceil_div(chunks, 4 * (int64_t)spans);
+    if (m < 1) m = 1;
+    P.span_cols = 4 * kLW * m;
+    P.nspans = (int)ceil_div(P.cols, P.span_cols);
+    P.nblocks = nrg * P.nspans;
+    P.lds_plan = 1;
+}
+
+bool rows_lds_applicable(const RowProblem &p0, const RowProblem &p1) {
+    if (!rows_lds_enabled() || p0.rows <= 0 || p0.cols < 4096) return false;
+    // 32-bit lane offsets inside a tile; the small problem in at most kLdsBlocksSmall workgroups' worth of row groups
+    if (16 * p0.ld * 8 >= ((int64_t)1 << 31) || 16 * p1.ld * 8 >= ((int64_t)1 << 31)) return false;
+    return lds_row_groups(p0.rows) <= kLdsBlocks / 8 && lds_row_groups(p1.rows) <= kLdsBlocksSmall;
+}
+
+void plan_rows_lds(RowProblem &p0, RowProblem &p1) {
+    plan_one_lds(p0, kLdsBlocks);
+    plan_one_lds(p1, kLdsBlocksSmall);
+}
+
+// most spans either plan makes of this problem (the partial buffers are carved for it)
+int rows_max_spans(const RowProblem &P, bool small) {
+    RowProblem a = P, b = P;
+    plan_rows(a, true);
+    plan_one_lds(b, small ? kLdsBlocksSmall : kLdsBlocks);
+    return a.nspans > b.nspans ? a.nspans : b.nspans;
+}
+
+int launch_gemv_rows_lds(const GemvRowsLaunch &Lin, int g0, int G, hipStream_t st) {
+    GemvRowsLaunch L = Lin;
+    for (int k = 0; k < 2; ++k) {
+        const int nt = (int)ceil_div(L.p[k].rows > 0 ? L.p[k].rows : 1, 16);
+        L.nrg[k] = (int)ceil_div(nt, kLdsNT);
+        L.tpg[k] = nt / L.nrg[k];
+        L.trem[k] = nt % L.nrg[k];
+        if (!L.p[k].nblocks) L.p[k].nspans = 0;
+        EVC_REQUIRE(L.p[k].span_cols % kLW == 0, "gemv_rows_lds: span of %lld columns", (long long)L.p[k].span_cols);
+        EVC_REQUIRE(!L.p[k].nblocks || (aligned16(L.p[k].A) && aligned16(L.p[k].v) && L.p[k].ld % 2 == 0 &&
+                                        L.p[k].vstride % 2 == 0),
+                    "gemv_rows_lds: operands must be 16-byte aligned with even pitches");
+    }
+    const int nb0 = L.p[0].nblocks ? 8 * L.nrg[0] * (int)ceil_div(L.p[0].nspans, 8) : 0;
+    const int nb1 = L.p[1].nblocks ? (int)ceil_div((int64_t)L.nrg[1] * L.p[1].nspans, 8) * 8 : 0;
+    L.nblk0 = nb0;
+    L.nblk1 = nb1;
+    if (G > 16) {
+        constexpr int lds = 4 * (kLdsNT + 2) * kTileBytes;
+        static LdsAttr attr;
+        if (int rc = allow_dynamic_lds(gemv_rows_lds_kernel<2, kLdsNT>, attr, lds, "gemv_rows_lds")) return rc;
+        hipLaunchKernelGGL((gemv_rows_lds_kernel<2, kLdsNT>), dim3(nb0 + nb1), dim3(256), lds, st, L, g0, G);
+    } else {
+        constexpr int lds = 4 * (kLdsNT + 1) * kTileBytes;
+        static LdsAttr attr;
+        if (int rc = allow_dynamic_lds(gemv_rows_lds_kernel<1, kLdsNT>, attr, lds, "gemv_rows_lds")) return rc;
+        hipLaunchKernelGGL((gemv_rows_lds_kernel<1, kLdsNT>), dim3(nb0 + nb1), dim3(256), lds, st, L, g0, G);
+    }
+    EVC_LAUNCH_CHECK("gemv_rows_lds");
+    return 0;
+}
+
+}  // namespace evc
+
+#ifdef EVC_DEBUG_STAMPS
+extern "C" int evc_debug_read_k5l(long long *stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(evc::g_k5l_wg), sizeof(long long) * 1024 * 8);
+}
+#endif

@@ -233,14 +233,14 @@ void plan_rows(RowProblem &P, bool batched) {
     P.span_cols = cps * kChunk;
     P.nspans = (int)ceil_div(P.cols, P.span_cols);
     P.nblocks = (int)(nrb * P.nspans);
+    P.lds_plan = 0;
 }
 
 size_t rows_ws_doubles(int64_t rows, int64_t cols) {
     RowProblem P{};
     P.rows = rows;
     P.cols = cols;
-    plan_rows(P, true);
-    return (size_t)rows * P.nspans;
+    return (size_t)rows * rows_max_spans(P, false);
 }
 
 // The span decomposition (span_cols, nspans -> layout of the partials) is fixed by plan_rows; the row-block
@@ -262,6 +262,24 @@ static void rows_wr_launch(GemvRowsLaunch L, int g0, hipStream_t st) {
                        L, g0);
 }
 
+static int mfma_min_g() {
+    static const int v = env_int("EVC_MFMA_MIN_G", 12);   // groups of >= this many geometries use the matrix cores
+    return v;
+}
+static int mfma_max_g() {
+    static const int v = env_int("EVC_MFMA_MAX_G", 32);   // geometries per pass over the matrix (16 or 32)
+    return v;
+}
+// the grouping of launch_gemv_rows below: true if no group of fewer than mfma_min geometries is left over
+bool rows_groups_all_mfma(int count) {
+    int left = count;
+    while (left > 0) {
+        if (left < mfma_min_g()) return false;
+        left -= left < mfma_max_g() ? left : mfma_max_g();
+    }
+    return count > 0;
+}
+
 int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     GemvRowsLaunch L;
     L.p[0] = p0;
@@ -270,8 +288,7 @@ int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     if (p0.nblocks + p1.nblocks == 0 || count <= 0) return 0;
     static const int v8 = env_int("EVC_ROWS_G8", 0);   // 0: wave-rows kernel RBW=4; 1: lane-private RB=2
     static const int v4 = env_int("EVC_ROWS_G4", 0);   // 0: wave-rows RBW=8; 1: wave-rows RBW=4; 2: lane-private RB=4
-    static const int mfma_min = env_int("EVC_MFMA_MIN_G", 12);   // groups of >= this many geometries use the matrix cores
-    static const int mfma_max = env_int("EVC_MFMA_MAX_G", 32);   // geometries per pass over the matrix (16 or 32)
+    const int mfma_min = mfma_min_g(), mfma_max = mfma_max_g();
     static const int mfma_tiles = env_int("EVC_MFMA_TILES", 0);   // most 16-row tiles per row group (0: default, 3)
     int g0 = 0;
     while (g0 < count) {

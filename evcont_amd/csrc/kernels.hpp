@@ -20,6 +20,7 @@ struct RowProblem {
     int64_t rows, cols, ld, vstride, pstride;
     int nspans, nblocks;
     int64_t span_cols;  // columns per span (a multiple of 32; the last span may be shorter): span s = [s, s+1) * span_cols
+    int lds_plan;       // spans planned for the LDS-staged matrix-core kernel (gemv_lds.hip: plan_rows_lds)
 };
 struct GemvRowsLaunch {
     RowProblem p[2];
@@ -48,6 +49,12 @@ struct GemvColsLaunch {
 int launch_gemv_rows_mfma(const GemvRowsLaunch &L, int g0, int G, int tiles, hipStream_t st);
 int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st);
 void plan_rows(RowProblem &P, bool batched);
+// gemv_lds.hip: the LDS-staged rows kernel for groups of 12 .. 32 geometries and its span plan
+bool rows_lds_applicable(const RowProblem &p0, const RowProblem &p1);
+void plan_rows_lds(RowProblem &p0, RowProblem &p1);
+int rows_max_spans(const RowProblem &P, bool small);
+int launch_gemv_rows_lds(const GemvRowsLaunch &L, int g0, int G, hipStream_t st);
+bool rows_groups_all_mfma(int count);   // gemv_stream.hip: every group of a batch of `count` runs on the matrix cores
 size_t rows_ws_doubles(int64_t rows, int64_t cols);
 // `count` geometries; launched in groups of up to kMaxBatchG that share one read of A.
 int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st);

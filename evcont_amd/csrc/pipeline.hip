@@ -178,8 +178,9 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.rp1.cols = (int64_t)n2;
     w.rp1.ld = t->ld1;
     plan_rows(w.rp1, true);
-    w.h2part = take((size_t)t->rows2 * (w.rp2.nspans > 0 ? w.rp2.nspans : 1) + 1);
-    w.h1part = take((size_t)T * T * w.rp1.nspans);
+    // (carved for whichever span plan makes more spans: plan_rows or the LDS-staged kernel's, gemv_lds.hip)
+    w.h2part = take((size_t)t->rows2 * (t->rows2 > 0 ? rows_max_spans(w.rp2, false) : 1) + 1);
+    w.h1part = take((size_t)T * T * rows_max_spans(w.rp1, true));
     w.h2rows = take((size_t)t->rows2_total);
     w.w2 = take((size_t)t->rows2 + 1);
     w.w2t = take((size_t)t->rows2 * kMaxBatchG + 1);
@@ -234,6 +235,10 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const double *partial,
 // Span plan of this call (never more spans than the buffers were carved for).
 static void replan(const evc_trdm_set *t, Ws &w, int count) {
     const bool batched = count > 1;
+    if (t->rows2 > 0 && rows_groups_all_mfma(count) && rows_lds_applicable(w.rp2, w.rp1)) {
+        plan_rows_lds(w.rp2, w.rp1);
+        return;
+    }
     if (t->rows2 > 0) plan_rows(w.rp2, batched);
     plan_rows(w.rp1, batched);
 }

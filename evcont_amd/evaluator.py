@@ -451,9 +451,11 @@ class BatchedEvaluator:
 
     def __init__(self, trdms: DeviceTRDMs, natm: int, count: int, stream: Optional["torch.cuda.Stream"] = None,
                  keep_density_matrices: bool = False, keep_hmat: bool = False, warm_start: bool = False,
-                 keep_one_rdm: bool = False):
+                 keep_one_rdm: bool = False, energy_grad: Optional[torch.Tensor] = None):
         """``warm_start``: consecutive calls hold, slot by slot, nearby geometries (steps of ``count`` trajectories):
-        from the second call on the eigensolvers start from the previous call's eigenvectors (EVC_FLAG_WARM_START)."""
+        from the second call on the eigensolvers start from the previous call's eigenvectors (EVC_FLAG_WARM_START).
+        ``energy_grad``: caller's buffer of ``count * T + count * max(natm, 1) * 3`` doubles for the energies and the
+        gradients -- e.g. PINNED HOST memory, which the device writes directly (no download copy, hosted.py)."""
         self.t, self.natm, self.count, self.stream = trdms, int(natm), int(count), stream
         self.warm_start, self._primed = bool(warm_start), False
         self.lib = _lib.load()
@@ -468,7 +470,10 @@ class BatchedEvaluator:
         G = self.count
         # energies and gradients share one buffer: a caller that wants both on the host fetches them with ONE copy
         na = max(self.natm, 1)
-        self.energy_grad = torch.zeros(G * T + G * na * 3, dtype=F64, device=d)
+        if energy_grad is None:
+            energy_grad = torch.zeros(G * T + G * na * 3, dtype=F64, device=d)
+        assert energy_grad.dtype == F64 and energy_grad.numel() == G * T + G * na * 3 and energy_grad.is_contiguous()
+        self.energy_grad = energy_grad
         self.energy = self.energy_grad[: G * T].view(G, T)
         self.coeffs = torch.zeros((G, T, T), dtype=F64, device=d)
         self.grad = self.energy_grad[G * T:].view(G, na, 3)

@@ -34,7 +34,8 @@ _LATE = ("dhcore", "eri_ip1")
 
 class HostedEvaluator:
     def __init__(self, trdms: DeviceTRDMs, natm: int, aoslices, warm_start: bool = True,
-                 use_graph: Optional[bool] = None, keep_density_matrices: bool = False):
+                 use_graph: Optional[bool] = None, keep_density_matrices: bool = False,
+                 zero_copy: Optional[bool] = None):
         """``use_graph``: replay the step as one HIP graph (default: ``EVCONT_AMD_HOSTED_GRAPH=1``, else off --
         measured on MI355X / ROCm 7.2 the replay of a graph with memcpy nodes is no faster than the eager enqueue for
         the small systems and slower for H30)."""
@@ -51,6 +52,16 @@ class HostedEvaluator:
                   "eri_ip1": (1, 3, n, n, npr) if self.packed else (1, 3, n, n, n, n)}
         # two slabs = two H2D copies per step (a copy costs ~12 us before its first byte moves): the early arrays (the
         # small ones and int2e) and the late pair (dhcore, int2e_ip1); every array is a 16-byte aligned view of its slab
+        # SMALL systems (all inputs together below EVCONT_AMD_ZERO_COPY_BYTES, default 1 MiB): no copies at all -- the
+        # kernels read the integrals straight from the pinned staging buffers (device-visible on ROCm) and write the
+        # energies / forces straight into pinned memory.  An asynchronous copy costs ~10-15 us before its first byte
+        # moves and the step has three of them plus two stream joins, which for a 0.13 ms step (H2O 6-31G) is most of the
+        # time; reading 0.4 MB through PCIe inside the kernels costs less.
+        if zero_copy is None:
+            import os
+            lim = int(os.environ.get("EVCONT_AMD_ZERO_COPY_BYTES", str(1 << 20)))
+            zero_copy = 8 * sum(int(np.prod(v)) for v in shapes.values()) <= lim
+        self.zero_copy = bool(zero_copy)
         self._groups = (("S", "hcore", "enuc", "ipovlp", "gnuc", "eri"), _LATE)
         self.host: Dict[str, torch.Tensor] = {}
         self.dev: Dict[str, torch.Tensor] = {}
@@ -59,7 +70,7 @@ class HostedEvaluator:
             sizes = [int(np.prod(shapes[k])) for k in grp]
             offs = np.concatenate([[0], np.cumsum([(x + 1) // 2 * 2 for x in sizes])])
             hs = torch.zeros(int(offs[-1]), dtype=F64).pin_memory()
-            ds = torch.zeros(int(offs[-1]), dtype=F64, device=d)
+            ds = hs if self.zero_copy else torch.zeros(int(offs[-1]), dtype=F64, device=d)
             self._slabs.append((hs, ds))
             for k, o, x in zip(grp, offs[:-1], sizes):
                 self.host[k] = hs[int(o): int(o) + x].view(shapes[k])
@@ -71,11 +82,12 @@ class HostedEvaluator:
                                  ip1_s2kl=self.packed, eri_s4=self.packed)
         self.stream = torch.cuda.Stream(d)
         self.side = torch.cuda.Stream(d)
-        self.ev = BatchedEvaluator(trdms, self.natm, 1, stream=self.stream, warm_start=warm_start,
-                                   keep_density_matrices=keep_density_matrices, keep_one_rdm=True)
-        # (energies and gradient come back with one copy: they share a device buffer, evaluator.BatchedEvaluator)
-        self._out_slab = torch.zeros(self.ev.energy_grad.numel(), dtype=F64).pin_memory()
         T = trdms.T
+        self._out_slab = torch.zeros(T + max(self.natm, 1) * 3, dtype=F64).pin_memory()
+        self.ev = BatchedEvaluator(trdms, self.natm, 1, stream=self.stream, warm_start=warm_start,
+                                   keep_density_matrices=keep_density_matrices, keep_one_rdm=True,
+                                   energy_grad=self._out_slab if self.zero_copy else None)
+        # (energies and gradient come back with one copy: they share a device buffer, evaluator.BatchedEvaluator)
         self.out_host = {"energy": self._out_slab[:T].view(1, T),
                          "grad": self._out_slab[T:].view(1, max(self.natm, 1), 3)}
         self.use_graph = bool(use_graph)
@@ -113,6 +125,10 @@ class HostedEvaluator:
     def _enqueue_step(self) -> None:
         """Uploads, the device DAG and the downloads, on self.stream with self.side forked for the late inputs."""
         main, side = self.stream, self.side
+        if self.zero_copy:   # the kernels read the pinned buffers themselves and write the results into pinned memory
+            with torch.cuda.stream(main):
+                self.ev.enqueue(self.aob, 1, energy_only=False)
+            return
         (h0, d0), (h2, d2) = self._slabs
         # Early slab on the main stream, the late slab on a forked one, joined in front of the gradient tail.
         # (Measured alternatives on MI355X / ROCm 7.2, H30, per step: this order 425 us -- 393-402 us since the small

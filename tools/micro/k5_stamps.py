@@ -20,10 +20,11 @@ for _ in range(5):
     ev.enqueue(aob, 1, True)
 torch.cuda.synchronize()
 lib = _lib.load()
-wg = (C.c_longlong * 4096)()
-fn = lib.evc_debug_read_k5; fn.restype = C.c_int; fn.argtypes = [C.c_void_p]
+LDS = os.environ.get("EVC_ROWS_LDS") != "0"
+wg = (C.c_longlong * (8192 if LDS else 4096))()
+fn = lib.evc_debug_read_k5 if os.environ.get("EVC_ROWS_LDS") == "0" else lib.evc_debug_read_k5l; fn.restype = C.c_int; fn.argtypes = [C.c_void_p]
 assert fn(wg) == 0
-w = np.array(wg[:]).reshape(1024, 4)
+w = np.array(wg[:]).reshape(1024, 8 if LDS else 4)
 w = w[w[:, 0] != 0]
 live = w[:, 1] != 0      # blocks that returned early have no later stamps
 w = w[live]
@@ -38,3 +39,8 @@ hw = w[:, 3] & 0xFFFFFFFF
 key = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xF)
 u, cnt = np.unique(key, return_counts=True)
 print("distinct CUs", len(u), "wgs per CU histogram", np.bincount(cnt))
+
+if LDS:
+    ep = (w[:, 4:8] - w[:, 1:2]) / 100.0
+    print("epilogue stamps after the wave-0 loop end (us, median): barrier", np.median(ep[:, 0]).round(2), "LDS writes", np.median(ep[:, 1]).round(2),
+          "barrier", np.median(ep[:, 2]).round(2), "pass 0 done", np.median(ep[:, 3]).round(2), "; p90", np.percentile(ep, 90, axis=0).round(2))
