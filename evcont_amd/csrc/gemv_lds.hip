@@ -99,45 +99,56 @@ __device__ long long g_k5l_wg[1024 * 8];   // per workgroup: entry, main loop do
 #define EVC_K5L_WG(i_) do { } while (0)
 #endif
 
-// One wave's state: everything the unrolled chunk body needs.
-template <int GS, int NT>
+// block -> which << 15 | row group << 8 | span (lds_block_map below)
+struct LdsBlockMap {
+    unsigned short e[256];
+};
+
+// One wave's state: everything the unrolled body needs.  NCH chunks (consecutive chunks of this wave, 64 columns
+// apart) make one image of NSI = NCH (NT + GS) slots.
+template <int GS, int NT, int NCH>
 struct LdsRowsWave {
     static constexpr int NS = NT + GS;
+    static constexpr int NSI = NS * NCH;
     const char *abase;       // first row of the row group, column 0 (wave-uniform)
     int64_t tile_stride;     // 16 rows in bytes
-    int64_t rows_left;       // rows of the matrix from the row group's first row on (>= 1)
+    int rows_left;           // rows of the matrix from the row group's first row on (>= 1)
     int64_t ld;
+    int64_t clast;           // first column of this wave's last complete chunk (chunks beyond it re-read it)
     const char *vb[GS][2];   // per lane: its 16 bytes of its geometry's vector at column 0, both instructions of a tile
     unsigned voff[2];        // per lane: its 16 bytes relative to the tile's first row, column 0 (full tiles)
     unsigned lbase;          // LDS byte address of this wave's image
     int prow, ppiece;        // producer: row within the 8-row piece (lane >> 3) and 16-byte position (lane & 7)
     unsigned raddr[2];       // consumer: byte offset of (row l15, k pair u) within a tile
 
-    // refill slot S with the columns [cc, cc + 16)
+    // refill slot S of the image whose first chunk starts at column c0
     template <int S>
-    __device__ __forceinline__ void issue(int64_t cc) const {
+    __device__ __forceinline__ void issue(int64_t c0) const {
+        constexpr int j = S / NS, sl = S % NS;
         const unsigned la = lbase + S * kTileBytes;
-        if constexpr (S < GS) {
-            glds_v(vb[S][0] + cc * 8, la);
-            glds_v(vb[S][1] + cc * 8, la + 1024);
+        int64_t cc = c0 + j * (4 * kLW);
+        if (NCH > 1 && cc > clast) cc = clast;   // (a chunk the wave does not have: valid bytes, never consumed)
+        if constexpr (sl < GS) {
+            glds_v(vb[sl][0] + cc * 8, la);
+            glds_v(vb[sl][1] + cc * 8, la + 1024);
         } else {
-            constexpr int t = S - GS;
-            const int64_t left = rows_left - 16 * t;   // rows of the matrix in and below this tile (wave-uniform)
+            constexpr int t = sl - GS;
+            const int left = rows_left - 16 * t;   // rows of the matrix in and below this tile (wave-uniform)
             if (left >= 16) {
                 const char *sb = abase + t * tile_stride + cc * 8;
                 glds_s(voff[0], sb, la);
                 glds_s(voff[1], sb, la + 1024);
             } else {
                 // ragged or empty tile: rows beyond the matrix re-read its last row (their results are discarded)
-                const int64_t first = left >= 1 ? 16 * t : rows_left - 1;   // first row fetched, relative to the group
-                const int last = left >= 1 ? (int)left - 1 : 0;             // last valid row relative to `first`
-                const char *sb = abase + first * ld * 8 + cc * 8;
+                const int first = left >= 1 ? 16 * t : rows_left - 1;   // first row fetched, relative to the group
+                const int last = left >= 1 ? left - 1 : 0;              // last valid row relative to `first`
+                const char *sb = abase + (int64_t)first * ld * 8 + cc * 8;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int r = 8 * j + prow;
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int r = 8 * jj + prow;
                     const int q = ppiece ^ ((r >> 1) & 7);
                     const int rc = r < last ? r : last;
-                    glds_s((unsigned)(((int64_t)rc * ld + 2 * q) * 8), sb, la + 1024 * j);
+                    glds_s((unsigned)(((int64_t)rc * ld + 2 * q) * 8), sb, la + 1024 * jj);
                 }
             }
         }
@@ -145,47 +156,34 @@ struct LdsRowsWave {
 };
 
 // slot index known after unrolling: the chain folds to the one call
-template <int GS, int NT, int S = 0>
-__device__ __forceinline__ void lds_issue_dyn(const LdsRowsWave<GS, NT> &w, int s, int64_t cc) {
-    if constexpr (S < NT + GS) {
-        if (s == S) w.template issue<S>(cc);
-        else lds_issue_dyn<GS, NT, S + 1>(w, s, cc);
+template <int GS, int NT, int NCH, int S = 0>
+__device__ __forceinline__ void lds_issue_dyn(const LdsRowsWave<GS, NT, NCH> &w, int s, int64_t c0) {
+    if constexpr (S < (NT + GS) * NCH) {
+        if (s == S) w.template issue<S>(c0);
+        else lds_issue_dyn<GS, NT, NCH, S + 1>(w, s, c0);
     }
 }
-// slots 0 .. NS-2 (the prologue: slot NS-1 is requested by position 0 of the chunk itself)
-template <int GS, int NT, int S = 0>
-__device__ __forceinline__ void lds_issue_range(const LdsRowsWave<GS, NT> &w, int64_t cc) {
-    if constexpr (S < NT + GS - 1) {
-        w.template issue<S>(cc);
-        lds_issue_range<GS, NT, S + 1>(w, cc);
+// slots 0 .. NSI-2 (the prologue: slot NSI-1 is requested by position 0 of the image itself)
+template <int GS, int NT, int NCH, int S = 0>
+__device__ __forceinline__ void lds_issue_range(const LdsRowsWave<GS, NT, NCH> &w, int64_t c0) {
+    if constexpr (S < (NT + GS) * NCH - 1) {
+        w.template issue<S>(c0);
+        lds_issue_range<GS, NT, NCH, S + 1>(w, c0);
     }
 }
 
-// GS sets of 16 geometries [g0, g0 + G), 16 (GS - 1) < G <= 16 GS; NT = most tiles per row group.
-template <int GS, int NT>
-__global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L, int g0, int G) {
+// GS sets of 16 geometries [g0, g0 + G), 16 (GS - 1) < G <= 16 GS; NT = tiles per row group (every row group runs NT
+// tiles: tiles beyond the group's own are fetched from valid rows and discarded); NCH = chunks per image.
+template <int GS, int NT, int NCH>
+__global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L, LdsBlockMap M, int g0, int G) {
     extern __shared__ __align__(16) double lds_img[];
-    using W = LdsRowsWave<GS, NT>;
-    constexpr int NS = W::NS;
-    constexpr int IMG = NS * kTileBytes;   // bytes per wave
-    int b = blockIdx.x;
-    int which, span, rg;
-    if (b < L.nblk1) {  // the few blocks of the small second problem are dispatched first
-        which = 1;
-        const int nrg1 = L.nrg[1];
-        span = b / nrg1;
-        rg = b - span * nrg1;
-        if (span >= L.p[1].nspans) return;
-    } else {
-        which = 0;
-        b -= L.nblk1;  // nblk1 is a multiple of 8: b & 7 is still the XCD this block was dealt to
-        const int nrg0 = L.nrg[0];
-        const int xcd = b & 7, idx = b >> 3;
-        const int j = idx / nrg0;
-        rg = idx - j * nrg0;
-        span = j * 8 + xcd;
-        if (span >= L.p[0].nspans) return;
-    }
+    using W = LdsRowsWave<GS, NT, NCH>;
+    constexpr int NS = W::NS, NSI = W::NSI;
+    constexpr int IMG = NSI * kTileBytes;   // bytes per wave
+    // block -> (problem, span, row group) by the host's table: exactly one block per unit of work -- one workgroup
+    // fits a CU, a launch of more blocks than CUs runs its last blocks in a second round (measured: +20 us)
+    const unsigned e = M.e[blockIdx.x];
+    const int which = e >> 15, rg = (e >> 8) & 127, span = e & 255;
     EVC_K5L_WG(0);
     const RowProblem &P = L.p[which];
     const int64_t rows = P.rows, cols = P.cols, ld = P.ld;
@@ -197,12 +195,16 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
     const int ntile = tpg + (rg < trem ? 1 : 0);  // tiles of this row group (the last one may be ragged)
     const int64_t cbeg = (int64_t)span * P.span_cols;
     const int64_t cend = min(cols, (int64_t)(span + 1) * P.span_cols);
+    const int64_t cfull = min(cend, cols & ~(int64_t)(kLW - 1));   // chunks starting below this are complete
+    int64_t c = cbeg + wave * kLW;
+    const int nmy = c < cfull ? (int)((cfull - c + 4 * kLW - 1) / (4 * kLW)) : 0;   // complete chunks of this wave
 
     W w;
     w.abase = reinterpret_cast<const char *>(P.A + row_base * ld);
     w.tile_stride = 16 * ld * 8;
-    w.rows_left = rows - row_base;
+    w.rows_left = (int)(rows - row_base);
     w.ld = ld;
+    w.clast = c + (int64_t)(nmy > 0 ? nmy - 1 : 0) * (4 * kLW);
     w.prow = lane >> 3;
     w.ppiece = lane & 7;
     w.lbase = (unsigned)(wave * IMG);   // the dynamic array is the only LDS of this kernel: it starts at address 0
@@ -229,12 +231,8 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
         for (int t = 0; t < NT; ++t) acc[gs][t] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const char *img = reinterpret_cast<const char *>(lds_img) + wave * IMG;
-    const int64_t cfull = min(cend, cols & ~(int64_t)(kLW - 1));   // chunks starting below this are complete
-    int64_t c = cbeg + wave * kLW;
-    const int64_t nmy = c < cfull ? (cfull - c + 4 * kLW - 1) / (4 * kLW) : 0;   // complete chunks of this wave
-
-    double2 bf[GS][2];
-    double2 af[2][2];
+    double2 bf[GS][2], bfn[GS][2];   // geometry-vector fragments of the chunk in work / of the chunk being opened
+    double2 af[2][2];                // matrix fragments, alternating tiles
 #define EVC_LDS_MMA(T_, AF_)                                                                    \
     {                                                                                           \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                         \
@@ -244,36 +242,53 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
                 acc[gs][T_] = mfma64(AF_[u].y, bf[gs][u].y, acc[gs][T_]);                       \
         }                                                                                       \
     }
-// One chunk at columns CC_; NEXT_: the wave has another chunk at CN_ (refilled slot by slot behind the reads).
-#define EVC_LDS_CHUNK(NEXT_, CC_, CN_)                                                                      \
+// One image: chunks at C0_, C0_ + 64, ... of which NV_ are the wave's own; NEXT_: another image follows at CN_ (its slots
+// are refilled one position behind the reads).  PEND_: the last matrix tile of the chunk before still waits for its MFMAs
+// (they run behind the first fragment read of the next chunk, so no LDS latency is exposed between chunks).
+// Position p = (chunk j of the image, slot sl): wait for slot p, read its fragments, run the MFMAs of the tile before,
+// refill slot p - 1 (position 0: the image's own last slot).  LDS-DMA completes in order and NSI - 2 tiles are
+// younger than slot p whenever it is waited for: the constant vmcnt(2 (NSI - 2)) in the stream, counted down in the
+// last image.
+#define EVC_LDS_IMAGE(NEXT_, C0_, CN_, NV_)                                                                 \
     {                                                                                                       \
-        _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                    \
-            wait_vm_n((NEXT_) || p == 0 ? 2 * (NS - 2) : (p < NS - 1 ? 2 * (NS - 1 - p) : 0));              \
-            const char *tp = img + p * kTileBytes;                                                          \
-            if (p < GS) {                                                                                   \
-                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                               \
-                    bf[p < GS ? p : 0][u] = *reinterpret_cast<const double2 *>(tp + w.raddr[u]);            \
-            } else {                                                                                        \
-                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                               \
-                    af[p & 1][u] = *reinterpret_cast<const double2 *>(tp + w.raddr[u]);                     \
+        _Pragma("unroll") for (int p = 0; p < NSI; ++p) {                                                   \
+            const int j = p / NS, sl = p - j * NS;                                                          \
+            wait_vm_n((NEXT_) || p == 0 ? 2 * (NSI - 2) : (p < NSI - 1 ? 2 * (NSI - 1 - p) : 0));            \
+            if (j < (NV_)) {                                                                                \
+                const char *tp = img + p * kTileBytes;                                                      \
+                if (sl < GS) {                                                                              \
+                    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                           \
+                        bfn[sl < GS ? sl : 0][u] = *reinterpret_cast<const double2 *>(tp + w.raddr[u]);     \
+                    if (sl == 0 && pend) EVC_LDS_MMA(NT - 1, af[(NS - 1) & 1])                              \
+                } else {                                                                                    \
+                    if (sl == GS) {                                                                         \
+                        _Pragma("unroll") for (int gs = 0; gs < GS; ++gs)                                   \
+                            _Pragma("unroll") for (int u = 0; u < 2; ++u) bf[gs][u] = bfn[gs][u];           \
+                    }                                                                                       \
+                    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                           \
+                        af[sl & 1][u] = *reinterpret_cast<const double2 *>(tp + w.raddr[u]);                \
+                    if (sl >= GS + 1) EVC_LDS_MMA(sl - GS - 1 >= 0 ? sl - GS - 1 : 0, af[(sl - 1) & 1])     \
+                    if (sl == NS - 1) pend = true;                                                          \
+                }                                                                                           \
             }                                                                                               \
-            if (p >= GS + 1) EVC_LDS_MMA(p - GS - 1 >= 0 ? p - GS - 1 : 0, af[(p - 1) & 1])                 \
             __builtin_amdgcn_sched_barrier(0);                                                              \
             wait_lds();   /* the reads of slot p - 1 (and of slot p) have left LDS: the slot may be refilled */ \
-            if (p == 0) w.template issue<NS - 1>(CC_);                                                      \
-            else if (NEXT_) lds_issue_dyn<GS, NT>(w, p - 1, CN_);                                           \
+            if (p == 0) w.template issue<NSI - 1>(C0_);                                                     \
+            else if (NEXT_) lds_issue_dyn<GS, NT, NCH>(w, p - 1, CN_);                                      \
         }                                                                                                   \
-        EVC_LDS_MMA(NT - 1, af[(NS - 1) & 1])                                                               \
     }
+    bool pend = false;
     if (nmy > 0) {
-        lds_issue_range<GS, NT>(w, c);   // slots 0 .. NS-2 of the first chunk
-        for (int64_t i = 0; i + 1 < nmy; ++i) {
-            EVC_LDS_CHUNK(true, c, c + 4 * kLW)
-            c += 4 * kLW;
+        lds_issue_range<GS, NT, NCH>(w, c);   // slots 0 .. NSI-2 of the first image
+        int left = nmy;
+        for (; left > NCH; left -= NCH) {
+            EVC_LDS_IMAGE(true, c, c + NCH * 4 * kLW, NCH)
+            c += NCH * 4 * kLW;
         }
-        EVC_LDS_CHUNK(false, c, c)
+        EVC_LDS_IMAGE(false, c, c, left)
+        EVC_LDS_MMA(NT - 1, af[(NS - 1) & 1])   // (pend is set: the image held at least one chunk)
     }
-#undef EVC_LDS_CHUNK
+#undef EVC_LDS_IMAGE
     // the ragged last chunk of the matrix (fewer than 16 columns): the wave whose turn it is, with guarded loads
     const int64_t ctail = cols & ~(int64_t)(kLW - 1);
     if (ctail < cols && ctail >= cbeg && ctail < cend && (int)(((ctail - cbeg) / kLW) & 3) == wave) {
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
     EVC_K5L_WG(1);
     // Cross-wave sum through the (now idle) images, one geometry set per pass, as a reduce-scatter: tile tt belongs to
     // wave tt & 3; the other three waves file their accumulators of it in the accumulator's own layout
-    // ([tile][copy][lane][4 doubles]: 16-byte LDS accesses, no conflicts), the owner adds the four in wave order --
+    // ([tile][copy][lane][4 doubles]: 16-byte LDS accesses), the owner adds the four in wave order --
     // (w0 + w1) + (w2 + w3), whoever owns the tile -- and stores the tile straight from its registers.
     wait_vm<0>();
     d4 *red = reinterpret_cast<d4 *>(lds_img);
@@ -342,7 +357,6 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
 }
 
 // ---------------------------------------------------------------------------------- host side
-constexpr int kLdsNT = 14;          // tiles per row group (GS = 2: 28 accumulator tiles = 224 registers)
 constexpr int kLdsBlocks = 242;     // workgroups of the large problem: one per CU (the images fill the LDS), one round
 constexpr int kLdsBlocksSmall = 8;  // ... of the small (one-body) problem
 
@@ -351,12 +365,52 @@ static bool rows_lds_enabled() {
     return on;
 }
 
-static int lds_row_groups(int64_t rows) { return (int)ceil_div(ceil_div(rows > 0 ? rows : 1, 16), kLdsNT); }
+// Kernel shapes (tiles per row group, chunks per image): every shape keeps 16-18 tiles = 32-36 KB in flight per wave.
+// Fewer tiles per row group = more row groups = fewer column spans for the same number of workgroups: the partial sums
+// (spans x rows x geometries, written by every workgroup at the same moment and flushed at the end of the launch) shrink
+// -- measured at H30 / T = 20 / 32 geometries they cost 3 us in the epilogue and 3 us at the kernel boundary with 242
+// spans -- while the geometry vectors are fetched once per row group (the row groups of a span share an XCD: L2 hits).
+struct LdsShape {
+    int nt, nch;
+};
+static const LdsShape kLdsShapes[] = {{14, 1}, {7, 2}, {4, 3}, {2, 4}};
 
-// Span plan of the LDS-staged kernel: spans of 64 m columns (m 16-column chunks for each of the four waves), as many
-// as fit `budget` workgroups in one round.
-static void plan_one_lds(RowProblem &P, int budget) {
-    const int nrg = lds_row_groups(P.rows);
+// Tiles per row group for a matrix of `rows` rows (EVC_ROWS_LDS_NT forces a shape): the largest shape that makes at
+// least two row groups and pads the matrix by less than 1/8 (tiles fetched beyond its rows), else the largest one
+// that pads by less than 1/8.  Measured at H30 / T = 20 (14 tiles), 32 geometries, rocprofv3 averages of the launch
+// and of rows_reduce_kernel behind it: 14 tiles per group 52.7 + 5.9 us, 7: 50.1 + 4.6, 4: 51.2 + 4.5, 2: 51.5 + 0
+// (33 spans: summed inside the eigensolver kernel, +2 us there); the fragment-shaped kernel 57.4 + 4.6.
+static int lds_pick_nt(int64_t rows) {
+    static const int forced = getenv("EVC_ROWS_LDS_NT") ? atoi(getenv("EVC_ROWS_LDS_NT")) : 0;
+    const int nt = (int)ceil_div(rows > 0 ? rows : 1, 16);
+    static const int order[] = {7, 4, 2, 14};
+    int best = 0;
+    for (int want_groups = 2; want_groups >= 1 && !best; --want_groups)
+        for (int cand : order) {
+            const int nrg = (int)ceil_div(nt, cand);
+            if (!best && nrg >= want_groups && nrg * cand * 8 <= nt * 9 && nrg <= kLdsBlocks / 8) best = cand;
+        }
+    if (!best) {   // few tiles: the shape that fetches the fewest tiles, the larger one on a tie
+        int fewest = 1 << 30;
+        for (int cand : order) {
+            const int tiles = (int)ceil_div(nt, cand) * cand;
+            if (tiles < fewest || (tiles == fewest && cand > best)) {
+                fewest = tiles;
+                best = cand;
+            }
+        }
+    }
+    for (const LdsShape &sh : kLdsShapes)
+        if (forced == sh.nt) best = forced;
+    return best;
+}
+
+static int lds_row_groups(int64_t rows, int nt) { return (int)ceil_div(ceil_div(rows > 0 ? rows : 1, 16), nt); }
+
+// Span plan of the LDS-staged kernel: spans of 64 m columns (m 16-column chunks for each of the four waves),
+// as many as fit `budget` workgroups in one round; row groups of `ntg` tiles.
+static void plan_one_lds(RowProblem &P, int budget, int ntg) {
+    const int nrg = lds_row_groups(P.rows, ntg);
     int spans = budget / nrg;
     if (spans < 1) spans = 1;
     const int64_t chunks = ceil_div(P.cols, kLW);
@@ -365,34 +419,88 @@ static void plan_one_lds(RowProblem &P, int budget) {
     P.span_cols = 4 * kLW * m;
     P.nspans = (int)ceil_div(P.cols, P.span_cols);
     P.nblocks = nrg * P.nspans;
-    P.lds_plan = 1;
+    P.lds_plan = ntg;
 }
 
 bool rows_lds_applicable(const RowProblem &p0, const RowProblem &p1) {
-    if (!rows_lds_enabled() || p0.rows <= 0 || p0.cols < 4096) return false;
+    // (narrow matrices stay with the fragment-shaped kernel: nothing to stream; EVC_ROWS_LDS_MINCOLS=1 sends the small
+    //  shapes of the parity tests through this kernel)
+    static const int64_t min_cols = getenv("EVC_ROWS_LDS_MINCOLS") ? atoll(getenv("EVC_ROWS_LDS_MINCOLS")) : 4096;
+    if (!rows_lds_enabled() || p0.rows <= 0 || p0.cols < min_cols) return false;
     // 32-bit lane offsets inside a tile; the small problem in at most kLdsBlocksSmall workgroups' worth of row groups
     if (16 * p0.ld * 8 >= ((int64_t)1 << 31) || 16 * p1.ld * 8 >= ((int64_t)1 << 31)) return false;
-    return lds_row_groups(p0.rows) <= kLdsBlocks / 8 && lds_row_groups(p1.rows) <= kLdsBlocksSmall;
+    return lds_row_groups(p0.rows, 14) <= kLdsBlocks / 8 && lds_row_groups(p1.rows, 14) <= kLdsBlocksSmall;
 }
 
+// Both problems run in ONE launch, i.e. in one kernel shape (the large problem's); together they fill one round.
 void plan_rows_lds(RowProblem &p0, RowProblem &p1) {
-    plan_one_lds(p0, kLdsBlocks);
-    plan_one_lds(p1, kLdsBlocksSmall);
+    const int ntg = lds_pick_nt(p0.rows);
+    plan_one_lds(p1, kLdsBlocksSmall, ntg);
+    plan_one_lds(p0, kLdsBlocks + kLdsBlocksSmall - p1.nblocks, ntg);
 }
 
-// most spans either plan makes of this problem (the partial buffers are carved for it)
+// most spans any plan makes of this problem (the partial buffers are carved for it)
 int rows_max_spans(const RowProblem &P, bool small) {
     RowProblem a = P, b = P;
     plan_rows(a, true);
-    plan_one_lds(b, small ? kLdsBlocksSmall : kLdsBlocks);
+    // (the 14-tile shape has the fewest row groups, hence the most spans)
+    const int nrg = lds_row_groups(P.rows, 14);
+    int spans = (small ? kLdsBlocksSmall : kLdsBlocks) / nrg;
+    if (spans < 1) spans = 1;
+    const int64_t chunks = ceil_div(P.cols > 0 ? P.cols : 1, kLW);
+    const int64_t m = ceil_div(chunks, 4 * (int64_t)spans);
+    b.nspans = (int)ceil_div(P.cols > 0 ? P.cols : 1, 4 * kLW * (m < 1 ? 1 : m));
     return a.nspans > b.nspans ? a.nspans : b.nspans;
+}
+
+// Blocks are dealt to the 8 XCDs round-robin by their index (each XCD has its own L2): the row groups of one span,
+// which read the same pieces of the geometry vectors, get indices that are congruent mod 8 as long as the XCD has
+// `nrg` indices left; the last spans take what remains.  The small problem's blocks come first.
+static void lds_block_map(const GemvRowsLaunch &L, int nb1, int nb0, LdsBlockMap &M) {
+    int n = 0;
+    for (int b = 0; b < nb1; ++b) M.e[n++] = (unsigned short)(1u << 15 | (unsigned)(b % L.nrg[1]) << 8 | (unsigned)(b / L.nrg[1]));
+    int next[8], left[8];   // next free index of each XCD, indices it has left
+    for (int x = 0; x < 8; ++x) {
+        next[x] = nb1 + ((x - nb1) & 7);
+        left[x] = next[x] < nb1 + nb0 ? (nb1 + nb0 - 1 - next[x]) / 8 + 1 : 0;
+    }
+    const int nrg = L.nrg[0];
+    int x = nb1 & 7;
+    for (int s = 0; s < L.p[0].nspans; ++s) {
+        int pick = -1;
+        for (int k = 0; k < 8 && pick < 0; ++k)   // round-robin over the XCDs that can still take a whole span
+            if (left[(x + k) & 7] >= nrg) pick = (x + k) & 7;
+        for (int rg = 0; rg < nrg; ++rg) {
+            int xx = pick;
+            if (xx < 0) {   // no XCD has room for the whole span: the one with the most indices left, block by block
+                xx = 0;
+                for (int k = 1; k < 8; ++k)
+                    if (left[k] > left[xx]) xx = k;
+            }
+            M.e[next[xx]] = (unsigned short)((unsigned)rg << 8 | (unsigned)s);
+            next[xx] += 8;
+            --left[xx];
+        }
+        if (pick >= 0) x = (pick + 1) & 7;
+    }
+}
+
+template <int GS, int NT, int NCH>
+static int lds_launch(const GemvRowsLaunch &L, const LdsBlockMap &M, int nblocks, int g0, int G, hipStream_t st) {
+    constexpr int lds = 4 * (NT + GS) * NCH * kTileBytes;
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(gemv_rows_lds_kernel<GS, NT, NCH>, attr, lds, "gemv_rows_lds")) return rc;
+    hipLaunchKernelGGL((gemv_rows_lds_kernel<GS, NT, NCH>), dim3(nblocks), dim3(256), lds, st, L, M, g0, G);
+    return 0;
 }
 
 int launch_gemv_rows_lds(const GemvRowsLaunch &Lin, int g0, int G, hipStream_t st) {
     GemvRowsLaunch L = Lin;
+    // one kernel shape per launch: the large problem's (the small problem's row groups are dealt for the same shape)
+    const int ntg = L.p[0].nblocks ? L.p[0].lds_plan : L.p[1].lds_plan;
     for (int k = 0; k < 2; ++k) {
         const int nt = (int)ceil_div(L.p[k].rows > 0 ? L.p[k].rows : 1, 16);
-        L.nrg[k] = (int)ceil_div(nt, kLdsNT);
+        L.nrg[k] = (int)ceil_div(nt, ntg);
         L.tpg[k] = nt / L.nrg[k];
         L.trem[k] = nt % L.nrg[k];
         if (!L.p[k].nblocks) L.p[k].nspans = 0;
@@ -400,22 +508,27 @@ int launch_gemv_rows_lds(const GemvRowsLaunch &Lin, int g0, int G, hipStream_t s
         EVC_REQUIRE(!L.p[k].nblocks || (aligned16(L.p[k].A) && aligned16(L.p[k].v) && L.p[k].ld % 2 == 0 &&
                                         L.p[k].vstride % 2 == 0),
                     "gemv_rows_lds: operands must be 16-byte aligned with even pitches");
+        EVC_REQUIRE(L.p[k].nspans <= 255 && L.nrg[k] <= 127, "gemv_rows_lds: %d spans x %d row groups", L.p[k].nspans,
+                    L.nrg[k]);
     }
-    const int nb0 = L.p[0].nblocks ? 8 * L.nrg[0] * (int)ceil_div(L.p[0].nspans, 8) : 0;
-    const int nb1 = L.p[1].nblocks ? (int)ceil_div((int64_t)L.nrg[1] * L.p[1].nspans, 8) * 8 : 0;
+    const int nb0 = L.nrg[0] * L.p[0].nspans, nb1 = L.nrg[1] * L.p[1].nspans;
+    EVC_REQUIRE(nb0 + nb1 > 0 && nb0 + nb1 <= 256, "gemv_rows_lds: %d blocks", nb0 + nb1);
     L.nblk0 = nb0;
     L.nblk1 = nb1;
-    if (G > 16) {
-        constexpr int lds = 4 * (kLdsNT + 2) * kTileBytes;
-        static LdsAttr attr;
-        if (int rc = allow_dynamic_lds(gemv_rows_lds_kernel<2, kLdsNT>, attr, lds, "gemv_rows_lds")) return rc;
-        hipLaunchKernelGGL((gemv_rows_lds_kernel<2, kLdsNT>), dim3(nb0 + nb1), dim3(256), lds, st, L, g0, G);
-    } else {
-        constexpr int lds = 4 * (kLdsNT + 1) * kTileBytes;
-        static LdsAttr attr;
-        if (int rc = allow_dynamic_lds(gemv_rows_lds_kernel<1, kLdsNT>, attr, lds, "gemv_rows_lds")) return rc;
-        hipLaunchKernelGGL((gemv_rows_lds_kernel<1, kLdsNT>), dim3(nb0 + nb1), dim3(256), lds, st, L, g0, G);
+    LdsBlockMap M;
+    lds_block_map(L, nb1, nb0, M);
+    int rc = -1;
+#define EVC_LDS_CASE(NT_, NCH_)                                                        \
+    case NT_:                                                                          \
+        rc = G > 16 ? lds_launch<2, NT_, NCH_>(L, M, nb0 + nb1, g0, G, st)             \
+                    : lds_launch<1, NT_, NCH_>(L, M, nb0 + nb1, g0, G, st);            \
+        break;
+    switch (ntg) {
+        EVC_LDS_CASE(14, 1) EVC_LDS_CASE(7, 2) EVC_LDS_CASE(4, 3) EVC_LDS_CASE(2, 4)
+        default: set_error("gemv_rows_lds: no kernel for %d tiles per row group", ntg); return -1;
     }
+#undef EVC_LDS_CASE
+    if (rc) return rc;
     EVC_LAUNCH_CHECK("gemv_rows_lds");
     return 0;
 }

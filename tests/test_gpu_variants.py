@@ -26,11 +26,22 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
     {"EVC_SUBSPACE_FEW": "0"},                # large-T subspace kernel: every call through the Jacobi sweeps
     {"EVC_EIGH_F32": "0"},                    # FP64 Jacobi eigensolvers
     {"EVC_EIGH_F32": "1"},                    # FP32 Jacobi start + refinement
+    {"EVC_ROWS_LDS": "0"},                    # batched K5 with fragment-shaped loads (gemv_rows_mfma_pipe_kernel)
+    # the LDS-staged K5 (gemv_rows_lds_kernel) on the SMALL shapes of the subset (ragged / empty tiles, column tails,
+    # images with fewer chunks than slots), in its default shape and in every forced one
+    {"EVC_ROWS_LDS_MINCOLS": "1"},
+    {"EVC_ROWS_LDS_MINCOLS": "1", "EVC_ROWS_LDS_NT": "14"},
+    {"EVC_ROWS_LDS_MINCOLS": "1", "EVC_ROWS_LDS_NT": "7"},
+    {"EVC_ROWS_LDS_MINCOLS": "1", "EVC_ROWS_LDS_NT": "4"},
+    {"EVC_ROWS_LDS_MINCOLS": "1", "EVC_ROWS_LDS_NT": "2"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_variant_passes_parity_subset(env):
     e = dict(os.environ)
     e.update(env)
     subset = LARGE_T if "EVC_SUBSPACE_FEW" in env else SUBSET
+    if "EVC_ROWS_LDS_NT" in env or "EVC_ROWS_LDS" in env:   # (the kernels behind these knobs: batches of >= 12)
+        subset = ["tests/test_gpu_bench_config.py::test_k5_every_row_group_body",
+                  "tests/test_gpu_bench_config.py::test_k5_row_groups_wide_matrix", "tests/test_gpu_sym8.py::test_sym8_batched"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + subset,
                        cwd=REPO, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
