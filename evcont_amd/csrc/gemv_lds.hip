@@ -52,6 +52,14 @@ __device__ __forceinline__ void glds_s(unsigned voff, const void *sbase, unsigne
 __device__ __forceinline__ void glds_v(const void *vaddr, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(vaddr), "s"(lds_addr) : "memory");
 }
+// wave-uniform values the compiler's divergence analysis may not recognise as such (an "s" constraint alone does not
+// move a VGPR value into an SGPR)
+__device__ __forceinline__ unsigned uniform_u32(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ const void *uniform_ptr(const void *p) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = uniform_u32((unsigned)b), hi = uniform_u32((unsigned)(b >> 32));
+    return reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo);
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
@@ -530,6 +538,242 @@ int launch_gemv_rows_lds(const GemvRowsLaunch &Lin, int g0, int G, hipStream_t s
 #undef EVC_LDS_CASE
     if (rc) return rc;
     EVC_LAUNCH_CHECK("gemv_rows_lds");
+    return 0;
+}
+
+// ================================================================================== K8 through LDS-DMA
+//   O[g][c] = sum_r w[g][r] A[r][c]      (reference: ab_initio_gradients_loewdin.py:343-356, the predicted RDMs as the
+//   weighted sum of the stored transition RDMs)
+// M <-> 16 geometries, N <-> 16 columns, K <-> 4 rows per MFMA.  A wave owns whole 16-column tiles (128 bytes = one cache
+// line per row) and sums over ALL rows itself: no partial sums, no cross-wave reduction, no barrier after the weights
+// are staged.  The matrix streams through a per-wave ring of D pieces (a piece = one LDS-DMA instruction = 8 rows x
+// 128 bytes, in the order of the wave's tiles), D - 1 of them in flight; the weights of the whole launch sit in LDS as
+// wl[row][32 geometries] (the two halves of a row swapped on odd rows: the two rows a 32-lane group reads fall on
+// different banks).  Per piece: 2 + 4 ds_read_b64, 4 MFMAs (two K steps x two geometry sets), one refill.
+// A tile's pieces are padded to an even number (weights of the padding rows are zero, its loads re-read the last row), so
+// the loop body is two pieces with alternating fragment registers: the MFMAs of a piece run behind the fragment reads of
+// the next one.
+template <int GS, int D, int NW>
+__device__ __forceinline__ void cols_lds_body(const ColProblem &P, int g0, int G, int blk, int nblk, double *lds, int wave,
+                                              int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int rows = (int)P.rows;
+    const int64_t cols = P.cols, ld = P.ld;
+    const int NP = (rows + 7) >> 3;          // pieces per tile
+    const int H = (NP + 1) >> 1;             // loop iterations per tile (two pieces each)
+    const int NPe = 2 * H;
+    const int rows_w = NPe * 8;              // weight rows in LDS (zero beyond the matrix)
+    // ---- weights -> LDS (the only barrier of the kernel)
+    for (int idx = threadIdx.x; idx < rows_w * 32; idx += 64 * NW) {
+        const int r = idx >> 5, sl = idx & 31;
+        double v = 0.0;
+        if (r < rows && sl < G && sl < 16 * GS) {
+            const int gg = g0 + sl;
+            v = P.wt ? P.wt[(int64_t)(gg - gg % kMaxBatchG) * P.wstride + (int64_t)r * kMaxBatchG + gg % kMaxBatchG]
+                     : P.w[(int64_t)gg * P.wstride + r];
+        }
+        lds[r * 32 + ((((sl >> 4) ^ (r & 1)) & 1) << 4) + (sl & 15)] = v;
+    }
+    __syncthreads();
+    const int ntiles = (int)((cols + 15) >> 4);
+    // tiles of this wave: (k nblk + blk) NW + wave, k = 0, 1, ... (the waves of a workgroup take adjacent tiles)
+    const int tstride = nblk * NW;
+    int ctile = blk * NW + wave;             // consumer's tile
+    if (ctile >= ntiles) return;
+    const unsigned ring = (unsigned)(rows_w * 256 + wave * D * 1024);   // LDS byte address of this wave's ring
+    // producer lane constants: its 16 bytes of a piece
+    const int prow = lane >> 3, ppos = lane & 7;
+    const int last_valid = rows - 1 - 8 * (NP - 1);   // last valid row of the last piece, relative to it
+    const unsigned voff = (unsigned)(((int64_t)prow * ld + 2 * ppos) * 8);
+    const unsigned voff_last = (unsigned)(((int64_t)(prow < last_valid ? prow : last_valid) * ld + 2 * ppos) * 8);
+    const unsigned voff_dummy = (unsigned)(2 * ppos * 8);
+    const char *Ab = reinterpret_cast<const char *>(P.A);
+    // producer cursor
+    int ptile = ctile, ppiece = 0, pslot = 0;
+    bool pdone = false;
+    // one piece into ring slot pslot, cursor advanced: scalar work only (the vector pipe belongs to the FP64 MFMAs --
+    // a vector instruction of this wave waits for them) and a short common path: a full piece of a tile that does not
+    // hold the matrix's last columns; `psb` runs along the rows of the producer's tile
+    const int64_t piece_step = 8 * ld * 8;
+    const int tail_tile = (int)(ld >> 4) < ntiles && (((int64_t)(ld >> 4) * 16 + 16) > ld) ? (int)(ld >> 4) : -1;
+    const char *psb = Ab + (int64_t)ptile * 128;
+    int pfast = ptile == tail_tile ? 0 : NP - 1;   // pieces of the producer's tile that take the common path
+#define EVC_COLS_PRODUCE()                                                                                       \
+    {                                                                                                            \
+        const unsigned la = uniform_u32(ring + (unsigned)pslot * 1024);                                          \
+        if (ppiece < pfast) glds_s(voff, uniform_ptr(psb), la);                                                  \
+        else {                                                                                                   \
+            unsigned back = 0; /* the tile with the matrix's last columns: stay inside the row (ld is even) */   \
+            if (ptile == tail_tile) {                                                                            \
+                const int over = 2 * ppos - (int)(ld - 2 - (int64_t)ptile * 16);                                 \
+                back = over > 0 ? (unsigned)(over * 8) : 0u;                                                     \
+            }                                                                                                    \
+            if (ppiece < NP - 1) glds_s(voff - back, uniform_ptr(psb), la);                                      \
+            else if (ppiece == NP - 1) glds_s(voff_last - back, uniform_ptr(psb), la);                           \
+            else glds_s(voff_dummy - back, uniform_ptr(Ab + ((int64_t)(rows - 1) * ld + (int64_t)ptile * 16) * 8), la); \
+        }                                                                                                        \
+        pslot = pslot + 1 == D ? 0 : pslot + 1;                                                                  \
+        psb += piece_step;                                                                                       \
+        if (++ppiece == NPe) {                                                                                   \
+            ppiece = 0;                                                                                          \
+            ptile += tstride;                                                                                    \
+            psb = Ab + (int64_t)ptile * 128;                                                                     \
+            pfast = ptile == tail_tile ? 0 : NP - 1;                                                             \
+            if (ptile >= ntiles) pdone = true;                                                                   \
+        }                                                                                                        \
+    }
+#pragma unroll 1
+    for (int i = 0; i < D - 1; ++i) {
+        if (!pdone) EVC_COLS_PRODUCE()
+        else {   // (fewer pieces than ring slots: keep the in-order count with re-reads of the last row)
+            const char *sb = Ab + (int64_t)(rows - 1) * ld * 8;
+            glds_s(voff_dummy, uniform_ptr(sb), uniform_u32(ring + (unsigned)pslot * 1024));
+            pslot = pslot + 1 == D ? 0 : pslot + 1;
+        }
+    }
+    // consumer
+    const unsigned xlane = (unsigned)(l4 * 128 + l15 * 8);                       // B fragment within a piece
+    unsigned wl0[GS];                                                           // weight fragment of piece 0, K step 0
+#pragma unroll
+    for (int gs = 0; gs < GS; ++gs) wl0[gs] = (unsigned)(l4 * 256 + (((gs ^ (l4 & 1)) & 1) << 7) + l15 * 8);
+    const char *ldsb = reinterpret_cast<const char *>(lds);
+    int cslot = 0;
+    d4 acc[GS];
+    double xa[2], xb[2], wa[2][GS], wb[2][GS];
+#define EVC_COLS_READ(X_, W_, PIECE_)                                                                         \
+    {                                                                                                        \
+        const char *xp = ldsb + ring + (unsigned)cslot * 1024 + xlane;                                       \
+        X_[0] = *reinterpret_cast<const double *>(xp);                                                       \
+        X_[1] = *reinterpret_cast<const double *>(xp + 512);                                                 \
+        _Pragma("unroll") for (int gs = 0; gs < GS; ++gs) {                                                  \
+            const char *wp = ldsb + (unsigned)(PIECE_) * 2048 + wl0[gs];                                     \
+            W_[0][gs] = *reinterpret_cast<const double *>(wp);                                               \
+            W_[1][gs] = *reinterpret_cast<const double *>(wp + 1024);                                        \
+        }                                                                                                    \
+        cslot = cslot + 1 == D ? 0 : cslot + 1;                                                              \
+    }
+#define EVC_COLS_MMA_K(X_, W_, K_)                                                                           \
+    {                                                                                                        \
+        _Pragma("unroll") for (int gs = 0; gs < GS; ++gs) acc[gs] = mfma64(W_[K_][gs], X_[K_], acc[gs]);     \
+    }
+#define EVC_COLS_MMA(X_, W_)                                                                                 \
+    {                                                                                                        \
+        EVC_COLS_MMA_K(X_, W_, 0)                                                                            \
+        EVC_COLS_MMA_K(X_, W_, 1)                                                                            \
+    }
+// Position n of the wave's piece sequence: wait for piece n (D - 2 pieces are younger while the producer runs), read
+// its fragments, start the MFMAs of piece n - 1, and refill the slot read at position n - 1 BETWEEN the two halves of
+// those MFMAs: the scalar work of the refill and the LDS latency of piece n hide behind them.
+#define EVC_COLS_STEP(X_, W_, PIECE_, XP_, WP_, MMA_)                                                        \
+    {                                                                                                        \
+        if (pdone) wait_vm<0>();                                                                             \
+        else wait_vm<D - 2>();                                                                               \
+        EVC_COLS_READ(X_, W_, PIECE_)                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (MMA_) EVC_COLS_MMA_K(XP_, WP_, 0)                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        wait_lds();                                                                                          \
+        if (!pdone) EVC_COLS_PRODUCE()                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (MMA_) EVC_COLS_MMA_K(XP_, WP_, 1)                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+    for (; ctile < ntiles; ctile += tstride) {
+#pragma unroll
+        for (int gs = 0; gs < GS; ++gs) acc[gs] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int it = 0; it < H; ++it) {
+            EVC_COLS_STEP(xa, wa, 2 * it, xb, wb, it > 0)
+            EVC_COLS_STEP(xb, wb, 2 * it + 1, xa, wa, true)
+        }
+        EVC_COLS_MMA(xb, wb)
+        // D[i][j]: i = geometry l4 + 4 reg, j = column l15
+        const int64_t c = (int64_t)ctile * 16 + l15;
+        if (c < cols) {
+#pragma unroll
+            for (int gs = 0; gs < GS; ++gs)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = 16 * gs + l4 + 4 * r;
+                    if (g < G) P.out[(int64_t)(g0 + g) * P.ostride + c] = acc[gs][r];
+                }
+        }
+    }
+#undef EVC_COLS_READ
+#undef EVC_COLS_MMA
+#undef EVC_COLS_MMA_K
+#undef EVC_COLS_STEP
+#undef EVC_COLS_PRODUCE
+    wait_vm<0>();
+}
+
+template <int GS, int D0, int D1, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gemv_cols_lds_kernel(GemvColsLaunch L, int nblk1, int g0, int G) {
+    extern __shared__ __align__(16) double lds_cols[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // the few blocks of the small second problem are dispatched first
+    if ((int)blockIdx.x < nblk1) cols_lds_body<GS, D1, NW>(L.p[1], g0, G, blockIdx.x, nblk1, lds_cols, wave, lane);
+    else cols_lds_body<GS, D0, NW>(L.p[0], g0, G, blockIdx.x - nblk1, gridDim.x - nblk1, lds_cols, wave, lane);
+}
+
+// ring depth of a problem with `rows` rows and nw waves per workgroup: 24, 12 or 6 pieces, 0: the weights
+// (rows x 32) and the rings do not fit the LDS
+static int cols_lds_depth(int64_t rows, int nw) {
+    const int64_t rows_w = ((rows + 15) / 16) * 16;
+    const int64_t d = (160 * 1024 - rows_w * 256) / (nw * 1024);
+    return d >= 24 ? 24 : (d >= 12 ? 12 : (d >= 6 ? 6 : 0));
+}
+static int cols_lds_waves() {
+    static const int nw = getenv("EVC_COLS_LDS_NW") && atoi(getenv("EVC_COLS_LDS_NW")) == 4 ? 4 : 8;
+    return nw;
+}
+
+bool cols_lds_applicable(const ColProblem &p0, const ColProblem &p1, int G) {
+    static const bool on = !(getenv("EVC_COLS_LDS") && atoi(getenv("EVC_COLS_LDS")) == 0);
+    static const int64_t min_cols = getenv("EVC_ROWS_LDS_MINCOLS") ? atoll(getenv("EVC_ROWS_LDS_MINCOLS")) : 4096;
+    if (!on || p0.cols < min_cols || p0.rows <= 0 || !aligned16(p0.A) || p0.ld % 2 || p0.rows > (1 << 20)) return false;
+    if (16 * p0.ld * 8 >= ((int64_t)1 << 31) || 16 * p1.ld * 8 >= ((int64_t)1 << 31)) return false;
+    const int nw = cols_lds_waves();
+    if (cols_lds_depth(p0.rows, nw) < 12) return false;
+    if (p1.cols > 0 && (cols_lds_depth(p1.rows, nw) < 6 || !aligned16(p1.A) || p1.ld % 2 || p1.part)) return false;
+    return true;
+}
+
+template <int GS, int D0, int D1, int NW>
+static int cols_lds_launch(const GemvColsLaunch &L, int nblk1, int nblk0, size_t lds, int g0, int G, hipStream_t st) {
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(gemv_cols_lds_kernel<GS, D0, D1, NW>, attr, 160 * 1024, "gemv_cols_lds")) return rc;
+    hipLaunchKernelGGL((gemv_cols_lds_kernel<GS, D0, D1, NW>), dim3(nblk0 + nblk1), dim3(64 * NW), lds, st, L, nblk1, g0, G);
+    return 0;
+}
+
+int launch_gemv_cols_lds(const GemvColsLaunch &L, int g0, int G, hipStream_t st) {
+    const int nw = cols_lds_waves();
+    int d0 = cols_lds_depth(L.p[0].rows, nw);
+    if (nw == 8 && d0 > 12) d0 = 12;
+    const int d1 = L.p[1].cols > 0 ? (cols_lds_depth(L.p[1].rows, nw) >= 12 ? 12 : 6) : 12;
+    const int nblk1 = L.p[1].cols > 0 ? kLdsBlocksSmall : 0;
+    // workgroups of the large problem: every wave the same number of 16-column tiles (rounds), in one round of blocks
+    const int64_t ntiles = ceil_div(L.p[0].cols, 16);
+    const int64_t rounds = ceil_div(ntiles, (int64_t)nw * kLdsBlocks);
+    const int nblk0 = (int)ceil_div(ntiles, nw * rounds);
+    auto need = [&](const ColProblem &P, int d) {
+        const int64_t rows_w = ((P.rows + 15) / 16) * 16;
+        return (size_t)(rows_w * 256 + (int64_t)nw * d * 1024);
+    };
+    size_t lds = need(L.p[0], d0);
+    if (L.p[1].cols > 0 && need(L.p[1], d1) > lds) lds = need(L.p[1], d1);
+    int rc = -1;
+#define EVC_CL_CASE(GS_, D0_, D1_, NW_)                                                              \
+    if ((G > 16 ? 2 : 1) == GS_ && d0 == D0_ && d1 == D1_ && nw == NW_)                              \
+        rc = cols_lds_launch<GS_, D0_, D1_, NW_>(L, nblk1, nblk0, lds, g0, G, st);
+    EVC_CL_CASE(2, 24, 12, 4) EVC_CL_CASE(2, 12, 12, 4) EVC_CL_CASE(2, 24, 6, 4) EVC_CL_CASE(2, 12, 6, 4)
+    EVC_CL_CASE(1, 24, 12, 4) EVC_CL_CASE(1, 12, 12, 4) EVC_CL_CASE(1, 24, 6, 4) EVC_CL_CASE(1, 12, 6, 4)
+    EVC_CL_CASE(2, 12, 12, 8) EVC_CL_CASE(2, 12, 6, 8) EVC_CL_CASE(1, 12, 12, 8) EVC_CL_CASE(1, 12, 6, 8)
+#undef EVC_CL_CASE
+    if (rc == -1) set_error("gemv_cols_lds: no kernel for ring depths %d / %d, %d waves", d0, d1, nw);
+    if (rc) return rc;
+    EVC_LAUNCH_CHECK("gemv_cols_lds");
     return 0;
 }
 

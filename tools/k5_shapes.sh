@@ -19,8 +19,9 @@ print("$tag:", "; ".join(out), "value", v)
 PY
   rm -rf $R/gpurun_out/kst
 }
-one OLD EVC_ROWS_LDS=0
-one OLD-pad90K EVC_ROWS_LDS=0 EVC_ROWS_PAD_LDS=92160
-one OLD EVC_ROWS_LDS=0
-one OLD-pad90K EVC_ROWS_LDS=0 EVC_ROWS_PAD_LDS=92160
-one NT=7 EVC_ROWS_LDS_NT=7
+one K8-LDS-8w EVC_COLS_LDS=1
+one K8-LDS-4w EVC_COLS_LDS=1 EVC_COLS_LDS_NW=4
+one K8-OLD EVC_COLS_LDS=0
+one K8-LDS-8w EVC_COLS_LDS=1
+one K8-LDS-4w EVC_COLS_LDS=1 EVC_COLS_LDS_NW=4
+one K8-OLD EVC_COLS_LDS=0
