@@ -84,10 +84,12 @@ class HostedEvaluator:
         self.side = torch.cuda.Stream(d)
         T = trdms.T
         self._out_slab = torch.zeros(T + max(self.natm, 1) * 3, dtype=F64).pin_memory()
+        # (copy mode: energies and gradient come back with one copy, they share a device buffer; letting the kernels
+        #  write them into pinned memory instead was measured at 2-4x the step time for H2O / Zundel / H30 -- the
+        #  gradient tail reads the buffer back -- so only the no-copy mode of the small systems does that)
         self.ev = BatchedEvaluator(trdms, self.natm, 1, stream=self.stream, warm_start=warm_start,
                                    keep_density_matrices=keep_density_matrices, keep_one_rdm=True,
                                    energy_grad=self._out_slab if self.zero_copy else None)
-        # (energies and gradient come back with one copy: they share a device buffer, evaluator.BatchedEvaluator)
         self.out_host = {"energy": self._out_slab[:T].view(1, T),
                          "grad": self._out_slab[T:].view(1, max(self.natm, 1), 3)}
         self.use_graph = bool(use_graph)
