@@ -361,7 +361,7 @@ def main():
                 import hashlib
                 rec = json.load(open(tj))
                 hh = hashlib.sha256()
-                for f_ in ("gemv_mfma.hip", "gemv_stream.hip"):
+                for f_ in ("gemv_mfma.hip", "gemv_stream.hip", "gemv_lds.hip"):
                     hh.update(open(os.path.join(REPO, "evcont_amd", "csrc", f_), "rb").read())
                 key = f"{a.workload}/{a.layout}/batch{G}/k5"
                 if key in rec and not pairs_first:

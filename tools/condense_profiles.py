@@ -67,7 +67,7 @@ for lay in ("sym8", "pack2"):
 import hashlib
 _repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _h = hashlib.sha256()
-for _f in ("gemv_mfma.hip", "gemv_stream.hip"):
+for _f in ("gemv_mfma.hip", "gemv_stream.hip", "gemv_lds.hip"):
     _h.update(open(os.path.join(_repo, "evcont_amd", "csrc", _f), "rb").read())
 traffic["_source_sha256"] = _h.hexdigest()
 json.dump(traffic, open(os.path.join(OUT, "pmc_traffic.json"), "w"), indent=1)
