@@ -12,7 +12,7 @@ f=glob.glob("$R/gpurun_out/kst/*/*kernel_stats.csv")[0]
 out=[]
 for r in csv.DictReader(open(f)):
     n=r["Name"]
-    for k in ("gemv_rows","rows_reduce","gemv_cols","subspace"):
+    for k in ("gemv_rows","rows_reduce","gemv_cols","ip1_"):
         if k in n: out.append("%s %.1f" % (n[:44], float(r["AverageNs"])/1e3))
 v=[json.loads(l[l.index("{"):])["value"] for l in open("$R/gpurun_out/kst.log") if '"metric"' in l]
 print("$tag:", "; ".join(out), "value", v)
@@ -20,5 +20,7 @@ PY
   rm -rf $R/gpurun_out/kst
 }
 if [ -n "$NTS" ]; then for nt in $NTS; do one NT=$nt EVC_ROWS_LDS_NT=$nt; done; exit 0; fi
-one NEW EVC_ROWS_LDS=1 EVC_COLS_LDS=1
-one OLD EVC_ROWS_LDS=0 EVC_COLS_LDS=0
+one NEW EVC_ROWS_LDS=1 EVC_COLS_LDS=1 EVC_IP1_LDS=1
+one OLD EVC_ROWS_LDS=0 EVC_COLS_LDS=0 EVC_IP1_LDS=0
+one NEW EVC_ROWS_LDS=1 EVC_COLS_LDS=1 EVC_IP1_LDS=1
+one OLD-IP1 EVC_ROWS_LDS=1 EVC_COLS_LDS=1 EVC_IP1_LDS=0
