@@ -435,16 +435,24 @@ bool rows_lds_applicable(const RowProblem &p0, const RowProblem &p1) {
     //  shapes of the parity tests through this kernel)
     static const int64_t min_cols = getenv("EVC_ROWS_LDS_MINCOLS") ? atoll(getenv("EVC_ROWS_LDS_MINCOLS")) : 4096;
     if (!rows_lds_enabled() || p0.rows <= 0 || p0.cols < min_cols) return false;
-    // 32-bit lane offsets inside a tile; the small problem in at most kLdsBlocksSmall workgroups' worth of row groups
+    // 32-bit lane offsets inside a tile
     if (16 * p0.ld * 8 >= ((int64_t)1 << 31) || 16 * p1.ld * 8 >= ((int64_t)1 << 31)) return false;
-    return lds_row_groups(p0.rows, 14) <= kLdsBlocks / 8 && lds_row_groups(p1.rows, 14) <= kLdsBlocksSmall;
+    return lds_row_groups(p0.rows, 14) <= kLdsBlocks / 8;
 }
+
+// the small (one-body) problem rides in the launch of the large one if its row groups fit a few workgroups; a tall one
+// (T^2 rows: large training sets) keeps its own launch of the fragment-shaped kernel (plan_rows)
+static bool lds_small_rides(const RowProblem &p1) { return lds_row_groups(p1.rows, 14) <= kLdsBlocksSmall; }
 
 // Both problems run in ONE launch, i.e. in one kernel shape (the large problem's); together they fill one round.
 void plan_rows_lds(RowProblem &p0, RowProblem &p1) {
     const int ntg = lds_pick_nt(p0.rows);
-    plan_one_lds(p1, kLdsBlocksSmall, ntg);
-    plan_one_lds(p0, kLdsBlocks + kLdsBlocksSmall - p1.nblocks, ntg);
+    if (lds_small_rides(p1)) plan_one_lds(p1, kLdsBlocksSmall, ntg);
+    else {
+        plan_rows(p1, true);
+        p1.lds_plan = 0;
+    }
+    plan_one_lds(p0, kLdsBlocks + kLdsBlocksSmall - (p1.lds_plan ? p1.nblocks : 0), ntg);
 }
 
 // most spans any plan makes of this problem (the partial buffers are carved for it)
@@ -453,7 +461,7 @@ int rows_max_spans(const RowProblem &P, bool small) {
     plan_rows(a, true);
     // (the 14-tile shape has the fewest row groups, hence the most spans)
     const int nrg = lds_row_groups(P.rows, 14);
-    int spans = (small ? kLdsBlocksSmall : kLdsBlocks) / nrg;
+    int spans = (small ? kLdsBlocksSmall : kLdsBlocks + kLdsBlocksSmall) / nrg;
     if (spans < 1) spans = 1;
     const int64_t chunks = ceil_div(P.cols > 0 ? P.cols : 1, kLW);
     const int64_t m = ceil_div(chunks, 4 * (int64_t)spans);
