@@ -82,4 +82,11 @@ if sq:
         fo.write("kernel," + ",".join(cols) + "\n")
         for k, d in sq.items():
             fo.write(k + "," + ",".join(f"{d.get(c, 0):.0f}" for c in cols) + "\n")
+lds = kernel_means("pmc_lds_sym8_b32")   # LDS counters of the same run (a pass of its own)
+if lds:
+    cols = sorted({c for d in lds.values() for c in d})
+    with open(os.path.join(OUT, f"{ROUND}_pmc_lds_sym8_batch32.csv"), "w") as fo:
+        fo.write("kernel," + ",".join(cols) + "\n")
+        for k, d in lds.items():
+            fo.write(k + "," + ",".join(f"{d.get(c, 0):.0f}" for c in cols) + "\n")
 print(json.dumps(traffic, indent=1))
