@@ -777,9 +777,9 @@ int launch_gemv_cols_lds(const GemvColsLaunch &L, int g0, int G, hipStream_t st)
 #define EVC_CL_CASE(GS_, D0_, D1_, NW_)                                                              \
     if ((G > 16 ? 2 : 1) == GS_ && d0 == D0_ && d1 == D1_ && nw == NW_)                              \
         rc = cols_lds_launch<GS_, D0_, D1_, NW_>(L, nblk1, nblk0, lds, g0, G, st);
+    // (two geometry sets only: one set stays with the row-split kernel, cols_lds_applicable)
     EVC_CL_CASE(2, 24, 12, 4) EVC_CL_CASE(2, 12, 12, 4) EVC_CL_CASE(2, 24, 6, 4) EVC_CL_CASE(2, 12, 6, 4)
-    EVC_CL_CASE(1, 24, 12, 4) EVC_CL_CASE(1, 12, 12, 4) EVC_CL_CASE(1, 24, 6, 4) EVC_CL_CASE(1, 12, 6, 4)
-    EVC_CL_CASE(2, 12, 12, 8) EVC_CL_CASE(2, 12, 6, 8) EVC_CL_CASE(1, 12, 12, 8) EVC_CL_CASE(1, 12, 6, 8)
+    EVC_CL_CASE(2, 12, 12, 8) EVC_CL_CASE(2, 12, 6, 8)
 #undef EVC_CL_CASE
     if (rc == -1) set_error("gemv_cols_lds: no kernel for ring depths %d / %d, %d waves", d0, d1, nw);
     if (rc) return rc;
