@@ -31,6 +31,7 @@
 namespace evc {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -320,10 +321,10 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
     EVC_K5L_WG(1);
     // Cross-wave sum through the (now idle) images, one geometry set per pass, as a reduce-scatter: tile tt belongs to
     // wave tt & 3; the other three waves file their accumulators of it in the accumulator's own layout
-    // ([tile][copy][lane][4 doubles]: 16-byte LDS accesses), the owner adds the four in wave order --
+    // ([tile][copy][half][lane][2 doubles]: 16-byte LDS accesses, lanes 16 bytes apart), the owner adds the four in wave order --
     // (w0 + w1) + (w2 + w3), whoever owns the tile -- and stores the tile straight from its registers.
     wait_vm<0>();
-    d4 *red = reinterpret_cast<d4 *>(lds_img);
+    d2v *red = reinterpret_cast<d2v *>(lds_img);
 #pragma unroll
     for (int gs = 0; gs < GS; ++gs) {
         __syncthreads();
@@ -332,7 +333,9 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
         for (int tt = 0; tt < NT; ++tt) {
             if ((tt & 3) != wave) {
                 const int k = (wave - (tt & 3) - 1) & 3;   // 0..2: wave owner+1+k
-                red[(tt * 3 + k) * 64 + lane] = acc[gs][tt];
+                // (two 16-byte planes: consecutive lanes 16 bytes apart -- a 32-byte lane pitch is a 2-way conflict)
+                red[((tt * 3 + k) * 2 + 0) * 64 + lane] = (d2v){acc[gs][tt][0], acc[gs][tt][1]};
+                red[((tt * 3 + k) * 2 + 1) * 64 + lane] = (d2v){acc[gs][tt][2], acc[gs][tt][3]};
             }
         }
         if (gs == 0) EVC_K5L_WG(5);
@@ -346,7 +349,10 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
                 d4 v[4];
                 v[tt & 3] = acc[gs][tt];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) v[((tt & 3) + 1 + k) & 3] = red[(tt * 3 + k) * 64 + lane];
+                for (int k = 0; k < 3; ++k) {
+                    const d2v lo = red[((tt * 3 + k) * 2 + 0) * 64 + lane], hi = red[((tt * 3 + k) * 2 + 1) * 64 + lane];
+                    v[((tt & 3) + 1 + k) & 3] = (d4){lo[0], lo[1], hi[0], hi[1]};
+                }
                 const d4 sum = (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
