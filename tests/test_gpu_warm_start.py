@@ -11,6 +11,18 @@ from evcont_amd.synthetic import AOArrays, make_ao_arrays, make_trdms, pack_rows
 pytestmark = pytest.mark.gpu
 
 
+def _trdms(n, T, seed, dev, layout_packed=True):
+    """Training set on the device; the large shapes are generated THERE (a (40, 40, 35^4) host array is 10 GB and
+    40 s of numpy), the small ones on the host like everywhere else."""
+    from evcont_amd.evaluator import DeviceTRDMs
+    if n >= 32 and layout_packed:
+        from evcont_amd.synthetic import make_device_trdm_rows
+        S, one, rows = make_device_trdm_rows(n, T, 2, seed, dev)
+        return DeviceTRDMs.from_device_rows(one, rows, S, 2)
+    S, one, two = make_trdms(n, T, seed)
+    return DeviceTRDMs(one, pack_rows(two, True, True) if layout_packed else two, S, dev)
+
+
 def blend(a0: AOArrays, a1: AOArrays, t: float) -> AOArrays:
     mix = lambda x, y: (1.0 - t) * np.asarray(x) + t * np.asarray(y)
     return AOArrays(mix(a0.S, a1.S), mix(a0.hcore, a1.hcore), mix(a0.eri, a1.eri), mix(a0.ipovlp, a1.ipovlp),
@@ -23,9 +35,7 @@ def blend(a0: AOArrays, a1: AOArrays, t: float) -> AOArrays:
 def test_warm_start_matches_cold_start(n, T, A, lname):
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
     dev = torch.device("cuda:0")
-    S, one, two = make_trdms(n, T, 70 + n)
-    two_l = pack_rows(two, True, True) if lname == "pack2" else two
-    trd = DeviceTRDMs(one, two_l, S, dev)
+    trd = _trdms(n, T, 70 + n, dev, lname == "pack2")
     cold = ContinuationEvaluator(trd, A)
     warm = ContinuationEvaluator(trd, A, warm_start=True)
     a0, a1, other = make_ao_arrays(n, A, 1), make_ao_arrays(n, A, 2), make_ao_arrays(n, A, 3)
@@ -50,8 +60,7 @@ def test_warm_flag_on_stale_workspace_falls_back(fill, n, T):
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
     dev = torch.device("cuda:0")
     A = 3
-    S, one, two = make_trdms(n, T, 5)
-    trd = DeviceTRDMs(one, pack_rows(two, True, True), S, dev)
+    trd = _trdms(n, T, 5, dev)
     dao = DeviceAO.from_arrays(make_ao_arrays(n, A, 11), dev)
     Ec, gc = ContinuationEvaluator(trd, A).energy_with_grad(dao)
     ev = ContinuationEvaluator(trd, A, warm_start=True)
