@@ -1,4 +1,5 @@
-// K5 for 17..32 geometries per pass, the t-RDM streamed through LDS by LDS-DMA (global_load_lds_dwordx4):
+// The batched streaming contractions with the t-RDM streamed through LDS by LDS-DMA (global_load_lds_dwordx4).
+// K5 (this part of the file; batches of 12 .. 32 geometries per pass), K8 further down (17 .. 32):
 //   Y[row][g] = sum_c A[row][c] v[g][c]      (reference: ab_initio_eigenvector_continuation.py:57-64, the
 //   np.einsum / np.sum contractions of the stored transition RDMs with the rotated integrals)
 //
@@ -8,21 +9,22 @@
 // 5.9 TB/s) had the 182 MB matrix sitting in the 256 MB memory-side cache between the repeats, which the kernel in
 // situ never sees (a batch moves 1.4 GB between two passes over the matrix).  Here every load instruction moves
 // 8 rows x 128 bytes (whole cache lines) straight into LDS, no VGPRs in between, so one wave per SIMD keeps a whole
-// chunk image (32 instructions = 32 KB) in flight, and the MFMA fragments come out of LDS with ds_read_b128.
+// image (30-34 instructions = 30-34 KB) in flight, and the MFMA fragments come out of LDS with ds_read_b128.
 //
-// Decomposition: block = (column span, row group of <= NT 16-row tiles); H30 / T = 20: ONE row group of 14 tiles, so
-// the geometry vectors are read once per span (the pipe kernel reads them once per row group).  The four waves
-// interleave the 16-column chunks of the span (128 bytes per row: one cache line) and are completely independent
-// until the epilogue: no barrier in the stream.  A wave's LDS image holds one chunk: GS tiles of geometry vectors
-// (16 geometries x 16 columns) followed by NT tiles of matrix rows, 2 KB each.  Slot p of the image is refilled for
-// the NEXT chunk one position after it was read, so the image is a sliding window over two chunks and
-// (NS - 1) tiles = 2 (NS - 1) instructions are in flight all the time; LDS-DMA completes in order, so the wait in
-// front of the reads of slot p is the constant vmcnt(2 (NS - 2)).
+// Decomposition: block = (column span, row group of NT 16-row tiles), one block per CU, exactly as many blocks as
+// units of work (host-built block table).  The four waves interleave the 16-column chunks of the span (128 bytes per
+// row: one cache line) and are completely independent until the epilogue: no barrier in the stream.  A wave's LDS
+// image holds NCH chunks, each GS tiles of geometry vectors (16 geometries x 16 columns) followed by NT tiles of
+// matrix rows, 2 KB per tile.  Slot p of the image is refilled for the NEXT image one position after it was read, so
+// the image is a sliding window and (NSI - 1) tiles = 2 (NSI - 1) instructions are in flight all the time; LDS-DMA
+// completes in order, so the wait in front of the reads of slot p is the constant vmcnt(2 (NSI - 2)).
+// Shapes (NT, NCH) = (14,1) (7,2) (4,3) (2,4): see lds_pick_nt below for what the row groups buy.
 //
 // LDS image of a tile (rule "linear destination, swizzled SOURCE, same swizzle on the read"): instruction j of a
 // tile writes 1 KB = rows 8j..8j+7 x 128 bytes, lane i -> row 8j + (i >> 3), 16-byte position i & 7; the position
 // holds piece q = pos ^ ((row >> 1) & 7) of the row.  A fragment read (ds_read_b128: lane (l15, l4) takes piece
-// 4u + l4 of row l15) is then conflict free in every 16-lane group of the instruction.
+// 4u + l4 of row l15) is then conflict free in every 16-lane group of the instruction (SQ_LDS_BANK_CONFLICT = 0,
+// profiles/r03_pmc_lds_sym8_batch32.csv).
 #include <stdlib.h>
 
 #include "common.hpp"
