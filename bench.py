@@ -64,7 +64,29 @@ LAYOUT_ND = {"full6": 6, "pair5": 5, "elec3": 3, "pack2": 2,
              "sym8": 8}   # sym8: 8-fold compressed device layout, built from the pack2 rows (include/evcont_hip.h)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (~6 TB/s achievable by a plain streaming read)
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense FP64 matrix peak (v_mfma_f64_16x16x4_f64)
-MAX_G_PER_LAUNCH = 32   # geometries that share one pass over the t-RDM (csrc/gemv_mfma.hip)
+MAX_G_PER_LAUNCH = 32   # geometries that share one pass over the t-RDM (csrc/gemv_mfma.hip; K8 always)
+
+
+def k5_geometries_per_pass(G: int, rows: int, cols: int) -> int:
+    """Geometries one K5 launch contracts (mirrors csrc/gemv_lds.hip: rows_lds_max_g / lds_pick_nt): the LDS-staged
+    kernel takes up to 64 (four geometry sets) when its row groups have at most 7 tiles, every other kernel 32."""
+    if G <= 32 or os.environ.get("EVC_ROWS_LDS", "1") == "0" or os.environ.get("EVC_ROWS_LDS_G64", "1") == "0":
+        return min(G, MAX_G_PER_LAUNCH)
+    if cols < int(os.environ.get("EVC_ROWS_LDS_MINCOLS", "4096")):
+        return MAX_G_PER_LAUNCH
+    nt = -(-max(rows, 1) // 16)
+    forced = int(os.environ.get("EVC_ROWS_LDS_NT", "0"))
+    best = 0
+    for want in (2, 1):
+        for cand in (7, 4, 2, 14):
+            nrg = -(-nt // cand)
+            if not best and nrg >= want and nrg * cand * 8 <= nt * 9 and nrg <= 30:
+                best = cand
+    if not best:
+        best = min((7, 4, 2, 14), key=lambda c: (-(-nt // c) * c, -c))
+    if forced in (14, 7, 4, 2):
+        best = forced
+    return min(G, 64) if best <= 7 else MAX_G_PER_LAUNCH
 
 
 def parse():
@@ -299,20 +321,23 @@ def main():
             e_check = float(evs[0].energy.reshape(-1)[0].item())
         # every rank's own rate (its G geometries per step over the median of ITS wall times)
         per_rank = [steps * G / float(np.median(r)) for r in dts_rank]
-        gl = min(G, MAX_G_PER_LAUNCH)                  # geometries per launch of the streaming kernels
-        lps = -(-G // MAX_G_PER_LAUNCH)                # launches per step
+        gl = k5_geometries_per_pass(G, trd.rows_local, trd.cols)   # geometries per K5 launch (K8: <= 32)
+        lps = -(-G // gl)                                          # K5 launches per step
+        gl8, lps8 = min(G, MAX_G_PER_LAUNCH), -(-G // MAX_G_PER_LAUNCH)
         # ALGORITHMIC bytes of one K5 / K8 launch: the local two-body rows + the one-body t-RDM once,
         # plus one h2 (K5) / predicted-RDM (K8) vector per geometry of the launch
         nbytes = trd.rows_local * trd.cols * 8 + T * T * n * n * 8 + gl * (trd.cols * 8 + n * n * 8)
+        nbytes8 = trd.rows_local * trd.cols * 8 + T * T * n * n * 8 + gl8 * (trd.cols * 8 + n * n * 8)
         k5 = rows_ms.value / max(rows_n.value, 1) / lps
-        k8 = cols_ms.value / max(cols_n.value, 1) / lps if cols_n.value else None
+        k8 = cols_ms.value / max(cols_n.value, 1) / lps8 if cols_n.value else None
         # geometries evaluated by the whole job per step: G on every rank (distinct ones unless pair-sharded)
         job_g = G if (sharded_pairs or world == 1 or solo_mode[0]) else G * world
         return {"value": steps * job_g / dt, "ms_per_step": 1e3 * dt / steps, "batch": G, "streams": nslots,
                 "repeat_values": [steps * job_g / x for x in dts],
                 "k5_ms": k5, "k8_ms": k8, "bytes_per_launch": nbytes, "launches": rows_n.value * lps,
                 "geometries_per_launch": gl, "k5_GBs": nbytes / (k5 * 1e-3) / 1e9,
-                "k8_GBs": (nbytes / (k8 * 1e-3) / 1e9) if k8 else None, "last_energy": e_last, "check_energy": e_check,
+                "k8_GBs": (nbytes8 / (k8 * 1e-3) / 1e9) if k8 else None, "last_energy": e_last, "check_energy": e_check,
+                "k5_flops_per_launch": 2.0 * trd.rows_local * trd.cols * gl,
                 "stages": stages, "per_rank": per_rank,
                 "geometries_per_step": job_g}
 
@@ -324,8 +349,10 @@ def main():
         npr = n * (n + 1) // 2
         ao = (npr * npr + 3 * n * n * npr if packed_in else 4 * n ** 4) + (2 + 3 + 3 * A) * n * n + 3 * A
         passes = 1 if a.energy_only else 2
-        launches = -(-geoms // MAX_G_PER_LAUNCH)
-        nbytes = 8.0 * (passes * launches * (rows * cols + T * T * n * n) + geoms * ao + geoms * (3 * A + T))
+        # passes over the resident t-RDMs: K5 (up to 64 geometries each) and, with forces, K8 (up to 32 each)
+        l5 = -(-geoms // k5_geometries_per_pass(geoms, rows, cols))
+        l8 = 0 if a.energy_only else -(-geoms // MAX_G_PER_LAUNCH)
+        nbytes = 8.0 * ((l5 + l8) * (rows * cols + T * T * n * n) + geoms * ao + geoms * (3 * A + T))
         lead = npr if a.layout == "sym8" else n * n
         flops = geoms * (2 if a.energy_only else 4) * lead * 4.0 * n ** 3 + passes * 2.0 * rows * cols * geoms
         t_min = nbytes / (HBM_PEAK_GBS * 1e9) + flops / (MFMA_F64_PEAK_TFLOPS * 1e12)
@@ -539,6 +566,18 @@ def main():
         except Exception as exc:   # a collectives backend that cannot start must not take the headline down
             if rank == 0:
                 out["pair_sharded"] = {"value": None, "error": repr(exc)}
+    if world == 1 and not a.no_md_regime and G == 32 and len(aos_run) >= 64:
+        # twice the geometries per step: K5 then contracts 64 per pass over the t-RDM (four geometry sets,
+        # csrc/gemv_lds.hip) and is bound by its MFMAs instead of the HBM stream; K8 and everything else as before
+        b64 = measure(trd, aos_run, 64, S, max(10, a.steps // 2), max(2, a.warmup // 2), False, repeats=3)
+        if rank == 0:
+            fl = b64["k5_flops_per_launch"]
+            out["batch64"] = {"value": b64["value"], "unit": "geometries/s", "ms_per_step": b64["ms_per_step"],
+                              "repeat_values": b64["repeat_values"], "streams": S,
+                              "k5_geometries_per_launch": b64["geometries_per_launch"],
+                              "k5_rows_ms_contended": b64["k5_ms"], "k5_bytes_per_launch": b64["bytes_per_launch"],
+                              "k5_flops_per_launch": fl,
+                              "note": "the default configuration with 64 geometries per step (never `value`)"}
     if world == 1 and not a.no_md_regime and (G, S) != (1, 1):
         md = measure(trd, aos_run, 1, 1, max(20, min(a.steps * 2, 200)), 10, False)
         if rank == 0:

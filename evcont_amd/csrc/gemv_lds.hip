@@ -518,6 +518,13 @@ static int lds_launch(const GemvRowsLaunch &L, const LdsBlockMap &M, int nblocks
     return 0;
 }
 
+// most geometries one launch takes with the span plan of `p0`: 64 (four sets) with row groups of <= 7 tiles, else 32
+int rows_lds_max_g(const RowProblem &p0, const RowProblem &p1) {
+    static const int max64 = getenv("EVC_ROWS_LDS_G64") ? atoi(getenv("EVC_ROWS_LDS_G64")) : 1;
+    const int ntg = p0.nblocks ? p0.lds_plan : p1.lds_plan;
+    return (max64 && ntg >= 1 && ntg <= 7) ? 64 : 32;
+}
+
 int launch_gemv_rows_lds(const GemvRowsLaunch &Lin, int g0, int G, hipStream_t st) {
     GemvRowsLaunch L = Lin;
     // one kernel shape per launch: the large problem's (the small problem's row groups are dealt for the same shape)
@@ -542,13 +549,19 @@ int launch_gemv_rows_lds(const GemvRowsLaunch &Lin, int g0, int G, hipStream_t s
     LdsBlockMap M;
     lds_block_map(L, nb1, nb0, M);
     int rc = -1;
-#define EVC_LDS_CASE(NT_, NCH_)                                                        \
+    // (four geometry sets, 33 .. 64 geometries per pass: 8 accumulator registers per (set, tile) -- 7 tiles at most --
+    //  and fewer chunks per image, the four vector tiles of a chunk count)
+#define EVC_LDS_CASE(NT_, NCH_, NCH4_)                                                 \
     case NT_:                                                                          \
-        rc = G > 16 ? lds_launch<2, NT_, NCH_>(L, M, nb0 + nb1, g0, G, st)             \
-                    : lds_launch<1, NT_, NCH_>(L, M, nb0 + nb1, g0, G, st);            \
+        if (G > 32) {                                                                  \
+            if constexpr (NT_ <= 7) rc = lds_launch<4, NT_, NCH4_>(L, M, nb0 + nb1, g0, G, st);                 \
+            else { set_error("gemv_rows_lds: %d geometries need <= 7 tiles per row group", G); return -1; }     \
+        } else                                                                         \
+            rc = G > 16 ? lds_launch<2, NT_, NCH_>(L, M, nb0 + nb1, g0, G, st)         \
+                        : lds_launch<1, NT_, NCH_>(L, M, nb0 + nb1, g0, G, st);        \
         break;
     switch (ntg) {
-        EVC_LDS_CASE(14, 1) EVC_LDS_CASE(7, 2) EVC_LDS_CASE(4, 3) EVC_LDS_CASE(2, 4)
+        EVC_LDS_CASE(14, 1, 1) EVC_LDS_CASE(7, 2, 1) EVC_LDS_CASE(4, 3, 2) EVC_LDS_CASE(2, 4, 2)
         default: set_error("gemv_rows_lds: no kernel for %d tiles per row group", ntg); return -1;
     }
 #undef EVC_LDS_CASE

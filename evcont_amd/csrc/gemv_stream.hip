@@ -294,7 +294,13 @@ int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     while (g0 < count) {
         const int left = count - g0;
         if (left >= mfma_min) {
-            const int G = left < mfma_max ? left : mfma_max;
+            // (the LDS-staged kernel takes up to 64 geometries per pass over the matrix; 64 = 2 x 32 leaves the same
+            //  remainder as the grouping rows_groups_all_mfma assumed when the span plan was chosen)
+            int gmax = mfma_max;
+            const bool lds = p0.nblocks ? p0.lds_plan : p1.lds_plan;
+            if (lds && mfma_max == 32 && left > 32 && !(p0.nblocks && p1.nblocks && !p1.lds_plan))
+                gmax = rows_lds_max_g(p0, p1);
+            const int G = left < gmax ? left : gmax;
             int rc = launch_gemv_rows_mfma(L, g0, G, mfma_tiles, st);
             if (rc) return rc;
             g0 += G;

@@ -54,6 +54,7 @@ bool rows_lds_applicable(const RowProblem &p0, const RowProblem &p1);
 void plan_rows_lds(RowProblem &p0, RowProblem &p1);
 int rows_max_spans(const RowProblem &P, bool small);
 int launch_gemv_rows_lds(const GemvRowsLaunch &L, int g0, int G, hipStream_t st);
+int rows_lds_max_g(const RowProblem &p0, const RowProblem &p1);
 bool cols_lds_applicable(const ColProblem &p0, const ColProblem &p1, int G);
 int launch_gemv_cols_lds(const GemvColsLaunch &L, int g0, int G, hipStream_t st);
 bool rows_groups_all_mfma(int count);   // gemv_stream.hip: every group of a batch of `count` runs on the matrix cores

@@ -14,7 +14,9 @@ import torch
 # (N, A, T, G, layout): N = 30 / T = 20 is the benchmark shape; T = 23 -> 276 rows (18 tiles: row groups of 4 + padding),
 # T = 5 -> one ragged tile; G = 44 = one pass of 32 + one of 12; pack2 = the reference's layout (wide matrix)
 SHAPES = [(30, 4, 20, 32, "sym8"), (30, 4, 20, 17, "sym8"), (30, 3, 23, 29, "sym8"), (24, 3, 12, 44, "sym8"),
-          (32, 3, 5, 13, "sym8"), (20, 2, 14, 32, "sym8"), (26, 2, 9, 32, "pack2"), (17, 3, 16, 31, "sym8")]
+          (32, 3, 5, 13, "sym8"), (20, 2, 14, 32, "sym8"), (26, 2, 9, 32, "pack2"), (17, 3, 16, 31, "sym8"),
+          # more than 32 geometries: K5 takes up to 64 per pass (four geometry sets), K8 passes of 32
+          (30, 3, 20, 64, "sym8"), (30, 2, 20, 50, "sym8"), (22, 2, 23, 45, "sym8"), (16, 2, 7, 76, "sym8")]
 
 
 def main(out_path):
