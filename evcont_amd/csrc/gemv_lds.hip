@@ -359,11 +359,7 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = row_base + tt * 16 + l4 + 4 * r;
-#ifdef EVC_K5L_NOSTORE   // timing experiment: the sums are formed, (almost) nothing is stored
-                    if (row < rows && g < G && sum[r] == 1.2345) dst[tt * 16 + 4 * r] = sum[r];
-#else
                     if (row < rows && g < G) dst[tt * 16 + 4 * r] = sum[r];
-#endif
                 }
             }
         }
