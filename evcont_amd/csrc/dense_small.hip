@@ -1302,6 +1302,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         if (a.w1) a.w1 += g * a.sw;
         if (a.w2) a.w2 += g * a.sw;
         if (a.w2t) a.w2t += (g - g % kMaxBatchG) * a.sw;
+        if (a.w1t) a.w1t += (g - g % kMaxBatchG) * a.sw;
         if (a.vstd) a.vstd += g * a.sw;
         if (a.bcache) a.bcache += g * a.sw;
         if (a.e_shift_dev) a.e_shift = a.e_shift_dev[g];
@@ -1536,7 +1537,10 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     if (a.w1)
         for (int idx = tid; idx < T * T; idx += kThreads) {
             const int ia = idx / T;
-            a.w1[idx] = c0[ia] * c0[idx - ia * T];
+            const double w = c0[ia] * c0[idx - ia * T];
+            a.w1[idx] = w;
+            // transposed copy for the batched K8: [row][slot] in the workspace of the group's first geometry
+            if (a.w1t) a.w1t[(int64_t)idx * kMaxBatchG + (int)(blockIdx.x % kMaxBatchG)] = w;
         }
     if (a.w2) {
         for (int64_t r = tid; r < a.w2_count; r += kThreads) {

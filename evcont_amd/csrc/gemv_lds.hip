@@ -731,6 +731,221 @@ __device__ __forceinline__ void cols_lds_body(const ColProblem &P, int g0, int G
     wait_vm<0>();
 }
 
+// Tall matrices (large training sets: more rows than weights fit in LDS): the rows go in SLABS of kSlabRows; a wave owns
+// NTW ADJACENT column tiles (one workgroup round), keeps their accumulators and walks slab by slab, piece by piece, tile by
+// tile -- so it still sums over all rows itself (no partial sums), a piece's weights are read once for all its tiles, and
+// a workgroup's eight waves read 8 NTW x 128 contiguous bytes of every row within a few steps (DRAM pages are reused:
+// tile-by-tile order, each 128-byte piece of a row on its own, streamed a cold 3.4 GB matrix at 4.4 TB/s).
+// The weights of slab s + 1 are fetched by LDS-DMA from the transposed copy `wt` (rows x 32, contiguous) into the second
+// weight buffer while slab s is in work: each wave issues its share at the start of slab s, and the constant vmcnt
+// waits of the piece stream retire them long before the slab ends, so the slab boundary is ONE LDS-only barrier and the
+// ring never drains.  (The one-body problem has no transposed weights: its few workgroups stage a slab with plain
+// loads between two barriers.)  Waves at the end of the matrix run their missing tiles on the last tile (not stored).
+constexpr int kSlabRows = 160;          // 20 pieces; two weight buffers of 40 KB + eight rings of 10 KB = 160 KB
+constexpr int kSlabRing = 10;
+template <int GS, int NTW>
+__device__ __forceinline__ void cols_lds_slab_body(const ColProblem &P, int g0, int G, int blk, int nblk, double *lds,
+                                                   int wave, int lane) {
+    constexpr int NW = 8, D = kSlabRing;
+    constexpr unsigned WB = kSlabRows * 256;   // bytes of one weight buffer
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int rows = (int)P.rows;
+    const int64_t cols = P.cols, ld = P.ld;
+    const int nslab = (rows + kSlabRows - 1) / kSlabRows;
+    const int ntiles = (int)((cols + 15) >> 4);
+    const bool dma_w = P.wt != nullptr;        // workgroup-uniform
+    const int tile0 = (blk * NW + wave) * NTW; // this wave's tiles: tile0 .. tile0 + NTW - 1
+    const bool active = tile0 < ntiles;
+    // pieces of slab s (even: the weights of the padding rows are zero, its loads re-read the matrix's last row)
+    auto slab_pieces = [&](int sidx) {
+        const int left = rows - sidx * kSlabRows;
+        const int np = ((left < kSlabRows ? left : kSlabRows) + 7) >> 3;
+        return (np + 1) & ~1;
+    };
+    const unsigned ring = 2 * WB + (unsigned)(wave * D * 1024);   // LDS byte address of this wave's ring
+    const int prow = lane >> 3, ppos = lane & 7;
+    const char *Ab = reinterpret_cast<const char *>(P.A);
+    const int tail_tile = (int)(ld >> 4) < ntiles && (((int64_t)(ld >> 4) * 16 + 16) > ld) ? (int)(ld >> 4) : -1;
+    const unsigned voff_full = (unsigned)(((int64_t)prow * ld + 2 * ppos) * 8);
+    // weights of slab `sidx` into buffer `buf` by LDS-DMA: instruction k covers rows 4k .. 4k+3 of the slab (1 KB, lane i ->
+    // row 4k + (i >> 4), 16-byte piece i & 15); the piece holds geometries 16 (h ^ (row & 1)) + 2 (i & 7), + 1 with
+    // h = (i >> 3) & 1: the halves of odd rows swapped (the image the fragment reads expect).  Rows beyond the matrix
+    // fetch its last row and are zeroed once the buffer is complete.
+    const double *wtb = dma_w ? P.wt + (int64_t)(g0 - g0 % kMaxBatchG) * P.wstride + g0 % kMaxBatchG : nullptr;
+    auto issue_weights = [&](int sidx, int buf) {
+        const int r00 = sidx * kSlabRows;
+        for (int k = wave; k < kSlabRows / 4; k += NW) {
+            const int rl = 4 * k + (lane >> 4), r = r00 + rl;
+            const int rc = r < rows ? r : rows - 1;
+            const int h = (lane >> 3) & 1;
+            const double *src = wtb + (int64_t)rc * kMaxBatchG + 16 * (h ^ (rl & 1)) + 2 * (lane & 7);
+            glds_v(src, uniform_u32((unsigned)buf * WB + (unsigned)k * 1024));
+        }
+    };
+    // producer cursor: slab, piece, tile (the order the consumer reads in)
+    int pslab = 0, pj = 0, ppiece = 0, pslot = 0, pnp = slab_pieces(0);
+    bool pdone = !active;
+#define EVC_SLAB_PRODUCE()                                                                                       \
+    {                                                                                                            \
+        const int pt_ = tile0 + pj;                                                                              \
+        const int ptile = pt_ < ntiles ? pt_ : ntiles - 1;          /* (a tile the wave does not have) */        \
+        const int r0 = pslab * kSlabRows + 8 * ppiece;              /* first row of the piece */                 \
+        const int rf = r0 < rows ? r0 : rows - 1;                   /* (padding piece: the last row) */          \
+        const int lastv = rows - 1 - rf;                            /* last valid row relative to rf */          \
+        unsigned vo = voff_full;                                    /* (common path: no vector arithmetic) */    \
+        if (lastv < 7 || ptile == tail_tile) {                                                                   \
+            const int rr = prow < lastv ? prow : lastv;                                                          \
+            vo = (unsigned)(((int64_t)rr * ld + 2 * ppos) * 8);                                                  \
+            if (ptile == tail_tile) { /* stay inside the row (ld is even) */                                     \
+                const int over = 2 * ppos - (int)(ld - 2 - (int64_t)ptile * 16);                                 \
+                if (over > 0) vo -= (unsigned)(over * 8);                                                        \
+            }                                                                                                    \
+        }                                                                                                        \
+        glds_s(vo, uniform_ptr(Ab + ((int64_t)rf * ld + (int64_t)ptile * 16) * 8),                               \
+               uniform_u32(ring + (unsigned)pslot * 1024));                                                      \
+        pslot = pslot + 1 == D ? 0 : pslot + 1;                                                                  \
+        if (++pj == NTW) {                                                                                       \
+            pj = 0;                                                                                              \
+            if (++ppiece == pnp) {                                                                               \
+                ppiece = 0;                                                                                      \
+                if (++pslab == nslab) pdone = true;                                                              \
+                else pnp = slab_pieces(pslab);                                                                   \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+    if (dma_w) issue_weights(0, 0);
+#pragma unroll 1
+    for (int i = 0; i < D - 1; ++i) {
+        if (!pdone) EVC_SLAB_PRODUCE()
+        else {   // (fewer pieces than ring slots: keep the in-order count with re-reads of the last row)
+            glds_s((unsigned)(2 * ppos * 8), uniform_ptr(Ab + (int64_t)(rows - 1) * ld * 8),
+                   uniform_u32(ring + (unsigned)pslot * 1024));
+            pslot = pslot + 1 == D ? 0 : pslot + 1;
+        }
+    }
+    const unsigned xlane = (unsigned)(l4 * 128 + l15 * 8);
+    unsigned wl0[GS];
+#pragma unroll
+    for (int gs = 0; gs < GS; ++gs) wl0[gs] = (unsigned)(l4 * 256 + (((gs ^ (l4 & 1)) & 1) << 7) + l15 * 8);
+    const char *ldsb = reinterpret_cast<const char *>(lds);
+    int cslot = 0;
+    d4 acc[NTW][GS];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int gs = 0; gs < GS; ++gs) acc[j][gs] = (d4){0.0, 0.0, 0.0, 0.0};
+    double x[2][NTW][2];   // [piece parity][tile][K step]
+    double wf[2][2][GS];   // [piece parity][K step][geometry set]
+// position (piece parity Q_, tile J_): wait for its piece, read the matrix fragments (and, at the first tile, the piece's
+// weights), first half of the MFMAs of the position before (PQ_, PJ_), refill, second half
+#define EVC_SLAB_STEP(Q_, J_, PIECE_, PQ_, PJ_, MMA_)                                                        \
+    {                                                                                                        \
+        if (pdone) wait_vm<0>();                                                                             \
+        else wait_vm<D - 2>();                                                                               \
+        {                                                                                                    \
+            const char *xp = ldsb + ring + (unsigned)cslot * 1024 + xlane;                                   \
+            x[Q_][J_][0] = *reinterpret_cast<const double *>(xp);                                            \
+            x[Q_][J_][1] = *reinterpret_cast<const double *>(xp + 512);                                      \
+            if ((J_) == 0) {                                                                                 \
+                _Pragma("unroll") for (int gs = 0; gs < GS; ++gs) {                                          \
+                    const char *wp = ldsb + wbuf + (unsigned)(PIECE_) * 2048 + wl0[gs];                      \
+                    wf[Q_][0][gs] = *reinterpret_cast<const double *>(wp);                                   \
+                    wf[Q_][1][gs] = *reinterpret_cast<const double *>(wp + 1024);                            \
+                }                                                                                            \
+            }                                                                                                \
+            cslot = cslot + 1 == D ? 0 : cslot + 1;                                                          \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (MMA_) {                                                                                          \
+            _Pragma("unroll") for (int gs = 0; gs < GS; ++gs)                                                \
+                acc[PJ_][gs] = mfma64(wf[PQ_][0][gs], x[PQ_][PJ_][0], acc[PJ_][gs]);                         \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        wait_lds();                                                                                          \
+        if (!pdone) EVC_SLAB_PRODUCE()                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (MMA_) {                                                                                          \
+            _Pragma("unroll") for (int gs = 0; gs < GS; ++gs)                                                \
+                acc[PJ_][gs] = mfma64(wf[PQ_][1][gs], x[PQ_][PJ_][1], acc[PJ_][gs]);                         \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+    for (int sidx = 0; sidx < nslab; ++sidx) {
+        const unsigned wbuf = dma_w ? (unsigned)(sidx & 1) * WB : 0u;
+        const int r00 = sidx * kSlabRows;
+        if (dma_w) {
+            // every DMA of this slab's weights (issued a slab ago, or in the prologue) has been retired by the piece
+            // waits since; a wave that had no pieces to wait for waits here
+            if (sidx == 0 || !active || pdone) wait_vm<0>();
+            lds_barrier();   // ... by EVERY wave: the buffer is complete; and nobody reads the other buffer any more
+            // rows of the slab beyond the matrix: zero weights (they were fetched from the last row)
+            if (r00 + kSlabRows > rows) {
+                const int first = rows > r00 ? rows - r00 : 0;
+                for (int idx = threadIdx.x; idx < (kSlabRows - first) * 32; idx += 64 * NW)
+                    lds[wbuf / 8 + (first + (idx >> 5)) * 32 + (idx & 31)] = 0.0;
+                lds_barrier();
+            }
+            if (sidx + 1 < nslab) issue_weights(sidx + 1, (sidx + 1) & 1);
+        } else {
+            __syncthreads();   // every wave has read the last weights of the slab before
+            for (int idx = threadIdx.x; idx < kSlabRows * 32; idx += 64 * NW) {
+                const int rl = idx >> 5, sl = idx & 31, r = r00 + rl;
+                double v = 0.0;
+                if (r < rows && sl < G && sl < 16 * GS) v = P.w[(int64_t)(g0 + sl) * P.wstride + r];
+                lds[rl * 32 + ((((sl >> 4) ^ (rl & 1)) & 1) << 4) + (sl & 15)] = v;
+            }
+            __syncthreads();
+        }
+        if (active) {
+            const int H = slab_pieces(sidx) >> 1;
+            for (int it = 0; it < H; ++it) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {   // piece 2 it; the position before: (piece 2 it - 1, last tile) or (this, j - 1)
+                    if (j == 0) EVC_SLAB_STEP(0, 0, 2 * it, 1, NTW - 1, it > 0)
+                    else EVC_SLAB_STEP(0, j, 2 * it, 0, (j > 0 ? j - 1 : 0), true)
+                }
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {   // piece 2 it + 1
+                    if (j == 0) EVC_SLAB_STEP(1, 0, 2 * it + 1, 0, NTW - 1, true)
+                    else EVC_SLAB_STEP(1, j, 2 * it + 1, 1, (j > 0 ? j - 1 : 0), true)
+                }
+            }
+            // the last position of the slab (its fragments are in registers: the next slab's weights do not matter)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int gs = 0; gs < GS; ++gs)
+                    acc[NTW - 1][gs] = mfma64(wf[1][k][gs], x[1][NTW - 1][k], acc[NTW - 1][gs]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int64_t c = (int64_t)(tile0 + j) * 16 + l15;
+        if (active && tile0 + j < ntiles && c < cols) {
+#pragma unroll
+            for (int gs = 0; gs < GS; ++gs)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = 16 * gs + l4 + 4 * r;
+                    if (g < G) P.out[(int64_t)(g0 + g) * P.ostride + c] = acc[j][gs][r];
+                }
+        }
+    }
+#undef EVC_SLAB_STEP
+#undef EVC_SLAB_PRODUCE
+    wait_vm<0>();
+}
+
+template <int GS, int NTW>
+__global__ __launch_bounds__(512, 1) void gemv_cols_lds_slab_kernel(GemvColsLaunch L, int nblk1, int g0, int G) {
+    extern __shared__ __align__(16) double lds_cols_slab[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // the few blocks of the small second problem are dispatched first
+    if ((int)blockIdx.x < nblk1) cols_lds_slab_body<GS, 1>(L.p[1], g0, G, blockIdx.x, nblk1, lds_cols_slab, wave, lane);
+    else cols_lds_slab_body<GS, NTW>(L.p[0], g0, G, blockIdx.x - nblk1, gridDim.x - nblk1, lds_cols_slab, wave, lane);
+}
+
 template <int GS, int D0, int D1, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void gemv_cols_lds_kernel(GemvColsLaunch L, int nblk1, int g0, int G) {
     extern __shared__ __align__(16) double lds_cols[];
@@ -753,17 +968,27 @@ static int cols_lds_waves() {
     return nw;
 }
 
-bool cols_lds_applicable(const ColProblem &p0, const ColProblem &p1, int G) {
+// 0: not applicable; 1: both problems in one launch of gemv_cols_lds_kernel (the weights of all rows fit LDS); 2: tall
+// matrix, both problems in one launch of gemv_cols_lds_slab_kernel
+int cols_lds_mode(const ColProblem &p0, const ColProblem &p1, int G) {
     static const bool on = !(getenv("EVC_COLS_LDS") && atoi(getenv("EVC_COLS_LDS")) == 0);
+    static const bool slab_on = !(getenv("EVC_COLS_LDS_SLAB") && atoi(getenv("EVC_COLS_LDS_SLAB")) == 0);
     static const int64_t min_cols = getenv("EVC_ROWS_LDS_MINCOLS") ? atoll(getenv("EVC_ROWS_LDS_MINCOLS")) : 4096;
-    if (!on || p0.cols < min_cols || p0.rows <= 0 || !aligned16(p0.A) || p0.ld % 2 || p0.rows > (1 << 20)) return false;
-    if (16 * p0.ld * 8 >= ((int64_t)1 << 31) || 16 * p1.ld * 8 >= ((int64_t)1 << 31)) return false;
+    if (!on || p0.cols < min_cols || p0.rows <= 0 || !aligned16(p0.A) || p0.ld % 2 || p0.rows > (1 << 20)) return 0;
+    if (16 * p0.ld * 8 >= ((int64_t)1 << 31) || 16 * p1.ld * 8 >= ((int64_t)1 << 31)) return 0;
     // one set of geometries (G <= 16): the row-split kernel of gemv_mfma.hip is faster (31.8 against 36.1 us at H30)
-    if (G <= 16) return false;
+    if (G <= 16) return 0;
     const int nw = cols_lds_waves();
-    if (cols_lds_depth(p0.rows, nw) < 12) return false;
-    if (p1.cols > 0 && (cols_lds_depth(p1.rows, nw) < 6 || !aligned16(p1.A) || p1.ld % 2 || p1.part)) return false;
-    return true;
+    if (cols_lds_depth(p0.rows, nw) >= 12) {
+        if (p1.cols > 0 && (cols_lds_depth(p1.rows, nw) < 6 || !aligned16(p1.A) || p1.ld % 2 || p1.part)) return 0;
+        return 1;
+    }
+    // slab kernel: every wave's tiles in one round of <= 4, transposed weights for the LDS-DMA staging, a small second
+    // problem (<= 128 tiles: one per wave of <= 16 workgroups)
+    if (!slab_on || !p0.wt || !aligned16(p0.wt)) return 0;
+    if (ceil_div(ceil_div(p0.cols, 16), (int64_t)8 * kLdsBlocks) > 4) return 0;
+    if (p1.cols > 0 && (p1.cols > 2048 || !aligned16(p1.A) || p1.ld % 2)) return 0;
+    return 2;
 }
 
 template <int GS, int D0, int D1, int NW>
@@ -801,6 +1026,30 @@ int launch_gemv_cols_lds(const GemvColsLaunch &L, int g0, int G, hipStream_t st)
     if (rc == -1) set_error("gemv_cols_lds: no kernel for ring depths %d / %d, %d waves", d0, d1, nw);
     if (rc) return rc;
     EVC_LAUNCH_CHECK("gemv_cols_lds");
+    return 0;
+}
+
+int launch_gemv_cols_lds_slab(const GemvColsLaunch &L, int g0, int G, hipStream_t st) {
+    const int64_t ntiles = ceil_div(L.p[0].cols, 16);
+    const int64_t rounds = ceil_div(ntiles, (int64_t)8 * kLdsBlocks);
+    const int nblk0 = (int)ceil_div(ntiles, 8 * rounds);
+    const int nblk1 = L.p[1].cols > 0 ? (int)ceil_div(ceil_div(L.p[1].cols, 16), 8) : 0;
+    const size_t lds = (size_t)2 * kSlabRows * 256 + (size_t)8 * kSlabRing * 1024;
+    int rc = -1;
+#define EVC_SLAB_CASE(NTW_)                                                                                   \
+    if (rounds == NTW_) {                                                                                    \
+        static LdsAttr attr;                                                                                 \
+        if ((rc = allow_dynamic_lds(gemv_cols_lds_slab_kernel<2, NTW_>, attr, 160 * 1024, "gemv_cols_lds_slab"))) \
+            return rc;                                                                                       \
+        hipLaunchKernelGGL((gemv_cols_lds_slab_kernel<2, NTW_>), dim3(nblk0 + nblk1), dim3(512), lds, st, L, nblk1, g0, G); \
+    }
+    EVC_SLAB_CASE(1) EVC_SLAB_CASE(2) EVC_SLAB_CASE(3) EVC_SLAB_CASE(4)
+#undef EVC_SLAB_CASE
+    if (rc == -1) {
+        set_error("gemv_cols_lds_slab: no kernel for %lld rounds", (long long)rounds);
+        return -1;
+    }
+    EVC_LAUNCH_CHECK("gemv_cols_lds_slab");
     return 0;
 }
 

@@ -545,7 +545,9 @@ static int cols_mfma_launch(GemvColsLaunch L, int g0, int G, hipStream_t st) {
 int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
     if (L.p[0].cols + L.p[1].cols == 0) return 0;
     // whole-line LDS-DMA pieces, a wave sums over all rows of its column tiles (gemv_lds.hip)
-    if (cols_lds_applicable(L.p[0], L.p[1], G)) return launch_gemv_cols_lds(L, g0, G, st);
+    const int lds_mode = cols_lds_mode(L.p[0], L.p[1], G);
+    if (lds_mode == 1) return launch_gemv_cols_lds(L, g0, G, st);
+    if (lds_mode == 2 && g0 % kMaxBatchG == 0) return launch_gemv_cols_lds_slab(L, g0, G, st);
     // shape code = 100*CT + 10*KSN + MINW (EVC_COLS_SHAPE / EVC_COLS_SHAPE2 for one / two geometry sets)
     // Measured in situ at H30/T=20 (us per launch): lean shapes with many waves per SIMD win by a wide margin
     // over wide register-blocked ones — G=16: 126 -> 138, 224 -> 147, 343 (the first design) -> 193;

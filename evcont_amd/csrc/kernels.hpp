@@ -55,8 +55,9 @@ void plan_rows_lds(RowProblem &p0, RowProblem &p1);
 int rows_max_spans(const RowProblem &P, bool small);
 int launch_gemv_rows_lds(const GemvRowsLaunch &L, int g0, int G, hipStream_t st);
 int rows_lds_max_g(const RowProblem &p0, const RowProblem &p1);
-bool cols_lds_applicable(const ColProblem &p0, const ColProblem &p1, int G);
+int cols_lds_mode(const ColProblem &p0, const ColProblem &p1, int G);
 int launch_gemv_cols_lds(const GemvColsLaunch &L, int g0, int G, hipStream_t st);
+int launch_gemv_cols_lds_slab(const GemvColsLaunch &L, int g0, int G, hipStream_t st);
 bool rows_groups_all_mfma(int count);   // gemv_stream.hip: every group of a batch of `count` runs on the matrix cores
 size_t rows_ws_doubles(int64_t rows, int64_t cols);
 // `count` geometries; launched in groups of up to kMaxBatchG that share one read of A.
@@ -179,6 +180,7 @@ struct SolveArgs {
     double *w2, *w1;               // + g*sw
     double *w2t;                   // (w2_count, kMaxBatchG) or NULL: w2 of the geometries of a group of kMaxBatchG,
                                    // transposed, in the workspace of the group's first geometry (+ (g - g%32)*sw)
+    double *w1t;                   // (T*T, kMaxBatchG) or NULL: the same for w1
     int64_t sh1, sh2, sev, svec, sH, sw;
     int64_t w2_offset, w2_count;  // slice of the global weight vector to write (multi-GPU)
     double *vstd;                 // (m,m), m = T rounded up to even: standard-form eigenvectors, kept in the

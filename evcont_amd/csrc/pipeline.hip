@@ -77,7 +77,7 @@ struct Ws {
     double *B1, *B2, *K3, *G;
     double *vec2;  // ld2-long vector: packed h2 (phase A) / packed predicted 2-RDM (phase C)
     // t-RDM contraction
-    double *h2part, *h1part, *h2rows, *w2, *w1, *w2t;
+    double *h2part, *h1part, *h2rows, *w2, *w1, *w2t, *w1t;
     double *d1part;   // row-slab partials of the predicted 1-RDM (large training sets: gemv_cols_slab_kernel)
     // gradient partials
     double *y2part, *y2, *t2part, *term3;
@@ -185,6 +185,7 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.w2 = take((size_t)t->rows2 + 1);
     w.w2t = take((size_t)t->rows2 * kMaxBatchG + 1);
     w.w1 = take(T * T);
+    w.w1t = take((size_t)T * T * kMaxBatchG);
     w.d1part = take(T * T >= 1024 ? (size_t)kColSlabs * t->ld1 : 0);
     w.y2part = take((size_t)y2_slab_capacity((int)n) * n2);
     w.y2 = take(n2);
@@ -414,6 +415,7 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
     a.sH = out.sH;
     a.w2 = w.w2;
     a.w2t = g.count > 1 ? w.w2t : nullptr;
+    a.w1t = g.count > 1 ? w.w1t : nullptr;
     a.w1 = w.w1;
     a.sw = sw;
     a.w2_offset = t->row_offset;
@@ -655,6 +657,7 @@ static int phase_gradient(const evc_trdm_set *t, const Geo &g_in, const Out &out
     }
     c1.A = t->one_rdm;
     c1.w = w.w1;
+    c1.wt = cnt > 1 ? w.w1t : nullptr;
     c1.wstride = sw;
     c1.rows = (int64_t)t->ntrain * t->ntrain;
     c1.cols = (int64_t)n * n;

@@ -16,7 +16,9 @@ import torch
 SHAPES = [(30, 4, 20, 32, "sym8"), (30, 4, 20, 17, "sym8"), (30, 3, 23, 29, "sym8"), (24, 3, 12, 44, "sym8"),
           (32, 3, 5, 13, "sym8"), (20, 2, 14, 32, "sym8"), (26, 2, 9, 32, "pack2"), (17, 3, 16, 31, "sym8"),
           # more than 32 geometries: K5 takes up to 64 per pass (four geometry sets), K8 passes of 32
-          (30, 3, 20, 64, "sym8"), (30, 2, 20, 50, "sym8"), (22, 2, 23, 45, "sym8"), (16, 2, 7, 76, "sym8")]
+          (30, 3, 20, 64, "sym8"), (30, 2, 20, 50, "sym8"), (22, 2, 23, 45, "sym8"), (16, 2, 7, 76, "sym8"),
+          # tall matrices (more rows than weights fit in LDS): K8 in row slabs with LDS-DMA-staged weights
+          (16, 2, 40, 32, "sym8"), (18, 2, 48, 17, "sym8")]
 
 
 def main(out_path):
