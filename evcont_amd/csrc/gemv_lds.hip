@@ -448,24 +448,33 @@ bool rows_lds_applicable(const RowProblem &p0, const RowProblem &p1) {
 // (T^2 rows: large training sets) keeps its own launch of the fragment-shaped kernel (plan_rows)
 static bool lds_small_rides(const RowProblem &p1) { return lds_row_groups(p1.rows, 14) <= kLdsBlocksSmall; }
 
-// Both problems run in ONE launch, i.e. in one kernel shape (the large problem's); together they fill one round.
+// Both problems run in ONE launch, i.e. in one kernel shape (the large problem's); together they fill one round.  A tall
+// second problem (T^2 rows: large training sets) gets a launch of its own -- of this kernel too if its row groups leave
+// room for a few spans, else of the fragment-shaped kernel (plan_rows).
+static bool lds_tall_alone(const RowProblem &p1) {
+    return p1.cols >= 4 * kLW && lds_row_groups(p1.rows, 14) <= (kLdsBlocks + kLdsBlocksSmall) / 4;
+}
 void plan_rows_lds(RowProblem &p0, RowProblem &p1) {
     const int ntg = lds_pick_nt(p0.rows);
     if (lds_small_rides(p1)) plan_one_lds(p1, kLdsBlocksSmall, ntg);
-    else {
+    else if (lds_tall_alone(p1)) {
+        plan_one_lds(p1, kLdsBlocks + kLdsBlocksSmall, 14);
+        p1.lds_plan = -14;   // (< 0: planned for a launch of its own)
+    } else {
         plan_rows(p1, true);
         p1.lds_plan = 0;
     }
-    plan_one_lds(p0, kLdsBlocks + kLdsBlocksSmall - (p1.lds_plan ? p1.nblocks : 0), ntg);
+    plan_one_lds(p0, kLdsBlocks + kLdsBlocksSmall - (p1.lds_plan > 0 ? p1.nblocks : 0), ntg);
 }
 
 // most spans any plan makes of this problem (the partial buffers are carved for it)
 int rows_max_spans(const RowProblem &P, bool small) {
     RowProblem a = P, b = P;
     plan_rows(a, true);
-    // (the 14-tile shape has the fewest row groups, hence the most spans)
+    // (the 14-tile shape has the fewest row groups, hence the most spans; a tall small problem is planned for a whole
+    //  round of its own)
     const int nrg = lds_row_groups(P.rows, 14);
-    int spans = (small ? kLdsBlocksSmall : kLdsBlocks + kLdsBlocksSmall) / nrg;
+    int spans = (small && nrg <= kLdsBlocksSmall ? kLdsBlocksSmall : kLdsBlocks + kLdsBlocksSmall) / nrg;
     if (spans < 1) spans = 1;
     const int64_t chunks = ceil_div(P.cols > 0 ? P.cols : 1, kLW);
     const int64_t m = ceil_div(chunks, 4 * (int64_t)spans);

@@ -276,13 +276,21 @@ __global__ __launch_bounds__(256, MINW) void gemv_rows_mfma_pipe_kernel(GemvRows
 int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, hipStream_t st) {
     // spans planned for the LDS-staged kernel (gemv_lds.hip: whole-line LDS-DMA instead of fragment-shaped loads)
     if (Lin.p[0].nblocks ? Lin.p[0].lds_plan : Lin.p[1].lds_plan) {
-        if (Lin.p[0].nblocks && Lin.p[1].nblocks && !Lin.p[1].lds_plan) {
-            // a tall second problem (large training sets: T^2 rows) keeps the fragment-shaped kernel, in its own launch
+        if (Lin.p[0].nblocks && Lin.p[1].nblocks && Lin.p[1].lds_plan <= 0) {
+            // a tall second problem (large training sets: T^2 rows) in its own launch: of the LDS-staged kernel as the
+            // only problem (plan < 0), else of the fragment-shaped kernel
             GemvRowsLaunch La = Lin, Lb = Lin;
             La.p[1].nblocks = 0;
+            if (int rc = launch_gemv_rows_lds(La, g0, G, st)) return rc;
+            if (Lin.p[1].lds_plan < 0 && G <= 32) {
+                Lb.p[0] = Lin.p[1];
+                Lb.p[0].lds_plan = -Lin.p[1].lds_plan;
+                Lb.p[1].nblocks = 0;
+                return launch_gemv_rows_lds(Lb, g0, G, st);
+            }
             Lb.p[0].nblocks = 0;
             Lb.p[0].lds_plan = 0;
-            if (int rc = launch_gemv_rows_lds(La, g0, G, st)) return rc;
+            Lb.p[1].lds_plan = 0;
             return launch_gemv_rows_mfma(Lb, g0, G, tiles, st);
         }
         return launch_gemv_rows_lds(Lin, g0, G, st);

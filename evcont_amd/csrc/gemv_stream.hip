@@ -298,7 +298,7 @@ int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
             //  remainder as the grouping rows_groups_all_mfma assumed when the span plan was chosen)
             int gmax = mfma_max;
             const bool lds = p0.nblocks ? p0.lds_plan : p1.lds_plan;
-            if (lds && mfma_max == 32 && left > 32 && !(p0.nblocks && p1.nblocks && !p1.lds_plan))
+            if (lds && mfma_max == 32 && left > 32 && !(p0.nblocks && p1.nblocks && p1.lds_plan <= 0))
                 gmax = rows_lds_max_g(p0, p1);
             const int G = left < gmax ? left : gmax;
             int rc = launch_gemv_rows_mfma(L, g0, G, mfma_tiles, st);
