@@ -354,12 +354,20 @@ def main():
         l8 = 0 if a.energy_only else -(-geoms // MAX_G_PER_LAUNCH)
         nbytes = 8.0 * ((l5 + l8) * (rows * cols + T * T * n * n) + geoms * ao + geoms * (3 * A + T))
         lead = npr if a.layout == "sym8" else n * n
-        flops = geoms * (2 if a.energy_only else 4) * lead * 4.0 * n ** 3 + passes * 2.0 * rows * cols * geoms
-        t_min = nbytes / (HBM_PEAK_GBS * 1e9) + flops / (MFMA_F64_PEAK_TFLOPS * 1e12)
+        flops_rot = geoms * (2 if a.energy_only else 4) * lead * 4.0 * n ** 3
+        flops_con = passes * 2.0 * rows * cols * geoms
+        flops = flops_rot + flops_con
+        # the two contractions stream the t-RDMs AND multiply them on the matrix cores in the same kernels: each is
+        # bounded by the larger of its two rooflines, not by their sum; everything else: bytes at the HBM peak plus the
+        # rotations' flops at the MFMA peak
+        bytes_con = 8.0 * (l5 + l8) * (rows * cols + T * T * n * n)
+        t_con = max(bytes_con / (HBM_PEAK_GBS * 1e9), flops_con / (MFMA_F64_PEAK_TFLOPS * 1e12))
+        t_min = t_con + (nbytes - bytes_con) / (HBM_PEAK_GBS * 1e9) + flops_rot / (MFMA_F64_PEAK_TFLOPS * 1e12)
         return {"frac": t_min / (ms_per_step * 1e-3), "bytes_per_step": nbytes, "flops_per_step": flops,
                 "ms_at_peaks": t_min * 1e3, "ms_per_step": ms_per_step,
-                "note": "bytes / 8 TB/s + flops / 78.6 TFLOP/s over the measured step (per GPU); FP64 MFMA reaches "
-                        "77 TFLOP/s with ArchVGPR accumulators (profiles/mfma_f64_regclass.txt)"}
+                "note": "max(t-RDM bytes / 8 TB/s, contraction flops / 78.6 TFLOP/s) for the two batched contractions "
+                        "+ all other bytes / 8 TB/s + rotation flops / 78.6 TFLOP/s, over the measured step (per GPU); "
+                        "FP64 MFMA reaches 77 TFLOP/s with ArchVGPR accumulators (profiles/mfma_f64_regclass.txt)"}
 
     G, S = max(1, a.batch), max(1, a.streams)
     pairs_first = world > 1 and a.shard == "pairs"
