@@ -19,6 +19,7 @@ print("$tag:", "; ".join(out), "value", v)
 PY
   rm -rf $R/gpurun_out/kst
 }
+if [ -n "$SLABAB" ]; then one SLAB EVC_COLS_LDS_SLAB=1; one NOSLAB EVC_COLS_LDS_SLAB=0; one SLAB EVC_COLS_LDS_SLAB=1; one NOSLAB EVC_COLS_LDS_SLAB=0; exit 0; fi
 if [ -n "$NTS" ]; then for nt in $NTS; do one NT=$nt EVC_ROWS_LDS_NT=$nt; done; exit 0; fi
 one NEW EVC_ROWS_LDS=1 EVC_COLS_LDS=1 EVC_IP1_LDS=1
 one OLD EVC_ROWS_LDS=0 EVC_COLS_LDS=0 EVC_IP1_LDS=0
