@@ -972,10 +972,9 @@ static int cols_lds_depth(int64_t rows, int nw) {
     const int64_t d = (160 * 1024 - rows_w * 256) / (nw * 1024);
     return d >= 24 ? 24 : (d >= 12 ? 12 : (d >= 6 ? 6 : 0));
 }
-static int cols_lds_waves() {
-    static const int nw = getenv("EVC_COLS_LDS_NW") && atoi(getenv("EVC_COLS_LDS_NW")) == 4 ? 4 : 8;
-    return nw;
-}
+// eight waves per workgroup (two per SIMD): with one wave per SIMD and rings of 24 the loop was bound by its own
+// scalar instructions (54 us against 43 at H30; removed)
+static int cols_lds_waves() { return 8; }
 
 // 0: not applicable; 1: both problems in one launch of gemv_cols_lds_kernel (the weights of all rows fit LDS); 2: tall
 // matrix, both problems in one launch of gemv_cols_lds_slab_kernel
@@ -1029,7 +1028,6 @@ int launch_gemv_cols_lds(const GemvColsLaunch &L, int g0, int G, hipStream_t st)
     if ((G > 16 ? 2 : 1) == GS_ && d0 == D0_ && d1 == D1_ && nw == NW_)                              \
         rc = cols_lds_launch<GS_, D0_, D1_, NW_>(L, nblk1, nblk0, lds, g0, G, st);
     // (two geometry sets only: one set stays with the row-split kernel, cols_lds_applicable)
-    EVC_CL_CASE(2, 24, 12, 4) EVC_CL_CASE(2, 12, 12, 4) EVC_CL_CASE(2, 24, 6, 4) EVC_CL_CASE(2, 12, 6, 4)
     EVC_CL_CASE(2, 12, 12, 8) EVC_CL_CASE(2, 12, 6, 8)
 #undef EVC_CL_CASE
     if (rc == -1) set_error("gemv_cols_lds: no kernel for ring depths %d / %d, %d waves", d0, d1, nw);

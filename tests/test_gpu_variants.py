@@ -35,13 +35,12 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
     {"EVC_ROWS_LDS_MINCOLS": "1", "EVC_ROWS_LDS_NT": "4"},
     {"EVC_ROWS_LDS_MINCOLS": "1", "EVC_ROWS_LDS_NT": "2"},
     {"EVC_COLS_LDS": "0"},                    # batched K8 by the row-split / column-tiled kernels of gemv_mfma.hip
-    {"EVC_ROWS_LDS_MINCOLS": "1", "EVC_COLS_LDS_NW": "4"},   # LDS-staged K8 with four waves per workgroup (ring of 24)
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_variant_passes_parity_subset(env):
     e = dict(os.environ)
     e.update(env)
     subset = LARGE_T if "EVC_SUBSPACE_FEW" in env else SUBSET
-    if "EVC_ROWS_LDS_NT" in env or "EVC_ROWS_LDS" in env or "EVC_COLS_LDS" in env or "EVC_COLS_LDS_NW" in env:   # (the kernels behind these knobs: batches of >= 12)
+    if "EVC_ROWS_LDS_NT" in env or "EVC_ROWS_LDS" in env or "EVC_COLS_LDS" in env:   # (the kernels behind these knobs: batches of >= 12)
         subset = ["tests/test_gpu_bench_config.py::test_k5_every_row_group_body",
                   "tests/test_gpu_bench_config.py::test_k5_row_groups_wide_matrix", "tests/test_gpu_sym8.py::test_sym8_batched"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + subset,
