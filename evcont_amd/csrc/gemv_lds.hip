@@ -372,9 +372,25 @@ __global__ __launch_bounds__(256, 1) void gemv_rows_lds_kernel(GemvRowsLaunch L,
 constexpr int kLdsBlocks = 242;     // workgroups of the large problem: one per CU (the images fill the LDS), one round
 constexpr int kLdsBlocksSmall = 8;  // ... of the small (one-body) problem
 
+// These kernels put ONE workgroup on a CU (their LDS images fill it) and size their grids for a whole MI355X: a device
+// (or partition) with fewer CUs than blocks would run them in several rounds -- there the kernels of gemv_mfma.hip stay.
+static bool lds_device_fits() {
+    static std::atomic<uint64_t> known{0}, fits{0};   // bit d: device d examined / large enough
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const uint64_t bit = (uint64_t)1 << dev;
+    if (!(known.load(std::memory_order_acquire) & bit)) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        if (cus >= kLdsBlocks + kLdsBlocksSmall) fits.fetch_or(bit, std::memory_order_release);
+        known.fetch_or(bit, std::memory_order_release);
+    }
+    return (fits.load(std::memory_order_acquire) & bit) != 0;
+}
+
 static bool rows_lds_enabled() {
     static const bool on = !(getenv("EVC_ROWS_LDS") && atoi(getenv("EVC_ROWS_LDS")) == 0);
-    return on;
+    return on && lds_device_fits();
 }
 
 // Kernel shapes (tiles per row group, chunks per image): every shape keeps 16-18 tiles = 32-36 KB in flight per wave.
@@ -982,7 +998,9 @@ int cols_lds_mode(const ColProblem &p0, const ColProblem &p1, int G) {
     static const bool on = !(getenv("EVC_COLS_LDS") && atoi(getenv("EVC_COLS_LDS")) == 0);
     static const bool slab_on = !(getenv("EVC_COLS_LDS_SLAB") && atoi(getenv("EVC_COLS_LDS_SLAB")) == 0);
     static const int64_t min_cols = getenv("EVC_ROWS_LDS_MINCOLS") ? atoll(getenv("EVC_ROWS_LDS_MINCOLS")) : 4096;
-    if (!on || p0.cols < min_cols || p0.rows <= 0 || !aligned16(p0.A) || p0.ld % 2 || p0.rows > (1 << 20)) return 0;
+    if (!on || !lds_device_fits() || p0.cols < min_cols || p0.rows <= 0 || !aligned16(p0.A) || p0.ld % 2 ||
+        p0.rows > (1 << 20))
+        return 0;
     if (16 * p0.ld * 8 >= ((int64_t)1 << 31) || 16 * p1.ld * 8 >= ((int64_t)1 << 31)) return 0;
     // one set of geometries (G <= 16): the row-split kernel of gemv_mfma.hip is faster (31.8 against 36.1 us at H30)
     if (G <= 16) return 0;
