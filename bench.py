@@ -183,6 +183,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         a.gpus = world
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a five-line version
+    # banner when its first communicator comes up): file descriptor 1 is pointed at stderr for the whole run and the
+    # JSON line goes to the saved descriptor of the real stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # EVC_BENCH_BACKEND=gloo lets several ranks share one card (rehearsal on a one-GPU box); RCCL needs a card per rank
     backend = os.environ.get("EVC_BENCH_BACKEND", "nccl")
@@ -691,7 +697,8 @@ def main():
         if not a.no_cpu_baseline and world == 1 and not a.energy_only:
             samples = a.cpu_samples or (2 if a.workload == "Zundel100" else 8 if a.workload in ("H30", "Zundel") else 50)
             out["cpu_baseline"] = cpu_baseline(a.workload, nd_cpu, trd, aos, samples)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
     if dist.is_initialized():
