@@ -59,12 +59,16 @@ def _block_size(a: np.ndarray) -> int:
 
 
 def _block_sum(a: np.ndarray, blk: int) -> float:
-    """Sum of block `blk` (elements [blk*bs, (blk+1)*bs) in C order)."""
+    """Sum of block `blk` (elements [blk*bs, (blk+1)*bs) in C order), by the SAME routine as `_all_block_sums`
+    (`np.add.reduceat` adds in sequence, `np.sum` pairwise: the two differ in the last bits for most blocks, and a
+    checksum compared with `!=` must be reproduced bit for bit)."""
     bs = _block_size(a)
     lo, hi = blk * bs, min(a.size, (blk + 1) * bs)
     if a.flags.c_contiguous:
-        return float(np.sum(a.reshape(-1)[lo:hi], dtype=np.float64))
-    return float(np.sum(a[np.unravel_index(np.arange(lo, hi), a.shape)], dtype=np.float64))
+        seg = a.reshape(-1)[lo:hi]
+    else:
+        seg = a[np.unravel_index(np.arange(lo, hi), a.shape)]
+    return float(np.add.reduceat(seg, [0], dtype=np.float64)[0])
 
 
 def _all_block_sums(a: np.ndarray) -> np.ndarray:

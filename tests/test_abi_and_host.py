@@ -134,6 +134,29 @@ def test_cache_fingerprint():
     cache.clear()
 
 
+def test_cache_repeated_gets_on_unchanged_arrays_all_hit():
+    """Stored and spot-checked block sums come from one routine: ten reuses of an unchanged large entry all hit
+    (with np.sum against np.add.reduceat about 80 % of the blocks differed in the last bits and every third
+    get_energy_with_grad call dropped the resident training set)."""
+    from evcont_amd import cache
+    cache.clear()
+    rng = np.random.default_rng(11)
+    one = rng.standard_normal((20, 20, 30, 30))
+    two = rng.standard_normal((210, 108345))
+    S = np.eye(20)
+    k = cache.key_of(one, two, S)
+    cache.put(k, "dev", (one, two, S))
+    assert [cache.get(k, (one, two, S)) for _ in range(10)] == ["dev"] * 10
+    view = rng.standard_normal((6, 6, 8, 8, 8, 8))[:5, :5]          # the sliced views callers pass
+    kv = cache.key_of(one, view, S)
+    cache.put(kv, "view", (one, view, S))
+    assert [cache.get(kv, (one, view, S)) for _ in range(10)] == ["view"] * 10
+    for a in (one, two, view):
+        ref = cache._all_block_sums(a)
+        assert all(cache._block_sum(a, b) == ref[b] for b in range(0, len(ref), 37))
+    cache.clear()
+
+
 def test_array_level_mol_adapter():
     from evcont_amd.integrals import ao_arrays, is_array_mol, energy_nuc, grad_nuc, nao_of
     from evcont_amd.synthetic import make_ao_arrays
