@@ -41,23 +41,84 @@ def _select(vals, vecs, nroots, ground_state):
 
 
 # How the resident copy of the training data is stored by the mol-level entry points (``*_OAO``,
-# ``get_energy_with_grad``, ``MD_utils.get_scanner``): None = in the layout the caller passed (any input),
-# "sym8" = 8-fold compressed (``evaluator.DeviceTRDMs.compress_sym8_``: 3.7x fewer streamed bytes and the
-# symmetric AO-side pipeline; exact for AO integrals with the index symmetries of real two-electron integrals,
-# i.e. for every PySCF molecule; ``predicted_two_rdm`` then is the symmetrised 2-RDM).
-_COMPRESS = os.environ.get("EVCONT_AMD_COMPRESS") or None
+# ``get_energy_with_grad``, ``MD_utils.get_scanner``):
+#   "auto" (default)  8-fold compressed (``evaluator.DeviceTRDMs.compress_sym8_``: 3.7x fewer streamed bytes and the
+#                     symmetric AO-side pipeline, the configuration ``bench.py`` measures) whenever that is exact AND
+#                     indistinguishable from the reference for the caller: ``hermitian=True``, no predicted RDMs asked
+#                     for, and AO integrals with the index symmetries of real two-electron integrals -- a PySCF ``Mole``
+#                     has them by construction, an array-level molecule is checked at the first call for a training set
+#                     (``integrals_have_symmetry``).  Everything else (``hermitian=False``,
+#                     ``return_density_matrices=True``, ``predicted_two_rdm`` of a scanner, general tensors) runs on the
+#                     layout the caller passed, from a second resident copy made on first use;
+#   None / "none"     always the layout the caller passed;
+#   "sym8"            always compressed (``predicted_two_rdm`` then is the 8-fold symmetrised 2-RDM; integrals without
+#                     the symmetries raise ``EvcontHipError``).
+def _mode_from_env():
+    m = os.environ.get("EVCONT_AMD_COMPRESS", "auto").strip().lower()
+    if m in ("", "none", "0", "off"):
+        return None
+    if m not in ("auto", "sym8"):
+        raise ValueError(f"EVCONT_AMD_COMPRESS={m!r} (known: auto, sym8, none)")
+    return m
+
+
+_COMPRESS = _mode_from_env()
+_auto_decisions = {}   # training-set key -> bool: integrals of its first geometry had the symmetries
 
 
 def set_trdm_compression(mode) -> None:
-    """``None`` (default) or ``"sym8"``; applies to training data uploaded from now on."""
+    """``"auto"`` (default), ``"sym8"`` or ``None``; applies to training data uploaded from now on."""
     global _COMPRESS
-    if mode not in (None, "sym8"):
-        raise ValueError(f"unknown t-RDM compression {mode!r} (known: None, 'sym8')")
+    if mode not in (None, "sym8", "auto"):
+        raise ValueError(f"unknown t-RDM compression {mode!r} (known: None, 'sym8', 'auto')")
     _COMPRESS = mode
 
 
 def get_trdm_compression():
     return _COMPRESS
+
+
+def integrals_have_symmetry(mol_or_ao, tol: float = 1.0e-9) -> bool:
+    """Whether the AO integrals of a molecule have the index symmetries the compressed layout relies on (``eri``
+    8-fold, ``eri_ip1[x,p,q,r,s] = eri_ip1[x,p,q,s,r]``).  A PySCF ``Mole`` (anything with ``intor``): yes, libcint
+    integrals have them.  Array-level molecule: checked numerically (arrays handed over packed -- s4 / s2kl -- carry
+    the symmetries of their packing; the pair exchange of a packed ``eri`` is still checked)."""
+    if not is_array_mol(mol_or_ao):
+        return True
+    from .evaluator import check_integral_symmetry
+    from ._lib import EvcontHipError
+    n = int(np.asarray(mol_or_ao.S).shape[0])
+    ip1 = getattr(mol_or_ao, "eri_ip1", None)
+    if ip1 is not None and np.asarray(ip1).size == 0:
+        ip1 = None
+    try:
+        check_integral_symmetry(np.asarray(mol_or_ao.eri), None if ip1 is None else np.asarray(ip1), n, tol)
+    except EvcontHipError:
+        return False
+    return True
+
+
+def resolve_compression(mode, one_RDM, two_RDM, S, mol, hermitian=True, want_rdms=False, n=None):
+    """The storage (``None`` or ``"sym8"``) one call of a mol-level entry point uses under ``mode``
+    (``"default"`` = ``get_trdm_compression()``)."""
+    if mode == "default":
+        mode = _COMPRESS
+    if mode is None:
+        return None
+    if not hermitian:
+        return None              # the eig branch works on the subspace matrix of the caller's layout
+    if mode == "sym8":
+        return "sym8"
+    if want_rdms:
+        return None              # the reference returns the un-symmetrised predicted 2-RDM
+    key = cache.key_of(one_RDM, two_RDM, S, ("auto",))
+    ok = _auto_decisions.get(key)
+    if ok is None:
+        ok = integrals_have_symmetry(mol)
+        if len(_auto_decisions) > 64:
+            _auto_decisions.clear()
+        _auto_decisions[key] = ok
+    return "sym8" if ok else None
 
 
 def _trdms(one_RDM, two_RDM, S, compress=None) -> DeviceTRDMs:
@@ -69,9 +130,9 @@ def _trdms(one_RDM, two_RDM, S, compress=None) -> DeviceTRDMs:
     return t
 
 
-def _evaluator(one_RDM, two_RDM, S, natm: int, compress="default") -> ContinuationEvaluator:
-    if compress == "default":
-        compress = _COMPRESS
+def _evaluator(one_RDM, two_RDM, S, natm: int, compress=None) -> ContinuationEvaluator:
+    """``compress``: None or "sym8" (what ``resolve_compression`` returned for this call)."""
+    assert compress in (None, "sym8")
     t = _trdms(one_RDM, two_RDM, S, compress)       # verified against the host arrays, or uploaded again
     key = ("evaluator", id(t), int(natm))
     ev = cache.get(key)
@@ -122,7 +183,7 @@ def _oao(mol, one_RDM, two_RDM, S, nroots, hermitian=True, ground_state=False):
     ao = ao_arrays(mol, need_grad=False)
     # (the non-Hermitian branch works on the subspace matrix of the layout the caller passed)
     ev = _evaluator(one_RDM, two_RDM, S, int(np.asarray(ao.aoslices).shape[0]),
-                    compress="default" if hermitian else None)
+                    compress=resolve_compression("default", one_RDM, two_RDM, S, ao, hermitian=hermitian))
     dao = DeviceAO.from_arrays(ao, ev.t.device, energy_only=True)
     res = ev.energies(dao, nroots)
     if hermitian:

@@ -7,7 +7,8 @@ import torch
 
 from . import gradients as G
 from . import ops
-from .ab_initio_eigenvector_continuation import _evaluator, approximate_ground_state  # noqa: F401
+from .ab_initio_eigenvector_continuation import (_evaluator, approximate_ground_state,  # noqa: F401
+                                                 resolve_compression)
 from .electron_integral_utils import get_loewdin_trafo, restore_electron_exchange_symmetry  # noqa: F401
 from .evaluator import DeviceAO, _dev
 from .integrals import ao_arrays, grad_nuc, is_array_mol
@@ -96,6 +97,11 @@ def get_energy_with_grad(mol, one_RDM, two_RDM, S, hermitian=True, return_densit
         ev = _evaluator(one_RDM, two_RDM, S, natm, compress=None)
         return ev.energy_with_grad_nonhermitian(DeviceAO.from_arrays(ao, ev.t.device),
                                                 return_density_matrices=return_density_matrices)
-    ev = _evaluator(one_RDM, two_RDM, S, natm)
+    # default ("auto"): the compressed resident copy + symmetric pipeline when the call only wants (E, grad) and the
+    # integrals have the symmetries of real ones; the caller's layout otherwise (predicted RDMs as the reference
+    # returns them)
+    ev = _evaluator(one_RDM, two_RDM, S, natm,
+                    compress=resolve_compression("default", one_RDM, two_RDM, S, mol if not is_array_mol(mol) else ao,
+                                                 hermitian=True, want_rdms=return_density_matrices))
     dao = DeviceAO.from_arrays(ao, ev.t.device)
     return ev.energy_with_grad(dao, return_density_matrices=return_density_matrices)

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libevcont_hip.so")
-SOURCES = ["gemv_stream.hip", "gemv_mfma.hip", "gemv_lds.hip", "transform.hip", "dense_small.hip", "subspace_big.hip", "response.hip", "pipeline.hip"]
+SOURCES = ["gemv_stream.hip", "gemv_mfma.hip", "gemv_lds.hip", "transform.hip", "pair_dma.hip", "dense_small.hip", "subspace_big.hip", "response.hip", "pipeline.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "evcont_hip.h")]
 ARCH = "gfx950"
 # EVC_DEBUG_STAMPS=1 builds the eigen-kernels with their phase stamps (tools/micro/loewdin_time.py); never shipped

@@ -85,9 +85,16 @@ struct PairTransformArgs {
     int out_pairs;      // (with lead_sym and rs_lower) `out` is the dense (pair, pair) matrix out[tri(r',s')][tri(p,q)]
                         // instead of rows of an N^4 tensor; 2: times the multiplicity (p != q ? 2 : 1)
     int in_pairs;       // (with lead_sym) `in` is such a matrix: in[tri(p,q)][tri(r,s)]
+    int in_ld, out_ld;  // row pitch (doubles) of the dense (pair, pair) operand / result; 0: n(n+1)/2 (the caller's s4 `int2e`);
+                        // the pipeline's own intermediates use pair_ld(n): rows start on 128-byte lines
 };
+// Row pitch of the pipeline's dense (pair, pair) intermediates: n(n+1)/2 rounded up to 16 doubles.
+__host__ __device__ inline int pair_ld(int n) { return (n * (n + 1) / 2 + 15) & ~15; }
 constexpr int kPairTransformMaxN = 32;
 int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);
+// pair_dma.hip: the fully symmetric dense (pair, pair) -> dense (pair, pair) step, 16 < n <= 30, operand rows by LDS-DMA
+bool pair_transform_dma_applicable(const PairTransformArgs &a, int count);
+int launch_pair_transform_dma(const PairTransformArgs &a, int count, hipStream_t st);
 int launch_pack(const double *h2, int64_t sh2, int n, double diag_mult, double *out, int64_t sout, int64_t out_len,
                 int count, hipStream_t st);
 // 8-fold compressed vector of a tensor with the index symmetries of real two-electron integrals:
