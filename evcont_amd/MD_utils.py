@@ -11,7 +11,7 @@ import numpy as np
 
 from .ab_initio_gradients_loewdin import get_energy_with_grad
 from .ab_initio_eigenvector_continuation import (approximate_ground_state_OAO, _trdms,  # noqa: F401 (re-export)
-                                                 get_trdm_compression)
+                                                 get_trdm_compression, integrals_have_symmetry)
 from .electron_integral_utils import get_basis, get_integrals  # noqa: F401 (re-export)
 from .evaluator import ContinuationEvaluator, DeviceAO
 from .hosted import HostedEvaluator
@@ -30,12 +30,19 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="defaul
     """Fake PySCF gradient scanner driven by the continuation (reference :20-57): ``scanner(mol)``
     returns ``(E_tot, grad)`` and stores the predicted RDMs on ``scanner.base``.
 
-    ``compress``: storage of the resident training data, ``None``, ``"sym8"`` or ``"default"``
-    (= ``set_trdm_compression``); with ``"sym8"`` the stored predicted 2-RDM is the 8-fold symmetrised one.
+    ``compress``: storage of the resident training data, ``None``, ``"sym8"``, ``"auto"`` or ``"default"``
+    (= ``set_trdm_compression``, "auto" unless changed).  "auto": the 8-fold compressed copy and the packed s4 / s2kl
+    integrals for the per-step ``(E, grad)`` when ``hermitian`` and the first molecule's integrals have the symmetries
+    of real ones (a PySCF ``Mole`` always; array-level molecules are checked once), with ``predicted_two_rdm``
+    still the reference's un-symmetrised 2-RDM (evaluated on the caller's layout when it is read); with ``"sym8"``
+    the stored predicted 2-RDM is the 8-fold symmetrised one.
     ``device_trdms``: training data already resident on the device (``trdm_io.load_pair_directories`` /
     ``load_checkpoint``, a container's ``device_trdms()``): used instead of uploading the host arrays."""
     if compress == "default":
         compress = get_trdm_compression()
+    if compress not in (None, "sym8", "auto"):
+        raise ValueError(f"unknown t-RDM compression {compress!r} (known: None, 'sym8', 'auto', 'default')")
+    auto = compress == "auto"
 
     have_data = device_trdms is not None or (one_rdm is not None and two_rdm is not None and overlap is not None)
 
@@ -64,6 +71,8 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="defaul
         def __init__(self):
             self.mol = mol
             self.base = Base(self)
+            self._compress = None if auto else compress   # "auto": decided at the first call (needs integrals)
+            self._decided = not auto
             self._hev = None          # HostedEvaluator (Hermitian path)
             self._full = None         # ContinuationEvaluator with every output (lazy 2-RDM, hermitian=False)
             self._last = None         # (mol, D, G) of the last call as far as known
@@ -86,7 +95,9 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="defaul
         def _full_eval(self, m):
             ao = ao_arrays(m, need_grad=True)
             if self._full is None:
-                t = device_trdms if device_trdms is not None else _trdms(one_rdm, two_rdm, overlap, compress)
+                # "auto": the predicted 2-RDM as the reference returns it -- from the layout the caller passed
+                t = device_trdms if device_trdms is not None else \
+                    _trdms(one_rdm, two_rdm, overlap, None if auto else self._compress)
                 self._full = ContinuationEvaluator(t, int(np.asarray(ao.aoslices).shape[0]))
             return self._full.energy_with_grad(DeviceAO.from_arrays(ao, self._full.t.device), True)
 
@@ -113,7 +124,10 @@ def get_scanner(mol, one_rdm, two_rdm, overlap, hermitian=True, compress="defaul
             # step; with the compressed layout the two large integral arrays are requested / staged packed: 12 instead
             # of 26.6 MB at H30)
             if self._hev is None:
-                t = device_trdms if device_trdms is not None else _trdms(one_rdm, two_rdm, overlap, compress)
+                if not self._decided:
+                    self._compress = "sym8" if integrals_have_symmetry(mol) else None
+                    self._decided = True
+                t = device_trdms if device_trdms is not None else _trdms(one_rdm, two_rdm, overlap, self._compress)
                 sl = aoslices_of(mol)
                 self._hev = HostedEvaluator(t, len(sl), sl, warm_start=True)
             stage_mol(mol, self._hev)

@@ -81,8 +81,11 @@ def get_trdm_compression():
 def integrals_have_symmetry(mol_or_ao, tol: float = 1.0e-9) -> bool:
     """Whether the AO integrals of a molecule have the index symmetries the compressed layout relies on (``eri``
     8-fold, ``eri_ip1[x,p,q,r,s] = eri_ip1[x,p,q,s,r]``).  A PySCF ``Mole`` (anything with ``intor``): yes, libcint
-    integrals have them.  Array-level molecule: checked numerically (arrays handed over packed -- s4 / s2kl -- carry
+    integrals have them.  Array-level molecule: what it declares (``integral_symmetry``), else checked numerically (arrays handed over packed -- s4 / s2kl -- carry
     the symmetries of their packing; the pair exchange of a packed ``eri`` is still checked)."""
+    declared = getattr(mol_or_ao, "integral_symmetry", None)
+    if declared is not None:
+        return bool(declared)
     if not is_array_mol(mol_or_ao):
         return True
     from .evaluator import check_integral_symmetry
@@ -183,7 +186,8 @@ def _oao(mol, one_RDM, two_RDM, S, nroots, hermitian=True, ground_state=False):
     ao = ao_arrays(mol, need_grad=False)
     # (the non-Hermitian branch works on the subspace matrix of the layout the caller passed)
     ev = _evaluator(one_RDM, two_RDM, S, int(np.asarray(ao.aoslices).shape[0]),
-                    compress=resolve_compression("default", one_RDM, two_RDM, S, ao, hermitian=hermitian))
+                    compress=resolve_compression("default", one_RDM, two_RDM, S, ao if is_array_mol(mol) else mol,
+                                                 hermitian=hermitian))
     dao = DeviceAO.from_arrays(ao, ev.t.device, energy_only=True)
     res = ev.energies(dao, nroots)
     if hermitian:

@@ -235,8 +235,9 @@ def converge_EVCont_MD(EVCont_obj, init_mol, steps=100, dt=1, convergence_thresh
         # energies of the new trajectory with subsets of the training set: ONE t-RDM contraction per geometry
         T = EVCont_obj.ntrain
         traj_mols = [init_mol.with_coords(g, need_grad=False) for g in trajectory]
-        from .ab_initio_eigenvector_continuation import get_trdm_compression
-        lay = "sym8" if get_trdm_compression() == "sym8" else "pack2"
+        from .ab_initio_eigenvector_continuation import get_trdm_compression, integrals_have_symmetry
+        mode = get_trdm_compression()
+        lay = "sym8" if mode == "sym8" or (mode == "auto" and integrals_have_symmetry(traj_mols[0])) else "pack2"
         H, _, enuc = trajectory_hamiltonians(EVCont_obj.device_trdms(lay, device=dev), _device_aos(traj_mols, dev))
         S_dev = torch.from_numpy(np.ascontiguousarray(EVCont_obj.overlap, dtype=np.float64)).to(dev)
         reference_ens = subset_energies(H, S_dev, enuc, [list(range(T - 1))])[:, 0].cpu().numpy()

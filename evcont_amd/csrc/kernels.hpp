@@ -83,7 +83,7 @@ struct PairTransformArgs {
     int in_lower;       // in[p][q][r][s] = in[p][q][s][r] and only r >= s is valid (output of a lead_sym step)
     int rs_lower;       // only the rows (r',s'), s' <= r', of the result are needed (out rows / packed sym8 vector)
     int out_pairs;      // (with lead_sym and rs_lower) `out` is the dense (pair, pair) matrix out[tri(r',s')][tri(p,q)]
-                        // instead of rows of an N^4 tensor; 2: times the multiplicity (p != q ? 2 : 1)
+                        // instead of rows of an N^4 tensor (multiplicities are the consumers' business)
     int in_pairs;       // (with lead_sym) `in` is such a matrix: in[tri(p,q)][tri(r,s)]
     int in_ld, out_ld;  // row pitch (doubles) of the dense (pair, pair) operand / result; 0: n(n+1)/2 (the caller's s4 `int2e`);
                         // the pipeline's own intermediates use pair_ld(n): rows start on 128-byte lines
@@ -119,18 +119,15 @@ int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t 
                    int lead_half, hipStream_t st);
 // partial[b][i][a] = sum_{k in slab b} SB[i][k] * K3[k][a]: the Y2 contraction with the row-major operand
 int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st);
-// ... with SB only valid for i >= j, l <= k and K3[j][k][l][:] only for l <= k (symmetric pair-transform pipeline)
-// pairs: SB is the dense (pair, pair) matrix SB[tri(i,j)][tri(k,l)]
 // Y2 without K3 (symmetric pipeline): the half-transformed integrals are recomputed from the dense (pair, pair)
 // intermediate `M1` of the first pair step (kept by the energy phase) inside the contraction,
 //   Y2[i][a] = sum_v mult(v) sum_j SB[v][tri(i,j)] (M1_v X)[a][j];
-// writes y2_fused_slabs(n, count) partial (n, n) matrices per geometry (same layout as launch_y2_fold's)
+// writes y2_fused_slabs(n, count) partial (n, n) matrices per geometry (slabs as launch_y2's); SB and M1 at the pitch
+// pair_ld(n)
 int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial,
                     int64_t sws, int count, hipStream_t st);
 int y2_fused_slabs(int n, int count);
 bool y2_fused_available(int n);
-int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, int pairs,
-                   hipStream_t st);
 // partial[b][i][a] = sum_{k in slab b} GsT[k][i] * K3[k][a]   (k = jkl)
 int y2_slabs(int n);
 int y2_slab_capacity(int n);   // slabs the pipeline's partial buffer holds (>= y2_slabs)
@@ -154,7 +151,8 @@ struct Ip1Args {
                            // d <= c, b <= m
     int ip1_s2kl;          // (with fold_cd) ip1 is (3,n,n,n(n+1)/2): packed in its last two indices, c >= d
                            // (EVC_FLAG_IP1_S2KL); sip1 is the packed size and Gao the dense (pair, pair) matrix
-                           // Gao[tri(m,b)][tri(c,d)] with the multiplicity of (c,d) folded in (out_pairs)
+                           // Gao[tri(m,b)][tri(c,d)] at the pitch pair_ld(n), WITHOUT the multiplicity of (c,d): the
+                           // dot weighs it (2 for c != d)
 };
 int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st);
 

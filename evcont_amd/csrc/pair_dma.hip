@@ -38,7 +38,8 @@ constexpr unsigned kPdRaw = 4;                    // 1 KiB pieces per operand ro
 constexpr unsigned kPdRB = kPdRaw * 1024 + 64;    // bytes per wave: the row and a zero slot behind it
 constexpr unsigned kPdStage = 4 * kPdRB;          // byte offset of the stage (a multiple of 256)
 constexpr unsigned kPdP = 3872;                   // slot pitch of the stage: >= 8 (465 + 16) bytes, = 32 mod 128
-constexpr unsigned kPdLds = kPdStage + 16 * kPdP;
+constexpr unsigned kPdTab = kPdStage + 16 * kPdP;   // MODE 1: multiplicity of pair u (1 on the diagonal i == j, else 2), 512 floats
+constexpr unsigned kPdLds = kPdTab, kPdLds1 = kPdTab + 512 * 4;
 
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -62,8 +63,11 @@ __device__ __forceinline__ unsigned opaque(unsigned x) {
 // LDS accesses at integer byte addresses (through the `lds` array the compiler adds the array's base -- the literal 0 --
 // with a vector instruction per access in some of the unrolled phases)
 typedef __attribute__((address_space(3))) double lds_f64;
-__device__ __forceinline__ double lds_ld(unsigned addr) { return *(lds_f64 *)addr; }
-__device__ __forceinline__ void lds_st(unsigned addr, double v) { *(lds_f64 *)addr = v; }
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f2 lds_f2;
+__device__ __forceinline__ double lds_ld(unsigned addr) { return *(lds_f64 *)(uintptr_t)addr; }
+__device__ __forceinline__ void lds_st(unsigned addr, double v) { *(lds_f64 *)(uintptr_t)addr = v; }
 // k (0..3) wave-uniform: scalar compares and one wait
 __device__ __forceinline__ void wait_vm_dyn(int k) {
     if (k <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -75,13 +79,18 @@ __device__ __forceinline__ void wait_vm_dyn(int k) {
 }  // namespace
 
 // MODE 0: dense (pair, pair) result out[tri(r',s')][tri(p,q)], pitch out_ld.
+// MODE 1: the 8-fold compressed packed vector packed[tri(u, v)], u = tri(r',s') >= v = tri(p,q), times the
+//         multiplicities of both pairs (and diag_mult on u == v): the write-out walks the rows u = ur + 64 k from 0 with
+//         lane-constant offsets tri(u) and skips the passes above the diagonal (k < v / 64, wave-uniform); the pass that
+//         holds the diagonal takes a slower, predicated body, once per tile.  Its stores vary from tile to tile, so here
+//         the wait for an operand row is vmcnt(0) (the stores behind it are a phase old by then).
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void ptd_kernel(PairTransformArgs a) {
     constexpr int KS = 8, NT = 2;
     extern __shared__ __align__(16) char lds[];   // the only LDS of this kernel: it starts at LDS address 0
     const int n = a.n;
     const int npairs = n * (n + 1) / 2;
-    const int in_ld = a.in_ld, out_ld = a.out_ld;
+    const int in_ld = a.in_ld ? a.in_ld : npairs, out_ld = a.out_ld;   // (0: the caller's s4 matrix, pitch n(n+1)/2)
     const int64_t g = blockIdx.y;
     const double *__restrict__ in = a.in + g * a.sin;
     const double *__restrict__ C = a.C + g * a.sC;
@@ -156,7 +165,28 @@ __global__ __launch_bounds__(256, 2) void ptd_kernel(PairTransformArgs a) {
     const int wl = 2 * (threadIdx.x & 3), ur = threadIdx.x >> 2;
     const unsigned wo = opaque(kPdStage + (unsigned)wl * kPdP + 8u * (unsigned)ur);
     const unsigned gvo = (unsigned)((ur * out_ld + wl) * 8);
-    char *outg = reinterpret_cast<char *>(a.out + g * a.sout);
+    char *outg = reinterpret_cast<char *>(MODE == 0 ? a.out + g * a.sout : a.packed + g * a.spacked);
+    [[maybe_unused]] unsigned tv[8];     // MODE 1: byte offset of (row ur + 64 k, column wl) in the packed vector
+    [[maybe_unused]] double frow[8];     // MODE 1: multiplicity of row ur + 64 k
+    if constexpr (MODE == 1) {
+        // table of pair multiplicities (the diagonal pairs u = tri(i,i) = i (i + 3) / 2 are 1, the others 2)
+        for (int u = threadIdx.x; u < 512; u += 256) {
+            const int r = tri_row_small(u);
+            *(lds_f32 *)(uintptr_t)(kPdTab + 4u * (unsigned)u) = (u == r * (r + 3) / 2) ? 1.0f : 2.0f;
+        }
+        if (blockIdx.x == 0) {   // zero the padding [M, packed_len) once per geometry
+            double *pk = a.packed + g * a.spacked;
+            const int64_t M = (int64_t)npairs * (npairs + 1) / 2;
+            for (int64_t m = M + threadIdx.x; m < a.packed_len; m += 256) pk[m] = 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = ur + 64 * k;
+            tv[k] = (unsigned)((u * (u + 1) / 2 + wl) * 8);
+            frow[k] = (double)*(lds_f32 *)(uintptr_t)(kPdTab + 4u * (unsigned)(u & 511));
+        }
+    }
     const int wrows = npairs - 16 * wave;   // pass k valid <=> 64 k < wrows
     // stores of an N phase that are younger than its DMA (passes c = 1..3 of the phase): what the wait for the next
     // operand row leaves in flight
@@ -225,12 +255,22 @@ __global__ __launch_bounds__(256, 2) void ptd_kernel(PairTransformArgs a) {
             // tile jt (relative to t_begin) is complete after this barrier: written out in the N phases of iterations
             // 2 jt + 2 (passes 0..3) and 2 jt + 3 (passes 4..7); its buffer has the other parity than this matrix's tile
             int act = (ODD ? i >= 3 : i >= 2) ? vmask : 0;   // passes this wave writes in this phase (bit k)
-            asm volatile("" : "+s"(act));                    // (kept a scalar: bit tests at the uses, no lane-mask copies)
             const int jt = (ODD ? i - 3 : i - 2) >> 1;
             constexpr unsigned bimm = (TP ^ 1u) * 8u * kPdP;
             char *ob = outg + (int64_t)(8 * (t_begin + jt)) * 8;
-            const int K = i >= 3 ? (ODD ? cntA : cntB) : 0;
+            const int K = (MODE == 0 && i >= 3) ? (ODD ? cntA : cntB) : 0;
             d2 dv[4];
+            [[maybe_unused]] int kd = 0;       // MODE 1: the pass that holds the diagonal u == v of this tile's columns
+            [[maybe_unused]] d2 cf = {1.0, 1.0};   // MODE 1: multiplicities of the thread's two columns
+            if constexpr (MODE == 1) {
+                const int tg = t_begin + (jt < 0 ? 0 : jt);
+                kd = tg >> 3;
+                act &= ~((1 << kd) - 1);
+                ob = outg + (int64_t)(8 * tg) * 8;
+                const f2 c2 = *(lds_f2 *)(uintptr_t)(kPdTab + 4u * (unsigned)(8 * tg + wl));
+                cf = (d2){(double)c2[0], (double)c2[1]};
+            }
+            asm volatile("" : "+s"(act));   // (kept a scalar: bit tests at the uses, no lane-mask copies)
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 if ((kk & 1) == 0) {
@@ -265,7 +305,25 @@ __global__ __launch_bounds__(256, 2) void ptd_kernel(PairTransformArgs a) {
                     }
                     if (m == 2 && (kk & 1) == 1) {
                         const int c = kk / 2, k = (ODD ? 4 : 0) + c;
-                        if (act >> k & 1) gstore16(gvo, dv[c], ob + (int64_t)(64 * k) * out_ld * 8);
+                        if constexpr (MODE == 0) {
+                            if (act >> k & 1) gstore16(gvo, dv[c], ob + (int64_t)(64 * k) * out_ld * 8);
+                        } else if (act >> k & 1) {
+                            const int u = ur + 64 * k;
+                            d2 f = cf * frow[k];
+                            if (k != kd) {          // below the diagonal: both columns, rows beyond the last one masked
+                                const d2 v = dv[c] * f;
+                                if (u < npairs) gstore16(tv[k], v, ob);
+                            } else {                // the diagonal pass: column v of row u only for u >= v, diag_mult on u == v
+                                const int d = u - (8 * (t_begin + jt) + wl);
+                                if (d == 0) f[0] *= a.diag_mult;
+                                if (d == 1) f[1] *= a.diag_mult;
+                                const d2 v = dv[c] * f;
+                                if (u < npairs) {
+                                    if (d >= 1) *reinterpret_cast<d2 *>(ob + tv[k]) = v;
+                                    else if (d == 0) *reinterpret_cast<double *>(ob + tv[k]) = v[0];
+                                }
+                            }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -301,8 +359,9 @@ bool pair_transform_dma_applicable(const PairTransformArgs &a, int count) {
     static const bool on = !(getenv("EVC_PT_DMA") && atoi(getenv("EVC_PT_DMA")) == 0);
     const int npairs = a.n * (a.n + 1) / 2;
     return on && a.n > 16 && a.n <= kPdMaxN && count >= 4 && a.lead_sym && a.in_lower && a.rs_lower && a.in_pairs &&
-           a.out && a.out_pairs && !a.packed && !a.k3 && a.in_ld >= npairs && a.out_ld >= 8 * ((npairs + 7) / 8) &&
-           a.out_ld % 2 == 0;
+           !a.k3 && (a.in_ld == 0 || a.in_ld >= npairs) &&
+           ((a.out && a.out_pairs && !a.packed && a.out_ld >= 8 * ((npairs + 7) / 8) && a.out_ld % 2 == 0) ||
+            (a.packed && a.sym8 && !a.out));
 }
 
 int launch_pair_transform_dma(const PairTransformArgs &a_in, int count, hipStream_t st) {
@@ -310,9 +369,15 @@ int launch_pair_transform_dma(const PairTransformArgs &a_in, int count, hipStrea
     const int npairs = a.n * (a.n + 1) / 2, ntiles = (npairs + 7) / 8;
     if (a.tiles_per_wg < 1) a.tiles_per_wg = 4;
     const dim3 grid((unsigned)((ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)count);
-    static LdsAttr attr;
-    if (int rc = allow_dynamic_lds(ptd_kernel<0>, attr, 160 * 1024, "pair_transform_dma")) return rc;
-    hipLaunchKernelGGL((ptd_kernel<0>), grid, dim3(256), kPdLds, st, a);
+    if (a.packed) {
+        static LdsAttr attr1;
+        if (int rc = allow_dynamic_lds(ptd_kernel<1>, attr1, 160 * 1024, "pair_transform_dma")) return rc;
+        hipLaunchKernelGGL((ptd_kernel<1>), grid, dim3(256), kPdLds1, st, a);
+    } else {
+        static LdsAttr attr;
+        if (int rc = allow_dynamic_lds(ptd_kernel<0>, attr, 160 * 1024, "pair_transform_dma")) return rc;
+        hipLaunchKernelGGL((ptd_kernel<0>), grid, dim3(256), kPdLds, st, a);
+    }
     EVC_LAUNCH_CHECK("pair_transform_dma");
     return 0;
 }

@@ -162,9 +162,12 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.Dpred = take(n2);
     w.Pao = take(n2);
     w.Y1 = take(n2);
-    w.B1 = take(n4);
-    w.B2 = take(n4);
-    w.K3 = take(n4);
+    // (the symmetric pipeline keeps dense (pair, pair) matrices in these: pair_ld(n) rows -- whole 16-row groups are
+    //  written -- at the pitch pair_ld(n), which exceeds n^4 doubles for n <= 3)
+    const size_t ldp = (size_t)pair_ld((int)n), nbig = n4 > ldp * ldp ? n4 : ldp * ldp;
+    w.B1 = take(nbig);
+    w.B2 = take(nbig);
+    w.K3 = take(nbig);
     w.G = take(n4);
     w.vec2 = take((size_t)t->ld2 + 2);
     memset(&w.rp2, 0, sizeof(w.rp2));
@@ -305,12 +308,16 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
             // (in_lower: eri[p,q,r,s] = eri[p,q,s,r]; rs_lower: the next step's leading pairs are (r',s'), s' <= r')
             pa.lead_sym = pa.in_lower = pa.rs_lower = is_sym8(t->layout) ? 1 : 0;
             pa.in_pairs = g.eri_s4;       // int2e handed over as the dense (pair, pair) matrix (EVC_FLAG_ERI_S4)
+            pa.in_ld = 0;                 // ... at the caller's pitch n(n+1)/2
             pa.out_pairs = pa.lead_sym;   // the intermediate as a dense (pair, pair) matrix
+            pa.out_ld = pair_ld(n);
             int pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
             if ((rc = launch_pair_transform(pa, cc, st))) return rc;
             prof_stop(pr, st);
             pa.in_pairs = pa.out_pairs;
+            pa.in_ld = pa.out_ld;
             pa.out_pairs = 0;
+            pa.out_ld = 0;
             // ... and the second step again only needs the q <= p half of ITS leading pair
             pa.in = mid;
             pa.sin = sw;
@@ -538,8 +545,9 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                         }
                         if ((rc = launch_y2_fused(sbp, w.K3 + o, w.X + o, sw, n, w.y2part + o, sw, cc, st))) return rc;
                         y2_slabs_used = y2_fused_slabs(n, cc);
-                    } else if ((rc = launch_y2_fold(w.B1 + o, w.K3 + o, n, w.y2part + o, sw, cc, G ? 0 : 1, st))) {
-                        return rc;
+                    } else {
+                        set_error("gradient: the symmetric pipeline needs the fused Y2 contraction (n <= 32)");
+                        return -1;
                     }
                 } else {
                     if ((rc = launch_unpack_sym(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, w.B1 + o, sw,
@@ -563,6 +571,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.lead_sym = pa.in_lower = pa.rs_lower = sym8;   // SB is fully symmetric
                 pa.in_pairs = (sym8 && !G) ? 1 : 0;
                 pa.out_pairs = sym8;
+                pa.in_ld = pa.out_ld = pair_ld(n);   // (pitch of every dense (pair, pair) form of the pipeline)
                 pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
                 prof_stop(pr, st);
@@ -571,7 +580,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.in = w.B2 + o;
                 pa.out = w.B1 + o;
                 pa.in_pairs = pa.out_pairs;
-                pa.out_pairs = ip1_s2kl ? 2 : 0;   // the packed-ip1 dot wants the dense (pair, pair) form, weighted
+                pa.out_pairs = ip1_s2kl ? 1 : 0;   // the packed-ip1 dot wants the dense (pair, pair) form (it weighs it itself)
                 pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
                 if ((rc = launch_pair_transform(pa, cc, st))) return rc;
                 prof_stop(pr, st);

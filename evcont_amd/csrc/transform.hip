@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     const bool sym = a.lead_sym != 0;
     const int ntq = (n + QT - 1) / QT;
     const int npairs = n * (n + 1) / 2;
+    const int ild = a.in_ld ? a.in_ld : npairs, old_ = a.out_ld ? a.out_ld : npairs;   // pitch of the dense (pair, pair) forms
     const int ntiles = sym ? (npairs + QT - 1) / QT : n * ntq;
     const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(ntiles, t_begin + a.tiles_per_wg);
     if (t_begin >= t_end) return;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     // in_pairs: the operand is the dense (pair, pair) matrix in[tri(p,q)][tri(r,s)] (out_pairs of the previous step)
     const bool inp = a.in_pairs != 0;
     auto load_matrix = [&](double (&m)[NT][KS], bool ok, int p, int q) {
-        const double *Mb = inp ? in + (int64_t)(ok ? p * (p + 1) / 2 + q : 0) * npairs
+        const double *Mb = inp ? in + (int64_t)(ok ? p * (p + 1) / 2 + q : 0) * ild
                                : in + ((int64_t)(ok ? p : 0) * n + (ok ? q : 0)) * n2;
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
     }
     auto fetch_row = [&](bool ok, int p_, int q_, int &d_) {
         if constexpr (ROWBUF) {
-            const double *row = in + (int64_t)(ok ? p_ * (p_ + 1) / 2 + q_ : 0) * npairs;
+            const double *row = in + (int64_t)(ok ? p_ * (p_ + 1) / 2 + q_ : 0) * ild;
             d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
             const double *w0 = row - d_;          // 16-byte aligned window
             const int lim = npairs + d_;          // valid doubles of the window
@@ -422,11 +423,9 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
             if (!rsl) {
                 for (int rs = threadIdx.x >> 3; rs < n * n; rs += 32) out[(int64_t)rs * n2 + Cc] = stage[rs * QP + wl];
             } else if (a.out_pairs) {
-                // dense (pair, pair) result: row tri(r',s'), column = the leading pair's own triangle index; with
-                // out_pairs = 2 the multiplicity of the leading pair is folded in (the consumer is a plain dot)
-                const double mq = (a.out_pairs > 1 && wp != wq) ? 2.0 : 1.0;
+                // dense (pair, pair) result: row tri(r',s'), column = the leading pair's own triangle index
                 const int e = t * QT + wl;
-                for (int u = threadIdx.x >> 3; u < npairs; u += 32) out[(int64_t)u * npairs + e] = stage[u * QP + wl] * mq;
+                for (int u = threadIdx.x >> 3; u < npairs; u += 32) out[(int64_t)u * old_ + e] = stage[u * QP + wl];
             } else {
                 // (r', s') of stage row u, advanced incrementally: u += 32
                 int r2 = (int)tri_row(threadIdx.x >> 3), s2 = (threadIdx.x >> 3) - r2 * (r2 + 1) / 2;
@@ -506,7 +505,7 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 //   * H phase of matrix i (KS groups of NT*NT MFMAs): the stage writes of matrix i-1's result (kept in registers);
 //   * N phase: the operand row of matrix i+1 goes from registers to the wave's LDS row and comes back as MFMA
 //     fragments (the registers of matrix i's fragments are free after its H phase), the global fetch of matrix i+2's
-//     row is issued, K3 is stored (MODE 1), half of the write-out passes of an EARLIER tile --
+//     row is issued, half of the write-out passes of an EARLIER tile --
 // with a double-buffered stage (8 doubles per result row and buffer, the slot XOR-swizzled by the row against bank
 // conflicts of the accumulator layout) and ONE workgroup barrier per tile: barrier(j) sits after the H phase of
 // the first matrix of tile j+1 (which wrote the last results of tile j); tile j is then written out during the
@@ -514,8 +513,8 @@ __global__ __launch_bounds__(256) void pt_kernel(PairTransformArgs a) {
 // are spread evenly over its duration.  (vmcnt counts loads and stores in order on gfx9: the wait for an operand row
 // also waits for every store issued before it, so the write-out sits in the N phases only and the row is awaited at
 // the start of the next one, an H phase later.)
-// MODE 0: dense (pair, pair) result out[tri(r',s')][tri(p,q)] (x multiplicity of (p,q) with out_pairs = 2);
-// MODE 1: the 8-fold compressed packed vector (+ K3 when asked for).
+// MODE 0: dense (pair, pair) result out[tri(r',s')][tri(p,q)];
+// MODE 1: the 8-fold compressed packed vector.
 template <int NPAD, int MODE>
 __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     constexpr int KS = NPAD / 4;
@@ -525,7 +524,6 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     constexpr int NRES = NT * (NT + 1) / 2 * 4;                    // result registers (doubles) of a matrix per lane
     constexpr int SPG = (NRES + KS - 1) / KS;                      // stage writes per MFMA group
     constexpr int FPG = (NT * KS + (KS - 2) - 1) / (KS - 2);       // fragment reads per MFMA group (groups 2..KS-1)
-    constexpr int EPG = (NT * NT * 4 + KS - 1) / KS;               // K3 stores per MFMA group
     constexpr int PPG = (PH2 + KS - 1) / KS;                       // write-out passes per MFMA group (N phase)
     constexpr int RAWN = (NPAD * (NPAD + 1) / 2 + 1 + 127) / 128;  // 16-byte loads per lane that cover a row
     extern __shared__ __align__(16) double sm[];
@@ -534,6 +532,7 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     const int64_t g = blockIdx.y;
     const double *__restrict__ in = a.in + g * a.sin;
     const double *__restrict__ C = a.C + g * a.sC;
+    const int ild = a.in_ld ? a.in_ld : npairs, old_ = a.out_ld ? a.out_ld : npairs;   // pitch of the dense (pair, pair) forms
     const int ntiles = (npairs + 7) / 8;
     const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(ntiles, t_begin + a.tiles_per_wg);
     if (t_begin >= t_end) return;
@@ -552,7 +551,6 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     char *__restrict__ outb = nullptr;
     if constexpr (MODE == 0) outb = reinterpret_cast<char *>(a.out + g * a.sout);
     else outb = reinterpret_cast<char *>(a.packed + g * a.spacked);
-    const bool weigh = MODE == 1 || a.out_pairs > 1;
 
     int foff[NT][KS];   // fragment (rt, kk) of the symmetric n x n matrix in its packed row
 #pragma unroll
@@ -578,23 +576,12 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
                 sa[it][st][reg] = (r2 < n && s2 <= r2) ? u * 16 + (wave ^ (((u >> 1) & 3) << 1)) : npairs * 16 + wave;
             }
     [[maybe_unused]] const int dq = l15 - l4;   // result register reg of a diagonal tile is r' == s'  <=>  dq == 4 reg
-    // K3 (MODE 1): bit (rt * NT + st) * 4 + reg: the lane holds an element of H with r < n, s' < n
-    [[maybe_unused]] unsigned kmask = 0;
-    if constexpr (MODE == 1) {
-#pragma unroll
-        for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-            for (int st = 0; st < NT; ++st)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    if (rt * 16 + l4 + 4 * reg < n && st * 16 + l15 < n) kmask |= 1u << ((rt * NT + st) * 4 + reg);
-    }
     if (lane < 4) mrow[kPtRawMax * 128 + lane] = 0.0;
 
     d2 raw[RAWN];
     // row e of the operand (e clamped: idle slots fetch row 0 and their result is never written out)
     auto fetch = [&](int e) -> int {
-        const double *row = in + (int64_t)(e < npairs ? e : 0) * npairs;
+        const double *row = in + (int64_t)(e < npairs ? e : 0) * ild;
         const int d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
         const double *w0 = row - d_;          // 16-byte aligned window
         const int lim = npairs + d_;          // valid doubles of the window
@@ -651,9 +638,7 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     // write-out: 4 lanes cover the pair run of one result row, two pairs (16 bytes) each; thread (wl, ur) takes the
     // columns wl, wl + 1 (wl even) of rows u0 + 64 k
     const int wl = 2 * (threadIdx.x & 3), ur = threadIdx.x >> 2;
-    [[maybe_unused]] const unsigned stride_b = 64u * (unsigned)npairs * 8u;   // MODE 0: bytes between two passes
-    [[maybe_unused]] const int64_t krow_b = (int64_t)npairs * n * 8;          // MODE 1: bytes between two K3 rows s'
-    [[maybe_unused]] const unsigned k3lane = (unsigned)((l15 * npairs * n + l4) * 8);
+    [[maybe_unused]] const unsigned stride_b = 64u * (unsigned)old_ * 8u;     // MODE 0: bytes between two passes
 
     // the result of a matrix stays in registers until it is staged during the next matrix's H phase: two register
     // sets, alternating (the loop body is instantiated for even and odd i)
@@ -670,7 +655,6 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
     auto iteration = [&](auto compute_tag, auto odd_tag, const int i, d4 (&nnp)[NT][NT], d4 (&nn)[NT][NT]) {
         constexpr bool COMPUTE = decltype(compute_tag)::value, ODD = decltype(odd_tag)::value;
         const int ei = e0 + 4 * i;
-        const bool have = COMPUTE && ei < npairs;   // wave-uniform
         EVC_PT_STAMP(3 + 3 * i);
         // ---------------------------------------------------------------- H = M X  (+ stage writes of matrix i-1)
         d4 h[NT][NT];
@@ -733,9 +717,7 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
             [[maybe_unused]] unsigned offA = 0;
             if (dn) {
                 if constexpr (MODE == 0) {
-                    fac[0] = (weigh && !is_diag(ew)) ? 2.0 : 1.0;
-                    fac[1] = (weigh && !is_diag(ew + 1)) ? 2.0 : 1.0;
-                    off0 = (unsigned)(u0 * npairs + ew) * 8u;
+                    off0 = (unsigned)(u0 * old_ + ew) * 8u;
                 } else {
                     fac[0] = is_diag(ew) ? 2.0 : 4.0;              // multiplicity of (p,q) x 2 (see the stage writes)
                     fac[1] = is_diag(ew + 1) ? 2.0 : 4.0;
@@ -744,16 +726,6 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
                     fac0[1] = ur == 1 ? fac[1] * a.diag_mult : fac[1];
                     off0 = (unsigned)(u0 * (u0 + 1) / 2 + ew) * 8u;
                     offA = (unsigned)(64 * u0) * 8u;               // tri(u0 + 64 k) = tri(u0) + k (64 u0) + 2048 k^2 + 32 k
-                }
-            }
-            [[maybe_unused]] char *K3b = nullptr;
-            [[maybe_unused]] double km = 1.0;
-            if constexpr (MODE == 1 && COMPUTE) {
-                if (a.k3 && have) {
-                    // only K3[s'][tri(p,q)][:] with q <= p is written (its consumer folds the p <-> q symmetry), times
-                    // the multiplicity of (p,q)
-                    K3b = reinterpret_cast<char *>(a.k3 + g * a.sk3 + (int64_t)ei * n) + k3lane;
-                    km = is_diag(ei) ? 1.0 : 2.0;
                 }
             }
             constexpr int NM = NT * (NT + 1) / 2;   // MFMAs of a group: tiles (0,0), (1,0), (1,1)
@@ -790,21 +762,6 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
                                     if ((rt * KS + k2) / FPG == kk - 2) mf[rt][k2] = mrow[foff[rt][k2] + d_rd];
                         }
                     }
-                    if constexpr (MODE == 1 && COMPUTE) {
-                        if (m == (NM > 1 ? 1 : 0) && K3b) {
-#pragma unroll
-                            for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                                for (int st = 0; st < NT; ++st)
-#pragma unroll
-                                    for (int reg = 0; reg < 4; ++reg) {
-                                        const int e = (rt * NT + st) * 4 + reg;
-                                        if (e / EPG == kk && (kmask >> e & 1u))
-                                            *reinterpret_cast<double *>(K3b + st * 16 * krow_b + (rt * 16 + 4 * reg) * 8) =
-                                                h[rt][st][reg] * km;
-                                    }
-                        }
-                    }
                     if (m == NM - 1) {
 #pragma unroll
                         for (int c = 0; c < PPG; ++c) {
@@ -816,7 +773,7 @@ __global__ __launch_bounds__(256) void pt_pipe_kernel(PairTransformArgs a) {
                                 bool second = two;
                                 if constexpr (MODE == 0) {
                                     off = off0 + kq * stride_b;
-                                    v = dv[c] * fac;
+                                    v = dv[c];
                                 } else {
                                     off = off0 + kq * offA + (2048u * kq * kq + 32u * kq) * 8u;
                                     v = dv[c] * (kq == 0 ? fac0 : fac);
@@ -865,6 +822,7 @@ __global__ __launch_bounds__(256) void pt_pipe4_kernel(PairTransformArgs a) {
     const int64_t g = blockIdx.y;
     const double *__restrict__ in = a.in + g * a.sin;
     const double *__restrict__ C = a.C + g * a.sC;
+    const int ild = a.in_ld ? a.in_ld : npairs, old_ = a.out_ld ? a.out_ld : npairs;   // pitch of the dense (pair, pair) forms
     const int ntiles = (npairs + 3) / 4;
     const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(ntiles, t_begin + a.tiles_per_wg);
     if (t_begin >= t_end) return;
@@ -877,7 +835,6 @@ __global__ __launch_bounds__(256) void pt_pipe4_kernel(PairTransformArgs a) {
     char *__restrict__ outb = nullptr;
     if constexpr (MODE == 0) outb = reinterpret_cast<char *>(a.out + g * a.sout);
     else outb = reinterpret_cast<char *>(a.packed + g * a.spacked);
-    const bool weigh = MODE == 1 || a.out_pairs > 1;
 
     int foff[NT][KS];
 #pragma unroll
@@ -904,7 +861,7 @@ __global__ __launch_bounds__(256) void pt_pipe4_kernel(PairTransformArgs a) {
 
     d2 raw[RAWN];
     auto fetch = [&](int e) -> int {
-        const double *row = in + (int64_t)(e < npairs ? e : 0) * npairs;
+        const double *row = in + (int64_t)(e < npairs ? e : 0) * ild;
         const int d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
         const double *w0 = row - d_;
         const int lim = npairs + d_;
@@ -954,7 +911,7 @@ __global__ __launch_bounds__(256) void pt_pipe4_kernel(PairTransformArgs a) {
     // write-out: 2 lanes cover the 4 pairs of one result row (16 bytes each); thread (wl, ur): columns wl, wl + 1 of
     // rows u0 + 128 k
     const int wl = 2 * (threadIdx.x & 1), ur = threadIdx.x >> 1;
-    [[maybe_unused]] const unsigned stride_b = 128u * (unsigned)npairs * 8u;
+    [[maybe_unused]] const unsigned stride_b = 128u * (unsigned)old_ * 8u;
 
     d4 nnp[NT][NT];
 #pragma unroll
@@ -1016,9 +973,7 @@ __global__ __launch_bounds__(256) void pt_pipe4_kernel(PairTransformArgs a) {
             [[maybe_unused]] unsigned offA = 0;
             if (dn) {
                 if constexpr (MODE == 0) {
-                    fac[0] = (weigh && !is_diag(ew)) ? 2.0 : 1.0;
-                    fac[1] = (weigh && !is_diag(ew + 1)) ? 2.0 : 1.0;
-                    off0 = (unsigned)(u0 * npairs + ew) * 8u;
+                    off0 = (unsigned)(u0 * old_ + ew) * 8u;
                 } else {
                     fac[0] = is_diag(ew) ? 2.0 : 4.0;
                     fac[1] = is_diag(ew + 1) ? 2.0 : 4.0;
@@ -1071,7 +1026,7 @@ __global__ __launch_bounds__(256) void pt_pipe4_kernel(PairTransformArgs a) {
                                 bool second = two;
                                 if constexpr (MODE == 0) {
                                     off = off0 + kq * stride_b;
-                                    v = dv[c] * fac;
+                                    v = dv[c];
                                 } else {
                                     off = off0 + kq * offA + (8192u * kq * kq + 64u * kq) * 8u;
                                     v = dv[c] * (kq == 0 ? fac0 : fac);
@@ -1109,12 +1064,13 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     // fully symmetric step of the compressed layout's pipeline: the software-pipelined kernel, if two of its workgroups
     // fit a CU's LDS (n <= 30; EVC_PT_PIPE=0: the phase-alternating kernel below)
     static const bool pipe_on = !(getenv("EVC_PT_PIPE") && atoi(getenv("EVC_PT_PIPE")) == 0);
+    if (pair_transform_dma_applicable(a, count)) return launch_pair_transform_dma(a, count, st);
     if (pipe_on && a.lead_sym && a.in_lower && a.rs_lower && a.in_pairs && (npad == 16 || npad == 32)) {
-        const int mode = (a.out && a.out_pairs && !a.packed && !a.k3) ? 0 : (a.packed && a.sym8 && !a.out) ? 1 : -1;
+        const int mode = a.k3 ? -1 : (a.out && a.out_pairs && !a.packed) ? 0 : (a.packed && a.sym8 && !a.out) ? 1 : -1;
         const size_t npairs = (size_t)n * (n + 1) / 2;
         const size_t lds = sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 16 + 16);
         static const bool pipe4_on = !(getenv("EVC_PT_PIPE4") && atoi(getenv("EVC_PT_PIPE4")) == 0);
-        if (pipe4_on && mode >= 0 && count < 4 && !a.k3 && npairs >= 8) {
+        if (pipe4_on && mode >= 0 && count < 4 && npairs >= 8) {
             // a few geometries: tiles of 4 pairs, one per workgroup (twice the workgroups, half the length)
             a.tiles_per_wg = 1;
             const size_t lds4 = sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 8 + 8);
@@ -1414,7 +1370,7 @@ __global__ __launch_bounds__(256) void unpack8_half_kernel(const double *__restr
 // Dense (pair, pair) form of the same: SB[u][v] = 4 p8[tri(max(u,v), min(u,v))], u = tri(i,j), v = tri(k,l) -- the
 // symmetric matrix the compressed vector is the lower triangle of.  One wave per row u.
 __global__ __launch_bounds__(256) void unpack8_pairs_kernel(const double *__restrict__ p, int64_t sp, int n,
-                                                            double *__restrict__ SB, int64_t sws, int count) {
+                                                            double *__restrict__ SB, int64_t sws, int count, int ld) {
     const int npairs = n * (n + 1) / 2;
     const int bpg = (npairs + 3) / 4;   // workgroups per geometry
     const int nx = count & ~7;
@@ -1433,7 +1389,7 @@ __global__ __launch_bounds__(256) void unpack8_pairs_kernel(const double *__rest
     const int u = blk * 4 + wave;
     if (u >= npairs) return;
     p += (int64_t)geom * sp;
-    double *sb = SB + (int64_t)geom * sws + (int64_t)u * npairs;
+    double *sb = SB + (int64_t)geom * sws + (int64_t)u * ld;   // (rows at the pitch pair_ld(n) of the pipeline's dense forms)
     for (int v = lane; v < npairs; v += 64) sb[v] = 4.0 * (u >= v ? p[tri_index(u, v)] : p[tri_index(v, u)]);
 }
 
@@ -1442,7 +1398,7 @@ int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t 
     if (lead_half == 2 && !G) {
         const int bpg = (n * (n + 1) / 2 + 3) / 4;
         hipLaunchKernelGGL(unpack8_pairs_kernel, dim3((unsigned)(bpg * count)), dim3(256), 0, st, packed, sp, n, SB,
-                           sws, count);
+                           sws, count, pair_ld(n));
         EVC_LAUNCH_CHECK("unpack8_pairs");
         return 0;
     }
@@ -1599,180 +1555,10 @@ __global__ __launch_bounds__(256) void y2_sb_kernel(const double *__restrict__ S
     }
 }
 
-// Folded form for the symmetric pipeline: SB is only valid for i >= j, l <= k and K3 is K3p[j][tri(k,l)][:] =
-// (l < k ? 2 : 1) K3[j][k][l][:]; both are symmetric under i <-> j resp. k <-> l, so
-//   partial[slab][i][a] = sum_j sum_{l <= k} SB[max(i,j)][min(i,j)][k][l] K3p[j][tri(k,l)][a].
-// A K step covers 8 consecutive l of one (j,k) row: k/8 + 1 steps per row.  (Variant for the N^4-addressed SB that
-// is written when the caller wants the unpacked 2-RDM; the usual case is y2_pairs_kernel below.)
-template <int NT>
-__global__ __launch_bounds__(256) void y2_fold_kernel(const double *__restrict__ SB, const double *__restrict__ K3,
-                                                      int n, double *__restrict__ partial, int64_t sws, int pairs) {
-    __shared__ double red[4][NT * 16][NT * 16 + 1];
-    SB += (int64_t)blockIdx.y * sws;
-    K3 += (int64_t)blockIdx.y * sws;
-    partial += (int64_t)blockIdx.y * sws;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    int spj = 0;  // steps per j
-    for (int k = 0; k < n; ++k) spj += k / 8 + 1;
-    const int64_t nsteps = (int64_t)n * spj;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    const int64_t per = (nsteps + nw - 1) / nw;
-    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t s0 = w * per, s1 = min(nsteps, s0 + per);
-    // pairs: SB is the dense (pair, pair) matrix SB[tri(i,j)][tri(k,l)] (rows are not 16-byte aligned)
-    const int npairs = n * (n + 1) / 2;
-    const bool even = (n & 1) == 0 && !pairs;  // every (i,j,k) row of SB starts 16-byte aligned
-    d4 acc[NT][NT];
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int64_t s = s0; s < s1; ++s) {
-        const int j = (int)(s / spj);
-        const int r = (int)(s - (int64_t)j * spj);
-        int b = 0;  // k / 8: 8 rows with b + 1 steps each
-        while (4 * (b + 1) * (b + 2) <= r) ++b;
-        const int rp = r - 4 * b * (b + 1);
-        const int k = 8 * b + rp / (b + 1), ls = rp % (b + 1);
-        const int l = ls * 8 + 2 * l4;  // this lane's K slots: l, l + 1
-        const bool v0 = l <= k, v1 = l + 1 <= k;
-        // (the weight 2 of l < k is folded into K3 by the pair transform that wrote it)
-        const double *kb = K3 + ((int64_t)j * npairs + k * (k + 1) / 2 + l) * n;
-        double a0[NT], a1[NT], b0[NT], b1[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int i = t * 16 + l15;
-            const bool iok = i < n;
-            const int ii = iok ? i : 0;
-            const int hi = ii > j ? ii : j, lo = ii > j ? j : ii;
-            const double *ap = pairs ? SB + (int64_t)(hi * (hi + 1) / 2 + lo) * npairs + k * (k + 1) / 2 + l
-                                     : SB + (((int64_t)hi * n + lo) * n + k) * n + l;
-            double2 af;
-            if (even) af = (iok && v0) ? *reinterpret_cast<const double2 *>(ap) : make_double2(0.0, 0.0);
-            else af = make_double2((iok && v0) ? ap[0] : 0.0, (iok && v1) ? ap[1] : 0.0);
-            a0[t] = (iok && v0) ? af.x : 0.0;
-            a1[t] = (iok && v1) ? af.y : 0.0;
-            b0[t] = (iok && v0) ? kb[i] : 0.0;
-            b1[t] = (iok && v1) ? kb[n + i] : 0.0;
-        }
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(a0[ti], b0[ta], acc[ti][ta]);
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(a1[ti], b1[ta], acc[ti][ta]);
-    }
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
-    __syncthreads();
-    double *dst = partial + (int64_t)blockIdx.x * n * n;
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int i = idx / n, a = idx % n;
-        dst[idx] = (red[0][i][a] + red[1][i][a]) + (red[2][i][a] + red[3][i][a]);
-    }
-}
-
-// The usual case: SB dense (pair, pair), SB[tri(i,j)][v], and K3p[j][v][:]: for every j one contiguous K range
-// v = 0..n(n+1)/2-1, 8 consecutive v per step.
-template <int NT>
-__global__ __launch_bounds__(256) void y2_pairs_kernel(const double *__restrict__ SB, const double *__restrict__ K3,
-                                                       int n, double *__restrict__ partial, int64_t sws) {
-    __shared__ double red[4][NT * 16][NT * 16 + 1];
-    SB += (int64_t)blockIdx.y * sws;
-    K3 += (int64_t)blockIdx.y * sws;
-    partial += (int64_t)blockIdx.y * sws;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int npairs = n * (n + 1) / 2;
-    const int spj = (npairs + 7) / 8;  // steps per j
-    const int64_t nsteps = (int64_t)n * spj;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    const int64_t per = (nsteps + nw - 1) / nw;
-    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t s0 = w * per, s1 = min(nsteps, s0 + per);
-    d4 acc[NT][NT];
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int64_t s = s0; s < s1; ++s) {
-        const int j = (int)(s / spj);
-        const int v = (int)(s - (int64_t)j * spj) * 8 + 2 * l4;   // this lane's K slots: v, v + 1
-        const bool v0 = v < npairs, v1 = v + 1 < npairs;
-        const double *kb = K3 + ((int64_t)j * npairs + v) * n;
-        double a0[NT], a1[NT], b0[NT], b1[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int i = t * 16 + l15;
-            const bool iok = i < n;
-            const int ii = iok ? i : 0;
-            const int hi = ii > j ? ii : j, lo = ii > j ? j : ii;
-            const double *ap = SB + (int64_t)(hi * (hi + 1) / 2 + lo) * npairs + v;
-            a0[t] = (iok && v0) ? ap[0] : 0.0;
-            a1[t] = (iok && v1) ? ap[1] : 0.0;
-            b0[t] = (iok && v0) ? kb[i] : 0.0;
-            b1[t] = (iok && v1) ? kb[n + i] : 0.0;
-        }
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(a0[ti], b0[ta], acc[ti][ta]);
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(a1[ti], b1[ta], acc[ti][ta]);
-    }
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
-    __syncthreads();
-    double *dst = partial + (int64_t)blockIdx.x * n * n;
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int i = idx / n, a = idx % n;
-        dst[idx] = (red[0][i][a] + red[1][i][a]) + (red[2][i][a] + red[3][i][a]);
-    }
-}
-
-int launch_y2_fold(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, int pairs,
-                   hipStream_t st) {
-    if (pairs) {
-        const dim3 grid((unsigned)y2_slab_count(), (unsigned)count);
-        switch ((n + 15) / 16) {
-            case 1: hipLaunchKernelGGL(y2_pairs_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
-            case 2: hipLaunchKernelGGL(y2_pairs_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
-            case 3: hipLaunchKernelGGL(y2_pairs_kernel<3>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
-            case 4: hipLaunchKernelGGL(y2_pairs_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, partial, sws); break;
-            default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
-        }
-        EVC_LAUNCH_CHECK("y2_pairs");
-        return 0;
-    }
-    const int nt = (n + 15) / 16;
-    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count);
-    switch (nt) {
-        case 1: hipLaunchKernelGGL(y2_fold_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
-        case 2: hipLaunchKernelGGL(y2_fold_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
-        case 3: hipLaunchKernelGGL(y2_fold_kernel<3>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
-        case 4: hipLaunchKernelGGL(y2_fold_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, partial, sws, pairs); break;
-        default: set_error("y2: n=%d not supported by the gradient path (1..64)", n); return -1;
-    }
-    EVC_LAUNCH_CHECK("y2_fold");
-    return 0;
-}
-
 // ------------------------------------------------------------------ Y2 with the half-transformed integrals recomputed
-// y2_pairs_kernel above reads K3p[j][v][a] = mult(v) (M1_v X)[a][j], which the second pair step of the energy phase
-// has to store (107 MB per 32 geometries at N = 30: +18 us there) and this contraction to read back.  M1_v -- row v of
+// The reference's Y2 = sum K3 . Gamma~ needs K3p[j][v][a] = mult(v) (M1_v X)[a][j]; rounds 1-2 had the second pair step of
+// the energy phase store it (107 MB per 32 geometries at N = 30: +18 us there) and a split-K contraction read it back
+// (y2_pairs_kernel, removed in round 4).  M1_v -- row v of
 // the dense (pair, pair) intermediate of the FIRST pair step, a symmetric N x N matrix -- is 16x smaller, and
 // SB[tri(i,j)][v] = SB[v][tri(i,j)] is a contiguous row of the symmetric SB as well, so one wave per pair v does
 //   H^T = X^T M1_v            (32 MFMAs at N <= 32; X fragments as A operand, the fragments of the symmetric M1_v as B)
@@ -1789,7 +1575,7 @@ __global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict_
     constexpr int NT = NPAD / 16;
     constexpr int RAWN = (NPAD * (NPAD + 1) / 2 + 1 + 127) / 128;
     extern __shared__ __align__(16) double sm[];
-    const int npairs = n * (n + 1) / 2;
+    const int npairs = n * (n + 1) / 2, ld = pair_ld(n);   // both operands are dense (pair, pair) forms of the pipeline
     const int64_t g = blockIdx.y;
     SB += g * sws;
     M1 += g * sws;
@@ -1824,7 +1610,7 @@ __global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict_
         }
         d2 rawM[RAWN], rawT[RAWN];
         auto fetch = [&](const double *base, int e, d2 (&raw)[RAWN]) -> int {
-            const double *row = base + (int64_t)(e < npairs ? e : 0) * npairs;
+            const double *row = base + (int64_t)(e < npairs ? e : 0) * ld;
             const int d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
             const double *w0 = row - d_;
             const int lim = npairs + d_;
@@ -1932,10 +1718,7 @@ static int y2_fused_tiles(int n, int count) {
     while ((ntiles + t - 1) / t > y2_slab_capacity(n)) ++t;
     return t;
 }
-bool y2_fused_available(int n) {
-    static const bool on = !(getenv("EVC_Y2_FUSED") && atoi(getenv("EVC_Y2_FUSED")) == 0);
-    return on && n >= 1 && n <= kPairTransformMaxN;
-}
+bool y2_fused_available(int n) { return n >= 1 && n <= kPairTransformMaxN; }
 int y2_fused_slabs(int n, int count) {
     const int ppt = y2_fused_ppt(count);
     const int ntiles = (n * (n + 1) / 2 + ppt - 1) / ppt, t = y2_fused_tiles(n, count);
@@ -2025,8 +1808,8 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
     const bool pair_blocks = a.presym && a.fold_cd && a.ip1_s2kl;
     const int nb1 = pair_blocks ? n * (n + 1) / 2 : n * nchunk;
     if (pair_blocks && (int)blockIdx.x < nb1) {
-        // int2e_ip1 packed in (c,d), c >= d, against the dense (pair, pair) AO-basis 2-RDM G[tri(m,b)][v] (weight 2 for
-        // c != d folded in by the last rotation step): one block per unordered pair {m, b} -- the row G[tri(hi,lo)][:]
+        // int2e_ip1 packed in (c,d), c >= d, against the dense (pair, pair) AO-basis 2-RDM G[tri(m,b)][v] (rows at the
+        // pitch pair_ld(n); the weight 2 of c != d is applied here): one block per unordered pair {m, b} -- the row G[tri(hi,lo)][:]
         // is read once and contracted with ip1[x][hi][lo][:] (-> t2[x][hi], filed under partner lo) and, for
         // hi != lo, with ip1[x][lo][hi][:] (-> t2[x][lo], partner hi): 7 contiguous streams of n(n+1)/2 doubles
         const double *__restrict__ ip1 = a.ip1 + g * a.sip1;
@@ -2034,13 +1817,14 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
         const int npr = n * (n + 1) / 2;
         const int pidx = blockIdx.x, hi = tri_row_small(pidx), lo = pidx - hi * (hi + 1) / 2;
         const int64_t len = (int64_t)n * npr;          // one (x, m) block of ip1
-        const double *__restrict__ gr = G + (int64_t)pidx * npr;
+        const double *__restrict__ gr = G + (int64_t)pidx * pair_ld(n);
         const double *__restrict__ qh = ip1 + ((int64_t)hi * n + lo) * npr;
         const double *__restrict__ ql = ip1 + ((int64_t)lo * n + hi) * npr;
         const bool both = hi != lo;
         double ah[3] = {0.0, 0.0, 0.0}, al[3] = {0.0, 0.0, 0.0};
         for (int v = threadIdx.x; v < npr; v += 256) {
-            const double gv = gr[v];
+            const int vc = tri_row_small(v);
+            const double gv = gr[v] * (v == vc * (vc + 3) / 2 ? 1.0 : 2.0);   // multiplicity of the pair (c,d), c >= d
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
                 ah[x] = fma(qh[(int64_t)x * n * len + v], gv, ah[x]);
@@ -2076,48 +1860,7 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
         const int m = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         const int64_t e0 = (int64_t)ch * 256 * kIp1PerThread;
-        if (a.presym && a.fold_cd && a.ip1_s2kl) {
-            // int2e_ip1 packed in (c,d), c >= d: per (x,m) one dense [b][v] block of n * n(n+1)/2 doubles; the AO-basis
-            // 2-RDM comes as the dense (pair, pair) matrix G[tri(max(m,b),min(m,b))][v] with the weight 2 for c != d
-            // already folded in (out_pairs of the last rotation step): two contiguous streams per lane
-            const int npr = n * (n + 1) / 2;
-            const int64_t len = (int64_t)n * npr;
-            const double *__restrict__ q0 = ip1 + (int64_t)m * len;
-            const double *__restrict__ q1 = q0 + (int64_t)n * len;
-            const double *__restrict__ q2 = q1 + (int64_t)n * len;
-            int64_t per = (len + nchunk - 1) / nchunk;
-            per += per & 1;   // even, so that 16-byte pairs never straddle two chunks
-            const int64_t e1 = min(len, (int64_t)(ch + 1) * per);
-            const bool al = (len & 1) == 0;   // every (x,m) block starts 16-byte aligned
-            for (int64_t e = (int64_t)ch * per + 2 * threadIdx.x; e < e1; e += 512) {
-                double gx = 0.0, gy = 0.0;
-                const bool two = e + 1 < e1;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int64_t ee = e + h;
-                    if (h == 0 || two) {
-                        const int b = (int)(ee / npr), v = (int)(ee - (int64_t)b * npr);
-                        const int hi = b <= m ? m : b, lo = b <= m ? b : m;
-                        const double gv = G[(int64_t)(hi * (hi + 1) / 2 + lo) * npr + v];
-                        if (h == 0) gx = gv;
-                        else gy = gv;
-                    }
-                }
-                double2 p0, p1, p2;
-                if (al && two) {
-                    p0 = *reinterpret_cast<const double2 *>(q0 + e);
-                    p1 = *reinterpret_cast<const double2 *>(q1 + e);
-                    p2 = *reinterpret_cast<const double2 *>(q2 + e);
-                } else {
-                    p0 = make_double2(q0[e], two ? q0[e + 1] : 0.0);
-                    p1 = make_double2(q1[e], two ? q1[e + 1] : 0.0);
-                    p2 = make_double2(q2[e], two ? q2[e + 1] : 0.0);
-                }
-                a0 = fma(p0.y, gy, fma(p0.x, gx, a0));
-                a1 = fma(p1.y, gy, fma(p1.x, gx, a1));
-                a2 = fma(p2.y, gy, fma(p2.x, gx, a2));
-            }
-        } else if (a.presym && a.fold_cd && (n & 1) == 0) {
+        if (a.presym && a.fold_cd && (n & 1) == 0) {
             // symmetrised operand that is only valid for d <= c (and symmetric in c <-> d, like ip1 itself): the
             // dot runs over the lower triangles with weight 2 off the diagonal.  The 16-byte pairs (d, d+1), d even,
             // d <= c, of one b are numbered row by row (rows 2h and 2h+1 hold h+1 pairs each, h(h+1) pairs precede

@@ -194,7 +194,7 @@ def s_gaussian_mol(coords, charges: Optional[Sequence[float]] = None,
     if nelec is None:
         nelec = ((ne + 1) // 2, ne // 2)
     return HChainMol(S=S, hcore=hcore, eri=eri, ipovlp=ipovlp, dhcore=dhcore, eri_ip1=eri_ip1,
-                     aoslices=aoslices, enuc=float(enuc), gnuc=gnuc, coords=R, nelec=tuple(nelec), charges=Z,
+                     aoslices=aoslices, enuc=float(enuc), gnuc=gnuc, integral_symmetry=True, coords=R, nelec=tuple(nelec), charges=Z,
                      exponents=tuple(float(x) for x in ex), coefficients=tuple(float(x) for x in co))
 
 

@@ -36,6 +36,11 @@ class AOArrays:
     aoslices: np.ndarray   # (A,2) int64  [start, stop) of each atom's AOs
     enuc: float
     gnuc: np.ndarray       # (A,3)
+    # Declared index symmetry of ``eri`` (8-fold) and ``eri_ip1`` (last two indices), as real two-electron integrals
+    # have it: True / False spare the numerical check of ``integrals_have_symmetry`` (the default compression mode
+    # "auto" of the mol-level API asks once per training set), None = unknown, checked.  ``eri`` may also be handed
+    # over packed, (Ms, Ms) like ``aosym="s4"``, and ``eri_ip1`` as (3,N,N,Ms) like ``aosym="s2kl"``.
+    integral_symmetry: Optional[bool] = None
 
     @property
     def nao(self) -> int:
@@ -97,7 +102,8 @@ def make_ao_arrays(nao: int, natm: int, seed: int,
         aoslices = np.stack([stops - np.array(ao_sizes), stops], axis=1).astype(np.int64)
     enuc = float(rng.standard_normal())
     gnuc = rng.standard_normal((natm, 3))
-    return AOArrays(S, hcore, eri, ipovlp, dhcore, eri_ip1, aoslices, enuc, gnuc)
+    return AOArrays(S, hcore, eri, ipovlp, dhcore, eri_ip1, aoslices, enuc, gnuc,
+                    integral_symmetry=bool(ip1_rs_symmetric or not with_ip1))
 
 
 def make_trdms(nao: int, ntrain: int, seed: int):

@@ -40,6 +40,13 @@ class StubMole:
         self.verbose = 0
         self.incore_anyway = False
         self.queries = []          # names of the intor calls made (tests look at them)
+        # A real Mole serves libcint integrals, which have the index symmetries of real two-electron integrals; this
+        # stand-in may be built from seeded general tensors (the golden fixtures' eri_ip1): it says so, and the
+        # default compression mode of evcont_amd then keeps the caller's layout for it
+        self.integral_symmetry = getattr(self._ao, "integral_symmetry", None)
+        if self.integral_symmetry is None:
+            from evcont_amd.ab_initio_eigenvector_continuation import integrals_have_symmetry
+            self.integral_symmetry = bool(integrals_have_symmetry(self._ao))
 
     # -- what the reference asks a Mole --------------------------------------------------
     @property

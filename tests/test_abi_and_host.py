@@ -199,13 +199,63 @@ def test_sym8_layout_shape_and_compression_switch():
         assert layout_shape(8, T, n) == (T * (T + 1) // 2, ms * (ms + 1) // 2)
     assert layout_shape(8, 20, 30) == (210, 108345)
     assert layout_shape(2, 20, 30)[1] / layout_shape(8, 20, 30)[1] > 3.7
-    assert aec.get_trdm_compression() in (None, "sym8")
+    assert aec.get_trdm_compression() in (None, "sym8", "auto")
     old = aec.get_trdm_compression()
     try:
         aec.set_trdm_compression("sym8")
         assert aec.get_trdm_compression() == "sym8"
         with pytest.raises(ValueError):
             aec.set_trdm_compression("other")
+    finally:
+        aec.set_trdm_compression(old)
+
+
+def test_default_compression_is_decided_per_call():
+    """The default mode "auto" of the mol-level API (evcont/ab_initio_gradients_loewdin.py:308-379 called with
+    whatever the container holds, MD_utils.py:40-57): the compressed copy only where the caller cannot tell the
+    difference -- Hermitian, no predicted RDMs, integrals with the symmetries of real ones."""
+    from evcont_amd import ab_initio_eigenvector_continuation as aec
+    from evcont_amd.synthetic import make_ao_arrays, make_trdms
+    if "EVCONT_AMD_COMPRESS" not in os.environ:
+        assert aec._mode_from_env() == "auto"
+    sym = make_ao_arrays(5, 2, 1, ip1_rs_symmetric=True)
+    gen = make_ao_arrays(5, 2, 2)                       # eri_ip1 a general tensor (the golden fixtures' kind)
+    assert sym.integral_symmetry is True and gen.integral_symmetry is False
+    assert aec.integrals_have_symmetry(sym) and not aec.integrals_have_symmetry(gen)
+    for ao in (sym, gen):                               # undeclared: checked numerically
+        ao.integral_symmetry = None
+    assert aec.integrals_have_symmetry(sym) and not aec.integrals_have_symmetry(gen)
+    bad = make_ao_arrays(5, 2, 3, ip1_rs_symmetric=True)
+    bad.integral_symmetry = None
+    bad.eri[0, 1, 2, 3] += 1.0e-3                       # eri no longer 8-fold symmetric
+    assert not aec.integrals_have_symmetry(bad)
+    iu, ju = np.tril_indices(5)
+    packed = make_ao_arrays(5, 2, 4, ip1_rs_symmetric=True)
+    packed.integral_symmetry = None
+    packed.eri = packed.eri[iu, ju][:, iu, ju]           # s4
+    packed.eri_ip1 = packed.eri_ip1[:, :, :, iu, ju]     # s2kl
+    assert aec.integrals_have_symmetry(packed)
+
+    class Mole:                                          # anything with .intor is a PySCF molecule: libcint integrals
+        def intor(self, *a, **k):
+            raise AssertionError("not called")
+    assert aec.integrals_have_symmetry(Mole())
+    S1, one1, two1 = make_trdms(5, 2, 5)
+    S2, one2, two2 = make_trdms(5, 2, 6)
+    rc = aec.resolve_compression
+    assert rc("auto", one1, two1, S1, sym) == "sym8"
+    assert rc("auto", one1, two1, S1, sym, hermitian=False) is None
+    assert rc("auto", one1, two1, S1, sym, want_rdms=True) is None
+    assert rc("auto", one2, two2, S2, gen) is None
+    assert rc(None, one1, two1, S1, sym) is None
+    assert rc("sym8", one1, two1, S1, gen) == "sym8" and rc("sym8", one1, two1, S1, gen, want_rdms=True) == "sym8"
+    assert rc("sym8", one1, two1, S1, sym, hermitian=False) is None
+    old = aec.get_trdm_compression()
+    try:
+        aec.set_trdm_compression("auto")
+        assert rc("default", one1, two1, S1, sym) == "sym8"
+        aec.set_trdm_compression(None)
+        assert rc("default", one1, two1, S1, sym) is None
     finally:
         aec.set_trdm_compression(old)
 

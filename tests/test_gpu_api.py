@@ -186,3 +186,55 @@ def test_scanner(load_golden):
     sc0 = get_scanner(mol, None, None, None)
     E0, g0 = sc0(mol)
     assert E0 == float(g["enuc"]) and np.array_equal(g0, g["gnuc"])
+
+
+@pytest.mark.parametrize("n,T,A", [(6, 3, 3), (10, 5, 10)])
+def test_default_call_uses_the_compressed_path(n, T, A):
+    """The reference's call, unchanged (ab_initio_gradients_loewdin.py:308-379 with the container's 6-index arrays,
+    FCI_EVCont.py:106-131; no extra arguments, no environment): with integrals that have the symmetries of real ones
+    the default mode keeps the 8-fold compressed copy resident and runs the symmetric pipeline -- same energy and
+    forces as the oracle on the ORIGINAL arrays; asking for the predicted RDMs switches to the caller's layout."""
+    import evcont_amd.ab_initio_gradients_loewdin as gl
+    import evcont_amd.ab_initio_eigenvector_continuation as evc
+    from evcont_amd import cache, _lib
+    from evcont_amd.synthetic import make_ao_arrays, make_trdms
+    from evcont_amd.MD_utils import get_scanner
+    from oracle import evcont_oracle as orc
+    assert evc.get_trdm_compression() == "auto"
+    S, one, two = make_trdms(n, T, 77 + n)
+    assert two.ndim == 6
+    mol = make_ao_arrays(n, A, 78 + n, ip1_rs_symmetric=True)
+    mol.integral_symmetry = None                      # an array-level molecule that does not say: checked numerically
+    b = orc.AOBundle(mol.S, mol.hcore, mol.eri, mol.ipovlp, mol.dhcore, mol.eri_ip1, mol.aoslices, mol.enuc, mol.gnuc)
+    Eo, go, Do, Go = orc.energy_with_grad(b, one, two, S, True, True)
+    E, grad = gl.get_energy_with_grad(mol, one, two, S)
+    assert abs(E - Eo) < 1e-10
+    np.testing.assert_allclose(grad, go, rtol=0, atol=1e-9)
+    ev = evc._evaluator(one, two, S, A, compress="sym8")
+    assert ev.t.layout == _lib.LAYOUT_SYM8 and ev._primed, "the default call did not run on the compressed copy"
+    assert cache.get(cache.key_of(one, two, S, ("trdms", None))) is None, "the caller's layout was uploaded as well"
+    E2, grad2, D, G = gl.get_energy_with_grad(mol, one, two, S, return_density_matrices=True)
+    assert abs(E2 - Eo) < 1e-10
+    np.testing.assert_allclose(grad2, go, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(D, Do, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(G, np.asarray(Go).reshape(G.shape), rtol=0, atol=1e-10)   # the un-symmetrised 2-RDM
+    # energy-only entry point and the MD scanner take the same decision
+    e, c = evc.approximate_ground_state_OAO(mol, one, two, S)
+    assert abs(e - Eo) < 1e-10
+    sc = get_scanner(mol, one, two, S)
+    Es, gs = sc(mol)
+    assert sc._hev.t.layout == _lib.LAYOUT_SYM8 and sc._hev.packed
+    assert abs(Es - Eo) < 1e-10
+    np.testing.assert_allclose(gs, go, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sc.base.predicted_one_rdm, Do, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(sc.base.predicted_two_rdm, np.asarray(Go).reshape(G.shape), rtol=0, atol=1e-10)
+    # a general eri_ip1 (what the golden fixtures hold): the same call stays on the caller's layout, and is right
+    gen = make_ao_arrays(n, A, 79 + n)
+    S2, one2, two2 = make_trdms(n, T, 80 + n)
+    bg = orc.AOBundle(gen.S, gen.hcore, gen.eri, gen.ipovlp, gen.dhcore, gen.eri_ip1, gen.aoslices, gen.enuc, gen.gnuc)
+    Eg, gg = orc.energy_with_grad(bg, one2, two2, S2)
+    E3, grad3 = gl.get_energy_with_grad(gen, one2, two2, S2)
+    assert abs(E3 - Eg) < 1e-10
+    np.testing.assert_allclose(grad3, gg, rtol=0, atol=1e-9)
+    assert cache.get(cache.key_of(one2, two2, S2, ("trdms", "sym8"))) is None
+    cache.clear()

@@ -211,8 +211,9 @@ def test_sym8_h30_full_size_against_pack2():
 
 def test_sym8_through_the_reference_api(h10_fci, tmp_path):
     """``set_trdm_compression("sym8")`` switches the mol-level entry points (get_energy_with_grad, the
-    *_OAO energies, the MD scanner / trajectory driver, the container's device copy) to the compressed set;
-    results on physical integrals are those of the default path."""
+    *_OAO energies, the MD scanner / trajectory driver, the container's device copy) to the compressed set
+    unconditionally (the default "auto" does so only where the caller cannot tell the difference); results on
+    physical integrals are those of the caller's layout (``None``)."""
     from evcont_amd import ab_initio_eigenvector_continuation as aec
     from evcont_amd.ab_initio_gradients_loewdin import get_energy_with_grad
     from evcont_amd.MD_utils import get_trajectory
@@ -221,11 +222,15 @@ def test_sym8_through_the_reference_api(h10_fci, tmp_path):
     h10 = h10_fci
     S, one, two = h10["overlap"], h10["one_rdm"], h10["two_rdm_pack2"]
     m = s_gaussian_mol(h10["R_test"])
-    assert aec.get_trdm_compression() is None
-    E0, g0 = get_energy_with_grad(m, one, two, S)
-    e0, c0 = aec.approximate_multistate_OAO(m, one, two, S, nroots=3)
-    traj0 = get_trajectory(hydrogen_chain(10, 1.9), S, one, two, dt=5.0, steps=4)
+    assert aec.get_trdm_compression() == "auto"
     try:
+        aec.set_trdm_compression(None)
+        E0, g0 = get_energy_with_grad(m, one, two, S)
+        e0, c0 = aec.approximate_multistate_OAO(m, one, two, S, nroots=3)
+        traj0 = get_trajectory(hydrogen_chain(10, 1.9), S, one, two, dt=5.0, steps=4)
+        aec.set_trdm_compression("auto")
+        Ea, ga = get_energy_with_grad(m, one, two, S)
+        traja = get_trajectory(hydrogen_chain(10, 1.9), S, one, two, dt=5.0, steps=4)
         aec.set_trdm_compression("sym8")
         E1, g1, D1, G1 = get_energy_with_grad(m, one, two, S, return_density_matrices=True)
         e1, c1 = aec.approximate_multistate_OAO(m, one, two, S, nroots=3)
@@ -233,8 +238,10 @@ def test_sym8_through_the_reference_api(h10_fci, tmp_path):
         # hermitian=False keeps working on the layout the caller passed
         en, _ = aec.approximate_ground_state_OAO(m, one, two, S, hermitian=False)
     finally:
-        aec.set_trdm_compression(None)
+        aec.set_trdm_compression("auto")
         cache.clear()
+    assert abs(Ea - E0) < 1e-10 and np.abs(ga - g0).max() < 1e-9
+    np.testing.assert_allclose(traja, traj0, rtol=0, atol=1e-8)
     assert abs(E1 - E0) < 1e-10 and np.abs(g1 - g0).max() < 1e-9
     np.testing.assert_allclose(e1, e0, rtol=0, atol=1e-10)
     np.testing.assert_allclose(traj1, traj0, rtol=0, atol=1e-8)

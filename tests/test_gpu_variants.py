@@ -17,12 +17,12 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
 
 
 @pytest.mark.parametrize("env", [
-    {"EVC_PT_PIPE": "0"},                     # phase-alternating pair transform (pt_kernel) instead of pt_pipe_kernel
-    {"EVC_PT_PIPE": "0", "EVC_PT_ROWBUF": "0"},   # pt_kernel with the per-lane gather
+    {"EVC_PT_PIPE": "0", "EVC_PT_DMA": "0"}, # phase-alternating pair transform (pt_kernel) instead of ptd_kernel / pt_pipe_kernel
+    {"EVC_PT_DMA": "0"},                      # pt_pipe_kernel (operand rows through registers) instead of ptd_kernel (LDS-DMA)
+    {"EVC_PT_PIPE": "0", "EVC_PT_DMA": "0", "EVC_PT_ROWBUF": "0"},   # pt_kernel with the per-lane gather
     {"EVC_PT_PIPE4": "0"},                    # a few geometries through pt_pipe_kernel (8-pair tiles) instead of pt_pipe4_kernel
     {"EVC_PT_TILES": "1"},                    # pipelined pair transform, one tile per workgroup (two matrices per wave)
     {"EVC_PT_TILES": "3"},                    # ... an odd number of tiles (last workgroup ragged)
-    {"EVC_Y2_FUSED": "0"},                    # K3 stored by the second pair step, split-K Y2 over it
     {"EVC_SUBSPACE_FEW": "0"},                # large-T subspace kernel: every call through the Jacobi sweeps
     {"EVC_EIGH_F32": "0"},                    # FP64 Jacobi eigensolvers
     {"EVC_EIGH_F32": "1"},                    # FP32 Jacobi start + refinement

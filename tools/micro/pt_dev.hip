@@ -80,10 +80,6 @@ int main(int argc, char **argv) {
     pn.sout = (int64_t)out_new_sz;
     pn.out_ld = ldp;
     pn.tiles_per_wg = getenv("PT_TILES") ? atoi(getenv("PT_TILES")) : 4;
-    setenv("EVC_PT_DMA", "0", 1);   // `po` through the old kernel whatever the library's default
-    if (!evc::pair_transform_dma_applicable(pn, G) && !(getenv("EVC_PT_DMA_FORCE"))) {
-        // (applicable() reads EVC_PT_DMA once: it was just set to 0 -- the check below is on the arguments only)
-    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
