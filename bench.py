@@ -67,26 +67,15 @@ MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense FP64 matrix peak (v_m
 MAX_G_PER_LAUNCH = 32   # geometries that share one pass over the t-RDM (csrc/gemv_mfma.hip; K8 always)
 
 
-def k5_geometries_per_pass(G: int, rows: int, cols: int) -> int:
-    """Geometries one K5 launch contracts (mirrors csrc/gemv_lds.hip: rows_lds_max_g / lds_pick_nt): the LDS-staged
-    kernel takes up to 64 (four geometry sets) when its row groups have at most 7 tiles, every other kernel 32."""
-    if G <= 32 or os.environ.get("EVC_ROWS_LDS", "1") == "0" or os.environ.get("EVC_ROWS_LDS_G64", "1") == "0":
-        return min(G, MAX_G_PER_LAUNCH)
-    if cols < int(os.environ.get("EVC_ROWS_LDS_MINCOLS", "4096")):
-        return MAX_G_PER_LAUNCH
-    nt = -(-max(rows, 1) // 16)
-    forced = int(os.environ.get("EVC_ROWS_LDS_NT", "0"))
-    best = 0
-    for want in (2, 1):
-        for cand in (7, 4, 2, 14):
-            nrg = -(-nt // cand)
-            if not best and nrg >= want and nrg * cand * 8 <= nt * 9 and nrg <= 30:
-                best = cand
-    if not best:
-        best = min((7, 4, 2, 14), key=lambda c: (-(-nt // c) * c, -c))
-    if forced in (14, 7, 4, 2):
-        best = forced
-    return min(G, 64) if best <= 7 else MAX_G_PER_LAUNCH
+def k5_launch_info(lib, G: int):
+    """(kernel symbol, geometries per launch) of the K5 launch the library made LAST (``evc_profile_kernel``: the
+    launchers record what they enqueue) -- asked of the library instead of mirroring its dispatch rules here."""
+    name = lib.evc_profile_kernel(0).decode()
+    gl = min(G, MAX_G_PER_LAUNCH)
+    if " G=" in name:
+        name, g = name.rsplit(" G=", 1)
+        gl = int(g)
+    return name, gl
 
 
 def parse():
@@ -327,7 +316,9 @@ def main():
             e_check = float(evs[0].energy.reshape(-1)[0].item())
         # every rank's own rate (its G geometries per step over the median of ITS wall times)
         per_rank = [steps * G / float(np.median(r)) for r in dts_rank]
-        gl = k5_geometries_per_pass(G, trd.rows_local, trd.cols)   # geometries per K5 launch (K8: <= 32)
+        k5_name, gl = k5_launch_info(lib, G)                       # the kernel that ran, geometries per K5 launch (K8: <= 32)
+        k8_name = lib.evc_profile_kernel(1).decode()
+        pt_name = lib.evc_profile_kernel(2).decode()
         lps = -(-G // gl)                                          # K5 launches per step
         gl8, lps8 = min(G, MAX_G_PER_LAUNCH), -(-G // MAX_G_PER_LAUNCH)
         # ALGORITHMIC bytes of one K5 / K8 launch: the local two-body rows + the one-body t-RDM once,
@@ -342,6 +333,7 @@ def main():
                 "repeat_values": [steps * job_g / x for x in dts],
                 "k5_ms": k5, "k8_ms": k8, "bytes_per_launch": nbytes, "launches": rows_n.value * lps,
                 "geometries_per_launch": gl, "k5_GBs": nbytes / (k5 * 1e-3) / 1e9,
+                "k5_kernel": k5_name, "k8_kernel": k8_name, "pt_kernel": pt_name,
                 "k8_GBs": (nbytes8 / (k8 * 1e-3) / 1e9) if k8 else None, "last_energy": e_last, "check_energy": e_check,
                 "k5_flops_per_launch": 2.0 * trd.rows_local * trd.cols * gl,
                 "stages": stages, "per_rank": per_rank,
@@ -454,8 +446,12 @@ def main():
                          "region": f"the timed region `value` is measured in ({m['streams']} stream(s); other batches' "
                                    f"kernels share the chip when > 1)",
                          "bytes_per_launch": m["bytes_per_launch"], "ms_per_launch": m["k5_ms"],
-                         "launches": m["launches"], "geometries_per_launch": m["geometries_per_launch"]},
-            "kernels": {"k5_rows_ms": m["k5_ms"], "k8_cols_ms": m["k8_ms"], "k8_cols_GBs": m["k8_GBs"]},
+                         "launches": m["launches"], "geometries_per_launch": m["geometries_per_launch"],
+                         # the symbol the library launched for K5 in this region (evc_profile_kernel), not the profile's
+                         "kernel_ran": m["k5_kernel"]},
+            "kernels": {"k5_rows_ms": m["k5_ms"], "k8_cols_ms": m["k8_ms"], "k8_cols_GBs": m["k8_GBs"],
+                        "k5_kernel_ran": m["k5_kernel"], "k8_kernel_ran": m["k8_kernel"],
+                        "pair_transform_kernel_ran": m["pt_kernel"]},
             "last_energy": m["last_energy"],
             "roofline_step": step_roofline(m["ms_per_step"], m["geometries_per_step"] if world == 1 else G),
             # what the collectives library itself reports, and what each rank delivered on its own clock: in the
@@ -537,7 +533,7 @@ def main():
             # `roofline` describes K5 inside the headline region; the same kernel with the device to itself:
             out["roofline"]["uncontended"] = {
                 "achieved": one["k5_GBs"], "frac": one["k5_GBs"] / HBM_PEAK_GBS, "ms_per_launch": one["k5_ms"],
-                "launches": one["launches"],
+                "launches": one["launches"], "kernel_ran": one["k5_kernel"],
                 "region": "single_stream leg (HIP events on the launch stream, same batches, one stream)"}
             # the other multi-workgroup stages of the same leg, against their own rooflines
             st = stg["stages"]
@@ -547,8 +543,8 @@ def main():
                 pairs = n * (n + 1) // 2 if a.layout == "sym8" else n * n
                 flops = G * pairs * 4.0 * n ** 3          # two N x N x N products per leading pair, unpadded
                 tf = flops / (st["pair_transform_ms"] * 1e-3) / 1e12
-                others.append({"kernel": "pt_pipe_kernel: one fused pair step of a four-index rotation (4 launches per "
-                                         "evaluation, the largest share of the step)", "bound": "mfma",
+                others.append({"kernel": f"{stg['pt_kernel']}: one fused pair step of a four-index rotation (4 launches "
+                                         "per evaluation, the largest share of the step)", "bound": "mfma",
                                "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / MFMA_F64_PEAK_TFLOPS, "flops_per_launch": flops,
                                "ms_per_launch": st["pair_transform_ms"]})

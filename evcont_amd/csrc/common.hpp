@@ -15,6 +15,9 @@ constexpr int kWave = 64;  // CDNA wavefront
 
 // ---- host side -------------------------------------------------------------------
 void set_error(const char *fmt, ...);
+// Name of the kernel a launcher just enqueued for a stage (EVC_PROF_* of include/evcont_hip.h): what a measurement of
+// that stage names as the kernel it timed (evc_profile_kernel).  printf-style; the last launch of a stage wins.
+void note_kernel(int stage, const char *fmt, ...);
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define EVC_REQUIRE(cond, ...)            \

@@ -536,6 +536,7 @@ static int lds_launch(const GemvRowsLaunch &L, const LdsBlockMap &M, int nblocks
     static LdsAttr attr;
     if (int rc = allow_dynamic_lds(gemv_rows_lds_kernel<GS, NT, NCH>, attr, lds, "gemv_rows_lds")) return rc;
     hipLaunchKernelGGL((gemv_rows_lds_kernel<GS, NT, NCH>), dim3(nblocks), dim3(256), lds, st, L, M, g0, G);
+    note_kernel(EVC_PROF_ROWS, "gemv_rows_lds_kernel<%d,%d,%d> G=%d", GS, NT, NCH, G);
     return 0;
 }
 
@@ -1022,6 +1023,7 @@ static int cols_lds_launch(const GemvColsLaunch &L, int nblk1, int nblk0, size_t
     static LdsAttr attr;
     if (int rc = allow_dynamic_lds(gemv_cols_lds_kernel<GS, D0, D1, NW>, attr, 160 * 1024, "gemv_cols_lds")) return rc;
     hipLaunchKernelGGL((gemv_cols_lds_kernel<GS, D0, D1, NW>), dim3(nblk0 + nblk1), dim3(64 * NW), lds, st, L, nblk1, g0, G);
+    note_kernel(EVC_PROF_COLS, "gemv_cols_lds_kernel<%d,%d,%d,%d>", GS, D0, D1, NW);
     return 0;
 }
 
@@ -1067,6 +1069,7 @@ int launch_gemv_cols_lds_slab(const GemvColsLaunch &L, int g0, int G, hipStream_
         if ((rc = allow_dynamic_lds(gemv_cols_lds_slab_kernel<2, NTW_>, attr, 160 * 1024, "gemv_cols_lds_slab"))) \
             return rc;                                                                                       \
         hipLaunchKernelGGL((gemv_cols_lds_slab_kernel<2, NTW_>), dim3(nblk0 + nblk1), dim3(512), lds, st, L, nblk1, g0, G); \
+        note_kernel(EVC_PROF_COLS, "gemv_cols_lds_slab_kernel<2,%d>", NTW_);                                  \
     }
     EVC_SLAB_CASE(1) EVC_SLAB_CASE(2) EVC_SLAB_CASE(3) EVC_SLAB_CASE(4)
 #undef EVC_SLAB_CASE

@@ -325,6 +325,7 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, h
     case 100 * MAXT_ + 10 * MINW_ + PIPE_:                                                             \
         hipLaunchKernelGGL((gemv_rows_mfma_pipe_kernel<GS_, MAXT_, MINW_, PIPE_ != 0>), dim3(nb0 + nb1), \
                            dim3(256), 0, st, L, g0, G);                                                \
+        note_kernel(EVC_PROF_ROWS, "gemv_rows_mfma_pipe_kernel<%d,%d,%d,%d> G=%d", GS_, MAXT_, MINW_, PIPE_, G); \
         break;
     if (gs == 2) {
         switch (shape) {
@@ -532,6 +533,7 @@ static void cols_mfma_rs_launch(GemvColsLaunch L, int g0, int G, hipStream_t st)
     L.nblk0 = (int)ceil_div(L.p[0].cols, 32);
     const int total = L.nblk0 + (int)ceil_div(L.p[1].cols, 32);
     hipLaunchKernelGGL((gemv_cols_mfma_rs_kernel<KSN, MINW, GS>), dim3(total), dim3(256), 0, st, L, g0, G);
+    note_kernel(EVC_PROF_COLS, "gemv_cols_mfma_rs_kernel<%d,%d,%d>", KSN, MINW, GS);
 }
 
 template <int CT, int KSN, int MINW, int GS>
@@ -547,6 +549,7 @@ static int cols_mfma_launch(GemvColsLaunch L, int g0, int G, hipStream_t st) {
                                    kRowTile * 16 * GS * (int)sizeof(double), "gemv_cols_mfma"))
         return rc;
     hipLaunchKernelGGL((gemv_cols_mfma_kernel<CT, KSN, MINW, GS>), dim3(total), dim3(256), lds, st, L, g0, G);
+    note_kernel(EVC_PROF_COLS, "gemv_cols_mfma_kernel<%d,%d,%d,%d>", CT, KSN, MINW, GS);
     return 0;
 }
 

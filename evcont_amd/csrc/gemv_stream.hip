@@ -251,6 +251,7 @@ static void rows_launch(GemvRowsLaunch L, int g0, hipStream_t st) {
         L.p[k].nblocks = L.p[k].nblocks ? (int)(ceil_div(L.p[k].rows, RB) * L.p[k].nspans) : 0;
     L.nblk0 = L.p[0].nblocks;
     hipLaunchKernelGGL((gemv_rows_kernel<RB, G>), dim3(L.p[0].nblocks + L.p[1].nblocks), dim3(256), 0, st, L, g0);
+    note_kernel(EVC_PROF_ROWS, "gemv_rows_kernel<%d,%d> G=%d", RB, G, G);
 }
 
 template <int RBW, int G>
@@ -260,6 +261,7 @@ static void rows_wr_launch(GemvRowsLaunch L, int g0, hipStream_t st) {
     L.nblk0 = L.p[0].nblocks;
     hipLaunchKernelGGL((gemv_rows_wr_kernel<RBW, G, 16 / RBW>), dim3(L.p[0].nblocks + L.p[1].nblocks), dim3(256), 0, st,
                        L, g0);
+    note_kernel(EVC_PROF_ROWS, "gemv_rows_wr_kernel<%d,%d,%d> G=%d", RBW, G, 16 / RBW, G);
 }
 
 static int mfma_min_g() {
@@ -491,10 +493,12 @@ static void cols_launch(const GemvColsLaunch &Lin, int total, int g0, hipStream_
         L.nblk0 = (int)ceil_div(L.p[0].cols, 128);
         const int tot = L.nblk0 + (int)ceil_div(L.p[1].cols, 128);
         hipLaunchKernelGGL((gemv_cols_rs_kernel<G>), dim3(tot), dim3(256), 0, st, L, g0);
+        note_kernel(EVC_PROF_COLS, "gemv_cols_rs_kernel<%d>", G);
         return;
     }
     const GemvColsLaunch &L = Lin;
     hipLaunchKernelGGL((gemv_cols_kernel<G>), dim3(total), dim3(256), 0, st, L, g0);
+    note_kernel(EVC_PROF_COLS, "gemv_cols_kernel<%d>", G);
 }
 
 // Row-slab form for a NARROW matrix with MANY rows -- the one-body t-RDM of a large training set, (T^2, N^2): 10 000 x 784

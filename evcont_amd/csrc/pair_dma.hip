@@ -76,6 +76,14 @@ __device__ __forceinline__ void wait_vm_dyn(int k) {
     else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
 }
 
+// (memory, LDS and scalar instructions at a higher priority than the MFMAs: a wave that issues MFMAs back to back
+//  otherwise keeps the issue port from its SIMD mate's loads and stores, profiles/mfma_f64_coissue.txt)
+#ifdef EVC_PTD_NO_SETPRIO
+#define EVC_PTD_PRIO(x_) do { } while (0)
+#else
+#define EVC_PTD_PRIO(x_) __builtin_amdgcn_s_setprio(x_)
+#endif
+
 }  // namespace
 
 // MODE 0: dense (pair, pair) result out[tri(r',s')][tri(p,q)], pitch out_ld.
@@ -235,9 +243,9 @@ __global__ __launch_bounds__(256, 2) void ptd_kernel(PairTransformArgs a) {
                 for (int m = 0; m < NT * NT; ++m) {
                     if constexpr (COMPUTE) {
                         const int rt = m / NT, st = m % NT;
-                        __builtin_amdgcn_s_setprio(0);
+                        EVC_PTD_PRIO(0);
                         h[rt][st] = mfma_f64(mf[rt][kk], xf[kk][st], kk == 0 ? zero : h[rt][st]);
-                        __builtin_amdgcn_s_setprio(1);
+                        EVC_PTD_PRIO(1);
                     }
                     const int f = kk * 2 + m;
                     if (m < 2 && f < 12) {
@@ -258,7 +266,11 @@ __global__ __launch_bounds__(256, 2) void ptd_kernel(PairTransformArgs a) {
             const int jt = (ODD ? i - 3 : i - 2) >> 1;
             constexpr unsigned bimm = (TP ^ 1u) * 8u * kPdP;
             char *ob = outg + (int64_t)(8 * (t_begin + jt)) * 8;
+#ifdef EVC_PTD_K0
+            const int K = 0;
+#else
             const int K = (MODE == 0 && i >= 3) ? (ODD ? cntA : cntB) : 0;
+#endif
             d2 dv[4];
             [[maybe_unused]] int kd = 0;       // MODE 1: the pass that holds the diagonal u == v of this tile's columns
             [[maybe_unused]] d2 cf = {1.0, 1.0};   // MODE 1: multiplicities of the thread's two columns
@@ -285,9 +297,9 @@ __global__ __launch_bounds__(256, 2) void ptd_kernel(PairTransformArgs a) {
                 for (int m = 0; m < 3; ++m) {
                     if constexpr (COMPUTE) {
                         const int it = m == 0 ? 0 : 1, st = m == 2 ? 1 : 0;
-                        __builtin_amdgcn_s_setprio(0);
+                        EVC_PTD_PRIO(0);
                         nn[it][st] = mfma_f64(xf[kk][it], h[kk / 4][st][kk % 4], kk == 0 ? zero : nn[it][st]);
-                        __builtin_amdgcn_s_setprio(1);
+                        EVC_PTD_PRIO(1);
                         if (m == 0) {
                             // the operand row of matrix i+1 (requested one iteration ago) has landed -> fragments;
                             // then the row of matrix i+2 is requested into the same LDS row
@@ -373,10 +385,12 @@ int launch_pair_transform_dma(const PairTransformArgs &a_in, int count, hipStrea
         static LdsAttr attr1;
         if (int rc = allow_dynamic_lds(ptd_kernel<1>, attr1, 160 * 1024, "pair_transform_dma")) return rc;
         hipLaunchKernelGGL((ptd_kernel<1>), grid, dim3(256), kPdLds1, st, a);
+        note_kernel(EVC_PROF_PAIR_TRANSFORM, "ptd_kernel<1>");
     } else {
         static LdsAttr attr;
         if (int rc = allow_dynamic_lds(ptd_kernel<0>, attr, 160 * 1024, "pair_transform_dma")) return rc;
         hipLaunchKernelGGL((ptd_kernel<0>), grid, dim3(256), kPdLds, st, a);
+        note_kernel(EVC_PROF_PAIR_TRANSFORM, "ptd_kernel<0>");
     }
     EVC_LAUNCH_CHECK("pair_transform_dma");
     return 0;

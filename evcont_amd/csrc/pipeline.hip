@@ -29,6 +29,14 @@ void set_error(const char *fmt, ...) {
 // duration inside the real per-geometry DAG.  Process-wide, off by default.
 // Stages: EVC_PROF_* of include/evcont_hip.h.
 constexpr int kProfStages = 8;
+static char g_kernel_ran[kProfStages][96];
+void note_kernel(int stage, const char *fmt, ...) {
+    if (stage < 0 || stage >= kProfStages) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel_ran[stage], sizeof(g_kernel_ran[stage]), fmt, ap);
+    va_end(ap);
+}
 constexpr int kProfPerSample = 16;   // event pairs one evaluation can record
 struct Prof {
     std::atomic<bool> on{false};
@@ -783,6 +791,10 @@ extern "C" int evc_profile_end(double *rows_ms, int *rows_n, double *cols_ms, in
     g_prof.cap = g_prof.n = 0;
     g_prof.on = false;
     return 0;
+}
+
+extern "C" const char *evc_profile_kernel(int stage) {
+    return (stage >= 0 && stage < kProfStages) ? g_kernel_ran[stage] : "";
 }
 
 extern "C" int evc_profile_select(unsigned stage_mask) {

@@ -1081,6 +1081,7 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
             else if (mode == 0) EVC_PT_PIPE4_CASE(32, 0);
             else EVC_PT_PIPE4_CASE(32, 1);
 #undef EVC_PT_PIPE4_CASE
+            note_kernel(EVC_PROF_PAIR_TRANSFORM, "pt_pipe4_kernel<%d,%d>", npad, mode);
             EVC_LAUNCH_CHECK("pair_transform_pipe4");
             return 0;
         }
@@ -1097,6 +1098,7 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
             else if (mode == 0) EVC_PT_PIPE_CASE(32, 0);
             else EVC_PT_PIPE_CASE(32, 1);
 #undef EVC_PT_PIPE_CASE
+            note_kernel(EVC_PROF_PAIR_TRANSFORM, "pt_pipe_kernel<%d,%d>", npad, mode);
             EVC_LAUNCH_CHECK("pair_transform_pipe");
             return 0;
         }
@@ -1124,6 +1126,7 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
         set_error("pair_transform: n=%d not supported (1..32)", n);
         return -1;
     }
+    note_kernel(EVC_PROF_PAIR_TRANSFORM, "pt_kernel<%d,%d>", npad, rowbuf ? 1 : 0);
     EVC_LAUNCH_CHECK("pair_transform");
     return 0;
 }

@@ -29,11 +29,13 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 7 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
+#define EVC_ABI_VERSION 8 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
                              3: EVC_LAYOUT_SYM8; 4: evc_profile_stage/_select, EVC_FLAG_IP1_S2KL, EVC_FLAG_ERI_S4;
                              5: evc_phase_set_coeffs; 6: evc_phase_loewdin_batch, EVC_FLAG_LOEWDIN_DONE;
                              7: training sets of up to 512 states (evc_subspace_solve[_batch] take a workspace,
-                                evc_subspace_solve_ws_bytes), `flags` argument of the phase A / B entry points */
+                                evc_subspace_solve_ws_bytes), `flags` argument of the phase A / B entry points;
+                             8: evc_profile_kernel; the workspace of the compressed layout's pipeline holds its dense
+                                (pair, pair) intermediates at the pitch N(N+1)/2 rounded up to 16 doubles */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
@@ -365,6 +367,10 @@ int evc_profile_stage(int stage, double *ms, int *launches);
 /* Stages timed by the next sessions: bit s = stage s (default: EVC_PROF_ROWS and EVC_PROF_COLS only -- every timed
  * launch costs two event records, which is visible in the one-geometry-at-a-time regime). */
 int evc_profile_select(unsigned stage_mask);
+/* Name (with template arguments) of the kernel the library most recently launched for a stage, e.g.
+ * "gemv_rows_lds_kernel<2,7,2> G=32" (K5 / EVC_PROF_ROWS: followed by the geometries that launch contracted): what a
+ * measurement of that stage timed.  "" before the first launch.  Process-wide. */
+const char *evc_profile_kernel(int stage);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,9 @@
 #include <vector>
 
 #include "kernels.hpp"
+#ifdef PT_DEV_INLINE_KERNEL   // the kernel under development compiled into the harness (variants by -D flags)
+#include "pair_dma.hip"
+#endif
 
 #define CK(x)                                                                             \
     do {                                                                                  \
