@@ -10,7 +10,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libevcont_hip.so")
+# EVC_BUILD_TAG=<tag>: an instrumented / experimental build goes to csrc/_build_<tag>/ and libevcont_hip_<tag>.so and is
+# selected with EVCONT_HIP_LIB -- the product library and its objects are never overwritten by such a build
+TAG = os.environ.get("EVC_BUILD_TAG", "")
+if os.environ.get("EVC_DEBUG_STAMPS") and not TAG:
+    TAG = "stamps"
+LIB = os.path.join(HERE, f"libevcont_hip_{TAG}.so" if TAG else "libevcont_hip.so")
+OBJDIR = os.path.join(CSRC, f"_build_{TAG}") if TAG else CSRC
 SOURCES = ["gemv_stream.hip", "gemv_mfma.hip", "gemv_lds.hip", "transform.hip", "pair_dma.hip", "dense_small.hip", "subspace_big.hip", "response.hip", "pipeline.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "evcont_hip.h")]
 ARCH = "gfx950"
@@ -41,11 +47,12 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile (if stale) and return the path of the shared library."""
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    os.makedirs(OBJDIR, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",

@@ -9,6 +9,10 @@ geometries, replicated on every rank):
                       which is LINEAR in it (``ab_initio_gradients_loewdin.py:210-252,300-303``);
                       rank 0 alone adds the one-body and nuclear terms
     all_reduce(SUM)   the (G,A,3) gradient        -- 720 B per geometry at A=30
+    [all_reduce(SUM)  the unpacked predicted 2-RDM, N^4 doubles per geometry -- only when the caller asked for the
+                      predicted RDMs (``return_density_matrices``, ``ab_initio_gradients_loewdin.py:366-373``; an MD
+                      callback reading ``scanner.base.predicted_two_rdm``).  The predicted 1-RDM needs no collective: the
+                      one-body t-RDM and the coefficients are replicated, every rank holds the complete matrix.]
 
 ``torch.distributed`` with backend "nccl" is RCCL over xGMI on ROCm; the same code runs on
 "gloo" for the CPU tests, where the three phases are supplied by a test double.
@@ -40,9 +44,17 @@ class PairShardedContinuation:
     ``evaluator.BatchedEvaluator`` (``count`` geometries per call; recognised by its ``count``
     attribute), or any object with the same three phase methods and ``grad``/``energy`` tensors."""
 
-    def __init__(self, evaluator, rows_total: int, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, evaluator, rows_total: int, group: Optional[dist.ProcessGroup] = None,
+                 return_density_matrices: bool = False):
+        """``return_density_matrices``: also reduce the predicted 2-RDM over the ranks after phase C (the evaluator
+        must have been built to keep it: ``ContinuationEvaluator(want_two_rdm=True)`` /
+        ``BatchedEvaluator(keep_density_matrices=True)``); ``predicted_rdms()`` then returns the complete matrices."""
         self.ev = evaluator
         self.group = group
+        self.want_rdms = bool(return_density_matrices)
+        if self.want_rdms and getattr(evaluator, "g_pred", None) is None:
+            raise ValueError("return_density_matrices needs an evaluator that keeps the predicted 2-RDM "
+                             "(want_two_rdm=True / keep_density_matrices=True)")
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.rows_total = int(rows_total)
@@ -85,19 +97,36 @@ class PairShardedContinuation:
             return
         self.ev.phase_gradient(ao, partial_rank=(self.rank != 0))
         dist.all_reduce(self.ev.grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.want_rdms:
+            # each rank unpacked the weighted sum over ITS pair rows: the sum over the ranks is the predicted 2-RDM
+            # (reference :343-361); d_pred is complete on every rank already
+            dist.all_reduce(self.ev.g_pred, op=dist.ReduceOp.SUM, group=self.group)
 
     def _sync(self):
         if self.ev.grad.is_cuda:
             st = getattr(self.ev, "stream", None)
             (st if st is not None else torch.cuda.current_stream(self.ev.grad.device)).synchronize()
 
-    def energy_with_grad(self, ao):
-        """Single-geometry evaluators: (E, grad (A,3)).  Batched: (E (G,), grad (G,A,3))."""
+    def predicted_rdms(self):
+        """(D_pred, Gamma_pred) of the last evaluation as numpy arrays ((N,N), (N,N,N,N); batched: leading axis G);
+        needs ``return_density_matrices=True``."""
+        if not self.want_rdms:
+            raise ValueError("built without return_density_matrices=True")
+        self._sync()
+        return self.ev.d_pred.cpu().numpy().copy(), self.ev.g_pred.cpu().numpy().copy()
+
+    def energy_with_grad(self, ao, return_density_matrices: bool = False):
+        """Single-geometry evaluators: (E, grad (A,3)).  Batched: (E (G,), grad (G,A,3)).  With
+        ``return_density_matrices`` (reference signature, :308-379) also the predicted RDMs."""
+        if return_density_matrices and not self.want_rdms:
+            raise ValueError("built without return_density_matrices=True")
         self.enqueue(ao)
         self._sync()
         if self.count is None:
-            return float(self.ev.energy[0].item()), self.ev.grad.cpu().numpy().copy()
-        return self.ev.energy[:, 0].cpu().numpy().copy(), self.ev.grad.cpu().numpy().copy()
+            res = (float(self.ev.energy[0].item()), self.ev.grad.cpu().numpy().copy())
+        else:
+            res = (self.ev.energy[:, 0].cpu().numpy().copy(), self.ev.grad.cpu().numpy().copy())
+        return res + self.predicted_rdms() if return_density_matrices else res
 
 
 class PipelinedPairSharded:

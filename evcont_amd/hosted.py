@@ -95,6 +95,11 @@ class HostedEvaluator:
         self.use_graph = bool(use_graph)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._calls = 0
+        self._sym_checked = False
+        # the two large arrays of the staged geometry, when the producer already holds them packed in PINNED memory:
+        # uploaded straight from there (no staging copy on the host -- 12 MB per step at H30)
+        self._direct: Dict[str, Optional[torch.Tensor]] = {"eri": None, "eri_ip1": None}
+        self._slab_prefix = [sum(((int(np.prod(shapes[k])) + 1) // 2 * 2) for k in grp[:-1]) for grp in self._groups]
 
     # -- staging ------------------------------------------------------------------------------------
     def staging(self) -> Dict[str, np.ndarray]:
@@ -112,16 +117,27 @@ class HostedEvaluator:
         st["enuc"][0] = float(ao.enuc)
         eri, ip1 = np.asarray(ao.eri), np.asarray(ao.eri_ip1)
         if self.packed:
-            from .evaluator import _host_check_once, check_integral_symmetry
-            if _host_check_once("HostedEvaluator.stage"):   # (packing below keeps one triangle: it must be THE triangle)
+            from .evaluator import _CHECK_SYM, check_integral_symmetry
+            # (packing below keeps one triangle: it must be THE triangle; once per evaluator, EVCONT_AMD_CHECK_SYM=2:
+            #  every call, unless the molecule declares the symmetry itself)
+            if _CHECK_SYM == "2" or (_CHECK_SYM != "0" and not self._sym_checked
+                                     and not getattr(ao, "integral_symmetry", False)):
                 check_integral_symmetry(eri, ip1, n, what="HostedEvaluator.stage")
+            self._sym_checked = True
             iu, ju = np.tril_indices(n)
             if eri.size != st["eri"].size:
                 eri = eri.reshape(n, n, n, n)[iu, ju][:, iu, ju]
             if ip1.size != st["eri_ip1"].size:
                 ip1 = ip1.reshape(3, n, n, n, n)[:, :, :, iu, ju]
-        np.copyto(st["eri"], eri.reshape(st["eri"].shape))
-        np.copyto(st["eri_ip1"], ip1.reshape(st["eri_ip1"].shape))
+        for k, src in (("eri", eri), ("eri_ip1", ip1)):
+            self._direct[k] = None
+            if (not self.zero_copy and src.size == st[k].size and src.dtype == np.float64 and src.flags.c_contiguous
+                    and src.flags.writeable and src.nbytes >= (1 << 20)):
+                tsrc = torch.from_numpy(src.reshape(-1))
+                if tsrc.is_pinned():          # the producer's own pinned buffer: uploaded from there
+                    self._direct[k] = tsrc
+                    continue
+            np.copyto(st[k], src.reshape(st[k].shape))
 
     # -- one step -----------------------------------------------------------------------------------
     def _enqueue_step(self) -> None:
@@ -140,11 +156,21 @@ class HostedEvaluator:
         #  the host to accept a 10 MB copy; the same with the Loewdin kernel reading S / hcore straight from the pinned
         #  host buffers (no upload in front of it at all) and every copy on the forked stream: 430-515 us; the same
         #  enqueue replayed as a HIP graph: 555-590 us.)
+        p0, p2 = self._slab_prefix
+        e_src, i_src = self._direct["eri"], self._direct["eri_ip1"]
         with torch.cuda.stream(main):                     # submitted FIRST: the copy engine works in submission order
-            d0.copy_(h0, non_blocking=True)
+            if e_src is None:
+                d0.copy_(h0, non_blocking=True)
+            else:                                         # small arrays from the slab, int2e from the producer's buffer
+                d0[:p0].copy_(h0[:p0], non_blocking=True)
+                d0[p0: p0 + e_src.numel()].copy_(e_src, non_blocking=True)
         side.wait_stream(main)                            # fork (behind the early copy)
         with torch.cuda.stream(side):
-            d2.copy_(h2, non_blocking=True)
+            if i_src is None:
+                d2.copy_(h2, non_blocking=True)
+            else:
+                d2[:p2].copy_(h2[:p2], non_blocking=True)
+                d2[p2: p2 + i_src.numel()].copy_(i_src, non_blocking=True)
         with torch.cuda.stream(main):
             self.ev.enqueue(self.aob, 1, energy_only=True)       # Loewdin .. eigensolve (what the tail needs stays in the workspace)
             main.wait_stream(side)                        # join: the gradient tail reads eri_ip1 and dhcore

@@ -50,6 +50,27 @@ class AOArrays:
     def natm(self) -> int:
         return int(self.aoslices.shape[0])
 
+    def pinned_packed(self) -> "AOArrays":
+        """A copy whose two large arrays are packed the way PySCF delivers them with ``aosym`` -- ``eri`` as the
+        (Ms, Ms) matrix of ``"s4"``, ``eri_ip1`` as (3,N,N,Ms) of ``"s2kl"`` -- and live in PINNED host memory: what an
+        integral producer that writes into caller-supplied buffers hands to the MD scanner
+        (``MD_utils.get_scanner``), which then uploads them without a staging copy.  Needs integrals with the
+        symmetries of real ones (declared by the result)."""
+        import torch
+        n = self.nao
+        iu, ju = np.tril_indices(n)
+        eri, ip1 = np.asarray(self.eri), np.asarray(self.eri_ip1)
+        if eri.ndim == 4:
+            eri = eri[iu, ju][:, iu, ju]
+        if ip1.ndim == 5:
+            ip1 = ip1[:, :, :, iu, ju]
+        pe = torch.from_numpy(np.ascontiguousarray(eri, dtype=np.float64)).pin_memory()
+        pi = torch.from_numpy(np.ascontiguousarray(ip1, dtype=np.float64)).pin_memory()
+        out = AOArrays(self.S, self.hcore, pe.numpy(), self.ipovlp, self.dhcore, pi.numpy(), self.aoslices, self.enuc,
+                       self.gnuc, integral_symmetry=True)
+        out._pinned = (pe, pi)       # (keeps the pinned allocations alive)
+        return out
+
 
 def equal_aoslices(nao: int, natm: int) -> np.ndarray:
     """Contiguous AO blocks, as equal as possible (first atoms get the surplus)."""

@@ -25,6 +25,8 @@ class OraclePhases:
         self.T, self.n = S.shape[0], one.shape[-1]
         self.grad = torch.zeros((natm, 3), dtype=torch.float64)
         self.energy = torch.zeros(self.T, dtype=torch.float64)
+        self.d_pred = torch.zeros((self.n, self.n), dtype=torch.float64)
+        self.g_pred = torch.zeros((self.n,) * 4, dtype=torch.float64)
 
     def _bundle(self, ao):
         return orc.AOBundle(ao.S, ao.hcore, ao.eri, ao.ipovlp, ao.dhcore, ao.eri_ip1, ao.aoslices, ao.enuc, ao.gnuc)
@@ -49,6 +51,9 @@ class OraclePhases:
         G = orc.unpack_pair_sym(w @ self.two, self.n) if len(w) else np.zeros((self.n,) * 4)
         dX = orc.derivative_ao_mo_trafo(b)
         g = 0.5 * orc.two_el_grad(b.eri, G, self.X, dX, b.eri_ip1, [tuple(s) for s in b.aoslices])
+        # as the device phases: the PARTIAL unpacked 2-RDM of the local rows, the complete 1-RDM on every rank
+        self.g_pred.copy_(torch.from_numpy(np.ascontiguousarray(G)))
+        self.d_pred.copy_(torch.from_numpy(np.tensordot(np.outer(self.c, self.c), self.one, axes=2)))
         if not partial_rank:
             D = np.tensordot(np.outer(self.c, self.c), self.one, axes=2)
             g = g + np.tensordot(D, orc.one_el_grad(b, self.X, dX), axes=([0, 1], [0, 1])) + b.gnuc
@@ -80,7 +85,12 @@ def _worker(rank, world, port, n, T, A, q):
         # a second geometry through the same driver (buffers are reused)
         ao2 = make_ao_arrays(n, A, 7)
         E2, g2 = drv.energy_with_grad(ao2)
-        q.put((rank, E, g, E2, g2))
+        # the predicted RDMs (return_density_matrices of the reference): the 2-RDM is reduced over the ranks
+        drv_r = PairShardedContinuation(OraclePhases(one, packed[r0:r1], S, r0, rows, A), rows,
+                                        return_density_matrices=True)
+        E3, g3, D3, G3 = drv_r.energy_with_grad(ao, return_density_matrices=True)
+        assert abs(E3 - E) < 1e-13 and np.abs(g3 - g).max() < 1e-13
+        q.put((rank, E, g, E2, g2, D3, G3))
     finally:
         dist.destroy_process_group()
 
@@ -107,6 +117,12 @@ def test_pair_sharded_matches_single(world, T):
         for r in res:
             assert abs(r[ie] - Eref) < 1e-11              # every rank holds the same energy
             np.testing.assert_allclose(r[ig], gref, rtol=0, atol=1e-10)   # ... and the reduced gradient
+    ao = make_ao_arrays(n, A, 5)
+    b = orc.AOBundle(ao.S, ao.hcore, ao.eri, ao.ipovlp, ao.dhcore, ao.eri_ip1, ao.aoslices, ao.enuc, ao.gnuc)
+    _, _, Dref, Gref = orc.energy_with_grad(b, one, packed, S, True, True)
+    for r in res:                                          # every rank holds the complete predicted RDMs
+        np.testing.assert_allclose(r[5], Dref, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(r[6], np.asarray(Gref).reshape(r[6].shape), rtol=0, atol=1e-11)
 
 
 class OraclePhasesBatch:

@@ -302,3 +302,10 @@ def test_phase_api_emulated_pair_sharding(lname, world, load_golden, dev):
     for ev in evs:
         assert abs(ev.energy[0].item() - float(g[f"ewg_E_{lname}"])) < 1e-10
     np.testing.assert_allclose(total.cpu().numpy(), g[f"ewg_grad_{lname}"], rtol=0, atol=1e-9)
+    # the predicted RDMs of the pair-sharded mode (distributed.PairShardedContinuation(return_density_matrices=True)):
+    # every rank holds the complete 1-RDM, the 2-RDM is the SUM of the ranks' unpacked partial ones
+    Gsum = torch.zeros_like(evs[0].g_pred)
+    for ev in evs:
+        np.testing.assert_allclose(ev.d_pred.cpu().numpy(), g[f"ewg_D_{lname}"], rtol=0, atol=1e-10)
+        Gsum += ev.g_pred
+    np.testing.assert_allclose(Gsum.cpu().numpy(), g[f"ewg_G_{lname}"], rtol=0, atol=1e-10)
