@@ -339,7 +339,7 @@ def main():
                 "stages": stages, "per_rank": per_rank,
                 "geometries_per_step": job_g}
 
-    def step_roofline(ms_per_step, geoms):
+    def step_roofline(ms_per_step, geoms, k5_per_launch):
         """Whole step against the two rooflines at once: ALGORITHMIC bytes (the resident t-RDMs twice, the AO inputs
         of every geometry once, the results) at the HBM peak PLUS the FP64 matrix work of the four-index rotations and
         the two batched contractions at the MFMA peak, over the measured time of a step on ONE GPU."""
@@ -348,7 +348,7 @@ def main():
         ao = (npr * npr + 3 * n * n * npr if packed_in else 4 * n ** 4) + (2 + 3 + 3 * A) * n * n + 3 * A
         passes = 1 if a.energy_only else 2
         # passes over the resident t-RDMs: K5 (up to 64 geometries each) and, with forces, K8 (up to 32 each)
-        l5 = -(-geoms // k5_geometries_per_pass(geoms, rows, cols))
+        l5 = -(-geoms // max(1, k5_per_launch))   # (geometries per K5 launch: what the library launched)
         l8 = 0 if a.energy_only else -(-geoms // MAX_G_PER_LAUNCH)
         nbytes = 8.0 * ((l5 + l8) * (rows * cols + T * T * n * n) + geoms * ao + geoms * (3 * A + T))
         lead = npr if a.layout == "sym8" else n * n
@@ -453,7 +453,8 @@ def main():
                         "k5_kernel_ran": m["k5_kernel"], "k8_kernel_ran": m["k8_kernel"],
                         "pair_transform_kernel_ran": m["pt_kernel"]},
             "last_energy": m["last_energy"],
-            "roofline_step": step_roofline(m["ms_per_step"], m["geometries_per_step"] if world == 1 else G),
+            "roofline_step": step_roofline(m["ms_per_step"], m["geometries_per_step"] if world == 1 else G,
+                                           m["geometries_per_launch"]),
             # what the collectives library itself reports, and what each rank delivered on its own clock: in the
             # geometry-sharded job a rank's figure is directly comparable with the N=1 run of the same command
             "ranks_seen": dist.get_world_size() if world > 1 else 1,

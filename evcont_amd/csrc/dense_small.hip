@@ -239,6 +239,12 @@ __device__ double g_dbg_val[64];
 #define EVC_STAMP(i_) do { } while (0)
 #define EVC_DBGVAL(i_, v_) do { } while (0)
 #endif
+#define EVC_FEW_STAMP(i_) EVC_STAMP(i_)
+}  // namespace evc
+namespace evc {
+#include "few_roots.hpp"
+}
+namespace evc {
 #ifdef EVC_DEBUG_STAMPS
 __device__ int g_dbg_max_sweeps = 0;   // > 0: cap on the sweeps of the wave solvers (EVC_DBG_MAX_SWEEPS)
 #else
@@ -502,7 +508,10 @@ __device__ __forceinline__ void tridiag_eig_wg_f32(float *Af, int m, float *Zf, 
     float *ww = vv + 32;                // w
     float *dd = ww + 32, *ee = dd + 32, *bb = ee + 32;   // diagonal, off-diagonal, 2 / v^T v
     const int c0 = h * 16;
-    // ---- Householder reduction: A <- H_k A H_k, H_k = I - beta v v^T, v zero up to row k
+    // ---- Householder reduction: A <- H_k A H_k, H_k = I - beta v v^T, v zero up to row k; the matrix stays in LDS, the
+    //      two half-waves split the columns (a register-resident variant, few_roots.hpp, measured 0.97 us per step in
+    //      single precision against 0.69 us for this loop: both are chains of reductions and LDS round trips, and this
+    //      one has the shorter sums)
     for (int k = 0; wave == 0 && k + 2 < m; ++k) {
         const float x = (j > k && j < m) ? Af[j * kTp + k] : 0.0f;
         const float sig = half32_sum(x * x);
@@ -946,64 +955,63 @@ __device__ __forceinline__ void eigh_small(double *A, double *V, int m, int nrea
             const int i = idx / kRp, j = idx - i * kRp;
             Ap[idx] = (i < m && j < m) ? A[i * m + j] : 0.0;
         }
-        if (warm) {
-            for (int idx = tid; idx < kRsz; idx += kThreads) {
-                const int i = idx / kRp, j = idx - i * kRp;
-                const bool in = i < m && j < m;
-                Z[idx] = in ? V[i * m + j] : 0.0;
-                Zt[idx] = in ? V[j * m + i] : 0.0;
-            }
-            __syncthreads();
-            ok = oa_refine(m, nreal, Ap, Z, Zt, B1, B2, B3, lam, red, 10);
-            if (!ok) {   // the buffers may have been permuted: re-establish the roles
-                Z = R6 + kRsz; Zt = R6 + 2 * kRsz; B1 = R6 + 3 * kRsz; B2 = R6 + 4 * kRsz; B3 = R6 + 5 * kRsz;
-            }
-        }
+        // ONE refinement call site, fed by up to three kinds of start vectors in turn (a loop that is not unrolled: every
+        // inlined copy of the refinement is ~15 KB of code, and the instruction cache of a CU pair holds 64 KB):
+        //   stage 0  the previous call's eigenvectors (warm start);
+        //   stage 1  FP32 tridiagonalisation + multisection + twisted factorisation (tridiag_eig_wg_f32);
+        //   stage 2  FP32 one-sided Jacobi on G0 = (A + shift I) / max|.|.
         double amax = 0.0;
-        if (!ok) {
-            for (int idx = tid; idx < m * m; idx += kThreads) {
-                const int i = idx / m, j = idx - i * m;
-                amax = nanmax(amax, fabs(A[idx] + (i == j ? shift : 0.0)));
+        bool sane = true, have_amax = false;
+#pragma unroll 1
+        for (int stage = warm ? 0 : 1; stage < 3 && !ok && sane; ++stage) {
+            if (stage == 1 && !tri) continue;
+            if (stage >= 1 && !have_amax) {
+                for (int idx = tid; idx < m * m; idx += kThreads) {
+                    const int i = idx / m, j = idx - i * m;
+                    amax = nanmax(amax, fabs(A[idx] + (i == j ? shift : 0.0)));
+                }
+                amax = block_max_nan(amax, red);
+                have_amax = true;
+                sane = amax > 0.0 && amax < 1.0e300;   // (zero, NaN or Inf input: left to the FP64 path)
+                if (!sane) break;
             }
-            amax = block_max_nan(amax, red);
-        }
-        const bool sane = amax > 0.0 && amax < 1.0e300;   // (zero, NaN or Inf input: left to the FP64 path)
-        if (!ok && sane && tri) {
-            // FP32 start 1: tridiagonalisation + multisection + twisted factorisation (scratch: the B buffers)
-            float *Af = reinterpret_cast<float *>(B1), *scr = Af + 32 * kTp, *zn = scr + 32 * 32 * 5 + 5 * 32;
-            float *Zf = Gf;
-            const double sc = 1.0 / amax;
-            for (int idx = tid; idx < 32 * kTp; idx += kThreads) {
-                const int i = idx / kTp, j = idx - i * kTp;
-                float v = 0.0f;
-                if (i < nreal && j < nreal) v = (float)(A[i * m + j] * sc);
-                else if (i == j && i < m) v = 40.0f;   // decoupled dummy dimension: an eigenvalue outside the spectrum
-                Af[idx] = v;
-            }
-            __syncthreads();
-            EVC_STAMP(1);
-            tridiag_eig_wg_f32(Af, m, Zf, zn, scr, reinterpret_cast<int *>(Gf + 34 * 32));
-            __syncthreads();
-            EVC_STAMP(2);
-            for (int idx = tid; idx < kRsz; idx += kThreads) {
-                const int i = idx / kRp, j = idx - i * kRp;   // Zt[i][j] = component j of eigenvector i
-                Zt[idx] = (i < m && j < m) ? (double)Zf[i * kZfp + j] * (double)zn[i] : 0.0;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < kRsz; idx += kThreads) {
-                const int i = idx / kRp, j = idx - i * kRp;
-                Z[idx] = (i < m && j < m) ? Zt[j * kRp + i] : 0.0;
-            }
-            __syncthreads();
-            ok = oa_refine(m, nreal, Ap, Z, Zt, B1, B2, B3, lam, red, 10);
-            EVC_DBGVAL(21, ok ? 1.0 : 0.0);
-            if (!ok) {
-                Z = R6 + kRsz; Zt = R6 + 2 * kRsz; B1 = R6 + 3 * kRsz; B2 = R6 + 4 * kRsz; B3 = R6 + 5 * kRsz;
-            }
-        }
-        if (!ok && sane) {
-            // FP32 start 2: one-sided Jacobi on G0 = (A + shift I) / max|.|, column-major with pitch kJfPitch
-            {
+            if (stage == 0) {
+                for (int idx = tid; idx < kRsz; idx += kThreads) {
+                    const int i = idx / kRp, j = idx - i * kRp;
+                    const bool in = i < m && j < m;
+                    Z[idx] = in ? V[i * m + j] : 0.0;
+                    Zt[idx] = in ? V[j * m + i] : 0.0;
+                }
+                __syncthreads();
+            } else if (stage == 1) {
+                // FP32 start 1: tridiagonalisation + multisection + twisted factorisation (scratch: the B buffers)
+                float *Af = reinterpret_cast<float *>(B1), *scr = Af + 32 * kTp, *zn = scr + 32 * 32 * 5 + 5 * 32;
+                float *Zf = Gf;
+                const double sc = 1.0 / amax;
+                for (int idx = tid; idx < 32 * kTp; idx += kThreads) {
+                    const int i = idx / kTp, j = idx - i * kTp;
+                    float v = 0.0f;
+                    if (i < nreal && j < nreal) v = (float)(A[i * m + j] * sc);
+                    else if (i == j && i < m) v = 40.0f;   // decoupled dummy dimension: an eigenvalue outside the spectrum
+                    Af[idx] = v;
+                }
+                __syncthreads();
+                EVC_STAMP(1);
+                tridiag_eig_wg_f32(Af, m, Zf, zn, scr, reinterpret_cast<int *>(Gf + 34 * 32));
+                __syncthreads();
+                EVC_STAMP(2);
+                for (int idx = tid; idx < kRsz; idx += kThreads) {
+                    const int i = idx / kRp, j = idx - i * kRp;   // Zt[i][j] = component j of eigenvector i
+                    Zt[idx] = (i < m && j < m) ? (double)Zf[i * kZfp + j] * (double)zn[i] : 0.0;
+                }
+                __syncthreads();
+                for (int idx = tid; idx < kRsz; idx += kThreads) {
+                    const int i = idx / kRp, j = idx - i * kRp;
+                    Z[idx] = (i < m && j < m) ? Zt[j * kRp + i] : 0.0;
+                }
+                __syncthreads();
+            } else {
+                // FP32 start 2: one-sided Jacobi on G0 = (A + shift I) / max|.|, column-major with pitch kJfPitch
                 const double sc = 1.0 / amax;
                 for (int idx = tid; idx < kJwMax * kJfPitch; idx += kThreads) {
                     const int j = idx / kJfPitch, i = idx - j * kJfPitch;
@@ -1031,7 +1039,11 @@ __device__ __forceinline__ void eigh_small(double *A, double *V, int m, int nrea
                     Z[idx] = (i < m && j < m) ? Zt[j * kRp + i] : 0.0;
                 }
                 __syncthreads();
-                ok = oa_refine(m, nreal, Ap, Z, Zt, B1, B2, B3, lam, red, 10);
+            }
+            ok = oa_refine(m, nreal, Ap, Z, Zt, B1, B2, B3, lam, red, 10);
+            EVC_DBGVAL(21, ok ? 1.0 : 0.0);
+            if (!ok) {   // the buffers may have been permuted: re-establish the roles
+                Z = R6 + kRsz; Zt = R6 + 2 * kRsz; B1 = R6 + 3 * kRsz; B2 = R6 + 4 * kRsz; B3 = R6 + 5 * kRsz;
             }
         }
         EVC_STAMP(10);
@@ -1468,8 +1480,31 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     }
     __syncthreads();
     EVC_STAMP(34);
+    // A few lowest roots (the energy+force path asks for one): double-precision tridiagonal route on ONE wave, verified
+    // against the matrix (few_roots.hpp); anything it does not like falls through to the full eigensolver below.
+    bool few_ok = false;
+    if (a.few && fastbase && a.nroots <= few::kMaxRoots && T >= 2) {
+        if (tid < 64) {
+            const int why = T <= 8    ? few::few_roots_wave<8>(Cm, m, T, a.nroots, ev, V, T, R6, red + 2)
+                            : T <= 16 ? few::few_roots_wave<16>(Cm, m, T, a.nroots, ev, V, T, R6, red + 2)
+                            : T <= 24 ? few::few_roots_wave<24>(Cm, m, T, a.nroots, ev, V, T, R6, red + 2)
+                                      : few::few_roots_wave<32>(Cm, m, T, a.nroots, ev, V, T, R6, red + 2);
+            if (tid == 0) red[0] = why == 0 ? 1.0 : 0.0;
+            EVC_DBGVAL(40, why);
+            EVC_DBGVAL(41, red[2]);
+            EVC_DBGVAL(42, red[3]);
+            EVC_DBGVAL(43, red[4]);
+            EVC_DBGVAL(44, red[5]);
+        }
+        __syncthreads();
+        few_ok = red[0] != 0.0;
+        __syncthreads();
+        EVC_STAMP(37);
+    }
     // warm start from the standard-form eigenvectors of the previous call (H is free as scratch here)
-    if (m <= kJwMax) {
+    if (few_ok) {
+        // (ev[r], V[r * T + i]: root r ascending; c = B^T y below)
+    } else if (m <= kJwMax) {
         // the standard-form matrix is indefinite: shift it by a Gershgorin bound (the eigenvectors do not change)
         if (tid < m) {
             double rs = 0.0;
@@ -1496,21 +1531,32 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
         const bool warm = a.warm && a.vstd && warm_start_rotate(Cm, V, H, T, m, a.vstd, m, red);
         jacobi_eigh_lds(Cm, V, m, rot, red, !warm);
     }
-    if (a.vstd)
+    if (a.vstd && !few_ok)
         for (int idx = tid; idx < m * m; idx += kThreads) a.vstd[idx] = V[idx];
     EVC_STAMP(35);
     // (5) ascending order
-    if (tid < T) ev[tid] = Cm[tid * m + tid];
-    __syncthreads();
-    if (tid < T) {
-        int rank = 0;
-        const double v = ev[tid];
-        for (int j = 0; j < T; ++j) rank += (ev[j] < v || (ev[j] == v && j < tid)) ? 1 : 0;
-        order[rank] = tid;
+    if (!few_ok) {
+        if (tid < T) ev[tid] = Cm[tid * m + tid];
+        __syncthreads();
+        if (tid < T) {
+            int rank = 0;
+            const double v = ev[tid];
+            for (int j = 0; j < T; ++j) rank += (ev[j] < v || (ev[j] == v && j < tid)) ? 1 : 0;
+            order[rank] = tid;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // (6) back-transform c = L^-T y for the requested roots; store into H region
-    if (fastbase) {
+    if (few_ok) {
+        // c_i = sum_{k >= i} B[k][i] y_k, y = row `root` of V (pitch T)
+        for (int idx = tid; idx < a.nroots * T; idx += kThreads) {
+            const int root = idx / T, i = idx - root * T;
+            double c = 0.0;
+            for (int k = i; k < T; ++k) c = fma(L[k * m + i], V[root * T + k], c);
+            H[idx] = c;
+        }
+        if (tid < a.nroots) a.evals[tid] = ev[tid] + a.e_shift;
+    } else if (fastbase) {
         // c_i = sum_{k >= i} B[k][i] y_k with B = L^-1 kept in `L` (pitch m): one thread per (root, i)
         for (int idx = tid; idx < a.nroots * T; idx += kThreads) {
             const int root = idx / T, i = idx - root * T, col = order[root];
@@ -1566,6 +1612,8 @@ int launch_subspace_solve(const SolveArgs &a_in, int count, hipStream_t st) {
     if (a_in.T > kSubspaceSmallT) return launch_subspace_big(a_in, count, st);
     SolveArgs a = a_in;
     a.fast = eigh_fast_enabled();
+    static const int few_on = getenv("EVC_SUBSPACE_FEW") ? atoi(getenv("EVC_SUBSPACE_FEW")) : 1;
+    a.few = few_on;
     const int m = (a.T + 1) & ~1;
     const size_t lds = sizeof(double) * (size_t)4 * m * m + sizeof(int) * m + jacobi_aux_bytes(m);
     static LdsAttr attr;

@@ -542,9 +542,8 @@ static int lds_launch(const GemvRowsLaunch &L, const LdsBlockMap &M, int nblocks
 
 // most geometries one launch takes with the span plan of `p0`: 64 (four sets) with row groups of <= 7 tiles, else 32
 int rows_lds_max_g(const RowProblem &p0, const RowProblem &p1) {
-    static const int max64 = getenv("EVC_ROWS_LDS_G64") ? atoi(getenv("EVC_ROWS_LDS_G64")) : 1;
     const int ntg = p0.nblocks ? p0.lds_plan : p1.lds_plan;
-    return (max64 && ntg >= 1 && ntg <= 7) ? 64 : 32;
+    return (ntg >= 1 && ntg <= 7) ? 64 : 32;
 }
 
 int launch_gemv_rows_lds(const GemvRowsLaunch &Lin, int g0, int G, hipStream_t st) {
@@ -997,7 +996,7 @@ static int cols_lds_waves() { return 8; }
 // matrix, both problems in one launch of gemv_cols_lds_slab_kernel
 int cols_lds_mode(const ColProblem &p0, const ColProblem &p1, int G) {
     static const bool on = !(getenv("EVC_COLS_LDS") && atoi(getenv("EVC_COLS_LDS")) == 0);
-    static const bool slab_on = !(getenv("EVC_COLS_LDS_SLAB") && atoi(getenv("EVC_COLS_LDS_SLAB")) == 0);
+    constexpr bool slab_on = true;
     static const int64_t min_cols = getenv("EVC_ROWS_LDS_MINCOLS") ? atoll(getenv("EVC_ROWS_LDS_MINCOLS")) : 4096;
     if (!on || !lds_device_fits() || p0.cols < min_cols || p0.rows <= 0 || !aligned16(p0.A) || p0.ld % 2 ||
         p0.rows > (1 << 20))

@@ -297,15 +297,12 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, h
     }
     GemvRowsLaunch L = Lin;
     const int gs = G > 16 ? 2 : 1;
-    // shape code = 100*MAXT + 10*MINW + PIPE (EVC_ROWS_SHAPE / EVC_ROWS_SHAPE2 for one / two geometry sets)
-    static const int sh1 = getenv("EVC_ROWS_SHAPE") ? atoi(getenv("EVC_ROWS_SHAPE")) : 421;
-    static const int sh2 = getenv("EVC_ROWS_SHAPE2") ? atoi(getenv("EVC_ROWS_SHAPE2")) : 321;
-    // narrow matrices (the 8-fold compressed layout, < 200 000 columns): the vectors of the 32 geometries weigh as
-    // much as the matrix itself when five row groups re-read them; two groups of seven tiles on ONE wave per SIMD
-    // (512 registers) read them twice: 66 against 76 us at 108 345 columns -- and 270 against 222 us at 405 450
-    // (an eight-wave kernel with one geometry set per half, 722 / 422, measured 89 us against 57-66; removed in round 3)
-    static const int sh2n = getenv("EVC_ROWS_SHAPE2_NARROW") ? atoi(getenv("EVC_ROWS_SHAPE2_NARROW")) : 711;
-    const int shape = gs == 2 ? (Lin.p[0].cols <= 200000 ? sh2n : sh2) : sh1;
+    // ONE shape per case, 100*MAXT + 10*MINW + PIPE (the alternatives of rounds 1-3 were measured slower and removed in
+    // round 4 with their knobs): one geometry set 421 (pipelined, in situ at G=16: 189 us against 194-221 for the lean
+    // shapes); two sets 321 on wide matrices (226 us against 238-300) and 711 on narrow ones (< 200 000 columns, the
+    // 8-fold compressed layout: the vectors of the 32 geometries weigh as much as the matrix itself when five row groups
+    // re-read them; two groups of seven tiles on ONE wave per SIMD read them twice: 66 against 76 us)
+    const int shape = gs == 2 ? (Lin.p[0].cols <= 200000 ? 711 : 321) : 421;
     const int kernel_maxt = shape / 100;
     int max_tiles = tiles <= 0 ? (kernel_maxt >= 5 ? kernel_maxt : kernel_maxt >= 3 ? 3 : kernel_maxt) : tiles;   // see the measurements above
     if (max_tiles > kernel_maxt) max_tiles = kernel_maxt;
@@ -321,27 +318,16 @@ int launch_gemv_rows_mfma(const GemvRowsLaunch &Lin, int g0, int G, int tiles, h
     const int nb1 = L.p[1].nblocks ? (int)ceil_div((int64_t)L.nrg[1] * L.p[1].nspans, 8) * 8 : 0;
     L.nblk0 = nb0;
     L.nblk1 = nb1;
-#define EVC_ROWS_CASE(GS_, MAXT_, MINW_, PIPE_)                                                        \
-    case 100 * MAXT_ + 10 * MINW_ + PIPE_:                                                             \
+#define EVC_ROWS_LAUNCH(GS_, MAXT_, MINW_, PIPE_)                                                      \
+    do {                                                                                               \
         hipLaunchKernelGGL((gemv_rows_mfma_pipe_kernel<GS_, MAXT_, MINW_, PIPE_ != 0>), dim3(nb0 + nb1), \
                            dim3(256), 0, st, L, g0, G);                                                \
         note_kernel(EVC_PROF_ROWS, "gemv_rows_mfma_pipe_kernel<%d,%d,%d,%d> G=%d", GS_, MAXT_, MINW_, PIPE_, G); \
-        break;
-    if (gs == 2) {
-        switch (shape) {
-            // in situ, G=32: pipelined 321 -> 226 us; lean 330 -> 238, 230 -> 247, 240 -> 259, 150 -> 300; 711 -> 270
-            EVC_ROWS_CASE(2, 3, 2, 1) EVC_ROWS_CASE(2, 3, 3, 0) EVC_ROWS_CASE(2, 2, 4, 0) EVC_ROWS_CASE(2, 7, 1, 1)
-            // (single-buffer one-wave shapes 710 / 610 / 510: 76 / 98 / 91 us against 57-66 for 711; removed in round 3)
-            default: set_error("gemv_rows_mfma: unknown EVC_ROWS_SHAPE2=%d", shape); return -1;
-        }
-    } else {
-        switch (shape) {
-            // in situ, G=16: pipelined 421 -> 189 us; lean 260 -> 194, 240 -> 196, 340 -> 208, 180 -> 221
-            EVC_ROWS_CASE(1, 4, 2, 1) EVC_ROWS_CASE(1, 2, 6, 0) EVC_ROWS_CASE(1, 3, 4, 0)
-            default: set_error("gemv_rows_mfma: unknown EVC_ROWS_SHAPE=%d", shape); return -1;
-        }
-    }
-#undef EVC_ROWS_CASE
+    } while (0)
+    if (shape == 711) EVC_ROWS_LAUNCH(2, 7, 1, 1);
+    else if (shape == 321) EVC_ROWS_LAUNCH(2, 3, 2, 1);
+    else EVC_ROWS_LAUNCH(1, 4, 2, 1);
+#undef EVC_ROWS_LAUNCH
     EVC_LAUNCH_CHECK("gemv_rows_mfma");
     return 0;
 }
@@ -559,52 +545,22 @@ int launch_gemv_cols_mfma(GemvColsLaunch L, int g0, int G, hipStream_t st) {
     const int lds_mode = cols_lds_mode(L.p[0], L.p[1], G);
     if (lds_mode == 1) return launch_gemv_cols_lds(L, g0, G, st);
     if (lds_mode == 2 && g0 % kMaxBatchG == 0) return launch_gemv_cols_lds_slab(L, g0, G, st);
-    // shape code = 100*CT + 10*KSN + MINW (EVC_COLS_SHAPE / EVC_COLS_SHAPE2 for one / two geometry sets)
-    // Measured in situ at H30/T=20 (us per launch): lean shapes with many waves per SIMD win by a wide margin
-    // over wide register-blocked ones — G=16: 126 -> 138, 224 -> 147, 343 (the first design) -> 193;
-    // G=32: 224 -> 182, 214 -> 197, 342 -> 312.
-    static const int sh1 = getenv("EVC_COLS_SHAPE") ? atoi(getenv("EVC_COLS_SHAPE")) : 126;
-    static const int sh2 = getenv("EVC_COLS_SHAPE2") ? atoi(getenv("EVC_COLS_SHAPE2")) : 224;
-#define EVC_COLS_CASE(CT_, KSN_, MINW_, GS_) \
-    case 100 * CT_ + 10 * KSN_ + MINW_:                                                        \
-        if (int rc_ = cols_mfma_launch<CT_, KSN_, MINW_, GS_>(L, g0, G, st)) return rc_;       \
-        break;
-    // shape code 1000 + 10*KSN + MINW = the row-split kernel; it is the default below kRsMaxCols columns
-#define EVC_COLS_RS_CASE(KSN_, MINW_, GS_) \
-    case 1000 + 10 * KSN_ + MINW_: cols_mfma_rs_launch<KSN_, MINW_, GS_>(L, g0, G, st); break;
-    static const int rs1 = getenv("EVC_COLS_RS_SHAPE") ? atoi(getenv("EVC_COLS_RS_SHAPE")) : 1026;
-    static const int rs2 = getenv("EVC_COLS_RS_SHAPE2") ? atoi(getenv("EVC_COLS_RS_SHAPE2")) : 1083;
-    static const int64_t rs_max_cols = getenv("EVC_COLS_RS_MAX") ? atoll(getenv("EVC_COLS_RS_MAX")) : 200000;
-    if (L.p[0].cols <= rs_max_cols) {
-        if (G > 16) {
-            switch (rs2) {
-                EVC_COLS_RS_CASE(2, 4, 2) EVC_COLS_RS_CASE(1, 4, 2) EVC_COLS_RS_CASE(2, 3, 2) EVC_COLS_RS_CASE(4, 3, 2) EVC_COLS_RS_CASE(4, 4, 2) EVC_COLS_RS_CASE(8, 3, 2) EVC_COLS_RS_CASE(8, 2, 2)
-                default: set_error("gemv_cols_mfma: unknown EVC_COLS_RS_SHAPE2=%d", rs2); return -1;
-            }
-        } else {
-            switch (rs1) {
-                EVC_COLS_RS_CASE(2, 6, 1) EVC_COLS_RS_CASE(1, 6, 1) EVC_COLS_RS_CASE(4, 6, 1) EVC_COLS_RS_CASE(2, 4, 1)
-                default: set_error("gemv_cols_mfma: unknown EVC_COLS_RS_SHAPE=%d", rs1); return -1;
-            }
-        }
+    // ONE shape per case (in situ at H30 / T = 20, us per launch: lean shapes with many waves per SIMD won by a wide
+    // margin over wide register-blocked ones -- G=16: 126 -> 138, 224 -> 147, 343 (the first design) -> 193; G=32:
+    // 224 -> 182, 214 -> 197, 342 -> 312; the alternatives were removed in round 4 with their knobs): the row-split
+    // kernel below 200 000 columns (K steps 2 / 8, waves per SIMD 6 / 3 for one / two geometry sets), the column-tiled
+    // kernel beyond
+    if (L.p[0].cols <= 200000) {
+        if (G > 16) cols_mfma_rs_launch<8, 3, 2>(L, g0, G, st);
+        else cols_mfma_rs_launch<2, 6, 1>(L, g0, G, st);
         EVC_LAUNCH_CHECK("gemv_cols_mfma_rs");
         return 0;
     }
     if (G > 16) {
-        switch (sh2) {
-            EVC_COLS_CASE(2, 2, 4, 2) EVC_COLS_CASE(2, 1, 4, 2) EVC_COLS_CASE(2, 2, 3, 2) EVC_COLS_CASE(2, 3, 3, 2)
-            EVC_COLS_CASE(3, 4, 2, 2)
-            default: set_error("gemv_cols_mfma: unknown EVC_COLS_SHAPE2=%d", sh2); return -1;
-        }
+        if (int rc_ = cols_mfma_launch<2, 2, 4, 2>(L, g0, G, st)) return rc_;
     } else {
-        switch (sh1) {
-            EVC_COLS_CASE(1, 2, 6, 1) EVC_COLS_CASE(1, 4, 6, 1) EVC_COLS_CASE(1, 2, 8, 1) EVC_COLS_CASE(2, 2, 4, 1)
-            EVC_COLS_CASE(3, 4, 3, 1)
-            default: set_error("gemv_cols_mfma: unknown EVC_COLS_SHAPE=%d", sh1); return -1;
-        }
+        if (int rc_ = cols_mfma_launch<1, 2, 6, 1>(L, g0, G, st)) return rc_;
     }
-#undef EVC_COLS_CASE
-#undef EVC_COLS_RS_CASE
     EVC_LAUNCH_CHECK("gemv_cols_mfma");
     return 0;
 }

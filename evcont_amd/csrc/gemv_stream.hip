@@ -207,11 +207,6 @@ __global__ void gemv_rows_reduce_kernel(const double *partial, int64_t rows, int
     y[r] = alpha * s;
 }
 
-static int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 constexpr int kRBPlan = 8;  // row-block height the workspace/partials are planned for (all variants use it)
 
 // Span plan.  `batched` selects the finer decomposition the batched (G > 1) kernels want (they own whole
@@ -221,11 +216,8 @@ void plan_rows(RowProblem &P, bool batched) {
     const int64_t nchunks = ceil_div(P.cols, kChunk);
     const int64_t nrb = ceil_div(P.rows, kRBPlan);
     // aim at `target` 8-row blocks (span count = target / row blocks) while keeping spans >= min_cps chunks
-    static const int target_b = env_int("EVC_ROWS_TARGET_WGS", 8192);
-    static const int target_1 = env_int("EVC_ROWS_TARGET_WGS_G1", 2048);
-    static const int min_cps_b = env_int("EVC_ROWS_MIN_CPS", 2);
-    const int target = batched ? target_b : target_1;
-    const int min_cps = batched ? min_cps_b : 4;
+    const int target = batched ? 8192 : 2048;
+    const int min_cps = batched ? 2 : 4;
     int64_t want_spans = ceil_div(target, nrb);
     int64_t cps = nchunks / want_spans;
     if (cps < min_cps) cps = nchunks < min_cps ? nchunks : min_cps;
@@ -264,14 +256,8 @@ static void rows_wr_launch(GemvRowsLaunch L, int g0, hipStream_t st) {
     note_kernel(EVC_PROF_ROWS, "gemv_rows_wr_kernel<%d,%d,%d> G=%d", RBW, G, 16 / RBW, G);
 }
 
-static int mfma_min_g() {
-    static const int v = env_int("EVC_MFMA_MIN_G", 12);   // groups of >= this many geometries use the matrix cores
-    return v;
-}
-static int mfma_max_g() {
-    static const int v = env_int("EVC_MFMA_MAX_G", 32);   // geometries per pass over the matrix (16 or 32)
-    return v;
-}
+static constexpr int mfma_min_g() { return 12; }          // groups of >= this many geometries use the matrix cores
+static constexpr int mfma_max_g() { return kMaxBatchG; }   // geometries per pass over the matrix
 // the grouping of launch_gemv_rows below: true if no group of fewer than mfma_min geometries is left over
 bool rows_groups_all_mfma(int count) {
     int left = count;
@@ -288,10 +274,7 @@ int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
     L.p[1] = p1;
     L.nblk0 = p0.nblocks;
     if (p0.nblocks + p1.nblocks == 0 || count <= 0) return 0;
-    static const int v8 = env_int("EVC_ROWS_G8", 0);   // 0: wave-rows kernel RBW=4; 1: lane-private RB=2
-    static const int v4 = env_int("EVC_ROWS_G4", 0);   // 0: wave-rows RBW=8; 1: wave-rows RBW=4; 2: lane-private RB=4
     const int mfma_min = mfma_min_g(), mfma_max = mfma_max_g();
-    static const int mfma_tiles = env_int("EVC_MFMA_TILES", 0);   // most 16-row tiles per row group (0: default, 3)
     int g0 = 0;
     while (g0 < count) {
         const int left = count - g0;
@@ -303,19 +286,16 @@ int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st) {
             if (lds && mfma_max == 32 && left > 32 && !(p0.nblocks && p1.nblocks && p1.lds_plan <= 0))
                 gmax = rows_lds_max_g(p0, p1);
             const int G = left < gmax ? left : gmax;
-            int rc = launch_gemv_rows_mfma(L, g0, G, mfma_tiles, st);
+            int rc = launch_gemv_rows_mfma(L, g0, G, 0, st);
             if (rc) return rc;
             g0 += G;
             continue;
         }
         if (left >= 8) {
-            if (v8 == 1) rows_launch<2, 8>(L, g0, st);
-            else rows_wr_launch<4, 8>(L, g0, st);
+            rows_wr_launch<4, 8>(L, g0, st);   // (wave-rows kernels for 4 / 8 geometries: the lane-private ones were slower)
             g0 += 8;
         } else if (left >= 4) {
-            if (v4 == 2) rows_launch<4, 4>(L, g0, st);
-            else if (v4 == 1) rows_wr_launch<4, 4>(L, g0, st);
-            else rows_wr_launch<8, 4>(L, g0, st);
+            rows_wr_launch<8, 4>(L, g0, st);
             g0 += 4;
         } else if (left >= 2) {
             rows_launch<8, 2>(L, g0, st);
@@ -570,8 +550,7 @@ __global__ __launch_bounds__(256) void gemv_cols_slab_reduce_kernel(ColProblem P
 }
 
 int launch_gemv_cols(ColProblem p0, ColProblem p1, int count, hipStream_t st) {
-    static const int mfma_min_g = env_int("EVC_MFMA_MIN_G", 12);
-    if (p1.part && p1.cols > 0 && p1.rows >= 1024 && p1.cols <= 16384 && count > 0 && count < mfma_min_g) {
+    if (p1.part && p1.cols > 0 && p1.rows >= 1024 && p1.cols <= 16384 && count > 0 && count < mfma_min_g()) {
         // (groups of >= 12 geometries go through the matrix-core kernel, whose four waves split the rows of a tile)
         // the narrow second problem in row slabs (its own two launches), the wide one alone below
         const int nslab = (int)(p1.rows / 64 < kColSlabs ? p1.rows / 64 : kColSlabs);
@@ -589,8 +568,7 @@ int launch_gemv_cols(ColProblem p0, ColProblem p1, int count, hipStream_t st) {
     L.nblk0 = (int)ceil_div(p0.cols, kChunk);
     const int total = L.nblk0 + (int)ceil_div(p1.cols, kChunk);
     if (total == 0 || count <= 0) return 0;
-    static const int mfma_min = env_int("EVC_MFMA_MIN_G", 12);
-    static const int mfma_max = env_int("EVC_MFMA_MAX_G", 32);
+    const int mfma_min = mfma_min_g(), mfma_max = mfma_max_g();
     int g0 = 0;
     while (g0 < count) {
         const int left = count - g0;

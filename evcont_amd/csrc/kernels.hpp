@@ -95,6 +95,10 @@ int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st)
 // pair_dma.hip: the fully symmetric dense (pair, pair) -> dense (pair, pair) step, 16 < n <= 30, operand rows by LDS-DMA
 bool pair_transform_dma_applicable(const PairTransformArgs &a, int count);
 int launch_pair_transform_dma(const PairTransformArgs &a, int count, hipStream_t st);
+// ... and the fused Y2 contraction with its two operand rows by LDS-DMA (same slabs as launch_y2_fused)
+bool y2_dma_applicable(int n);
+int launch_y2_dma(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial, int64_t sws,
+                  int count, int slabs, int tiles_per_wg, int ppt, hipStream_t st);
 int launch_pack(const double *h2, int64_t sh2, int n, double diag_mult, double *out, int64_t sout, int64_t out_len,
                 int count, hipStream_t st);
 // 8-fold compressed vector of a tensor with the index symmetries of real two-electron integrals:

@@ -367,6 +367,193 @@ __global__ __launch_bounds__(256, 2) void ptd_kernel(PairTransformArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the rows requested beyond the last matrix)
 }
 
+// ---------------------------------------------------------------------------------- Y2 with LDS-DMA operand rows
+// y2_fused_kernel (transform.hip) with the machinery above: per pair v one wave computes H^T = X^T M1_v (32 MFMAs) and
+// Y += mult(v) T_v H^T (32 MFMAs), M1_v = row v of the first pair step's intermediate, T_v = row v of SB, both dense
+// (pair, pair) forms at the pitch pair_ld(n).  The two rows come by LDS-DMA into two wave-private LDS rows; the T
+// fragments are read during the H phase and the next T row requested, the next M fragments during the Y phase and
+// the M row after that requested -- each DMA has a whole iteration to land and the wait in front of either read is the
+// constant "one row younger" vmcnt.  No barrier, no store, no vector instruction in the loop: the multiplicity of the
+// pair (1 on the diagonal i == j, else 2) selects one of two accumulator sets (wave-uniform branch), Y = Yd + 2 Yo at
+// the end.
+__global__ __launch_bounds__(256, 2) void y2d_kernel(const double *__restrict__ SB, const double *__restrict__ M1,
+                                                     const double *__restrict__ X, int64_t sX, int n,
+                                                     double *__restrict__ partial, int64_t sws, int tiles_per_wg, int ppt) {
+    constexpr int KS = 8, NT = 2, NPAD = 32;
+    extern __shared__ __align__(16) char lds[];
+    const int npairs = n * (n + 1) / 2, ld = pair_ld(n);
+    const int64_t g = blockIdx.y;
+    SB += g * sws;
+    M1 += g * sws;
+    X += g * sX;
+    partial += g * sws;
+    const int ntiles = (npairs + ppt - 1) / ppt;
+    const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    d4 yD[NT][NT], yO[NT][NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) yD[ti][ta] = yO[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (t_begin < t_end) {
+        const int niter = (ppt / 4) * (t_end - t_begin);
+        const unsigned rowM = (unsigned)wave * 2u * kPdRB, rowT = rowM + kPdRB;
+        unsigned fa[NT][KS];   // LDS address of fragment (rt, kk) in the M row (T row: + kPdRB)
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int r = rt * 16 + l15, s = 4 * kk + l4;
+                const int hi = s > r ? s : r, lo = s > r ? r : s;
+                fa[rt][kk] = opaque((r < n && s < n) ? rowM + 8u * (unsigned)(hi * (hi + 1) / 2 + lo) : rowM + kPdRaw * 1024);
+            }
+        if (lane < 8) {
+            *reinterpret_cast<double *>(lds + rowM + kPdRaw * 1024 + 8 * lane) = 0.0;
+            *reinterpret_cast<double *>(lds + rowT + kPdRaw * 1024 + 8 * lane) = 0.0;
+        }
+        const unsigned wbytes = (unsigned)((npairs * 8 + 15) & ~15);   // (rows start on 128-byte lines)
+        unsigned vo[kPdRaw];
+#pragma unroll
+        for (unsigned u = 0; u < kPdRaw; ++u) {
+            const unsigned o = 1024u * u + 16u * (unsigned)lane;
+            vo[u] = o < wbytes ? o : 0u;
+        }
+        const int npieces = __builtin_amdgcn_readfirstlane((int)((wbytes + 1023u) >> 10));
+        auto dma_row = [&](const double *base, int e, unsigned dst) {
+            const char *src = reinterpret_cast<const char *>(base + (int64_t)(e < npairs ? e : wave) * ld);
+#pragma unroll
+            for (unsigned u = 0; u < kPdRaw; ++u)
+                if ((int)u < npieces) glds16(vo[u], src, dst + 1024u * u);
+        };
+        // "everything but the youngest row has landed": npieces DMA instructions may stay in flight
+        auto wait_older = [&]() {
+            if (npieces >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (npieces == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (npieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        };
+        const int e0 = ppt * t_begin + wave;   // this wave's pair of iteration i: e0 + 4 i
+        dma_row(M1, e0, rowM);
+        dma_row(SB, e0, rowT);
+        double xf[KS][NT];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int d = 4 * kk + l4, c = t * 16 + l15;
+                const bool ok = d < n && c < n;
+                const double v = X[ok ? d * n + c : 0];
+                xf[kk][t] = ok ? v : 0.0;
+            }
+        double mf[NT][KS], tf[NT][KS];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = lds_ld(fa[rt][kk]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_row(M1, e0 + 4, rowM);
+        // (p, q) of the pair e, advanced by 4 per iteration with scalar arithmetic: on the diagonal <=> q == p
+        int pp = __builtin_amdgcn_readfirstlane(tri_row_small(e0 < npairs ? e0 : 0)), qq = (e0 < npairs ? e0 : 0) - pp * (pp + 1) / 2;
+        const d4 zero = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < niter; ++i) {
+            const int e = e0 + 4 * i;
+            const bool live = e < npairs, diag = qq == pp;
+            // ------------------------------------------------------------ H^T = X^T M_e  (+ T fragments of pair e)
+            d4 hT[NT][NT];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+                for (int m = 0; m < NT * NT; ++m) {
+                    const int it = m / NT, st = m % NT;
+                    hT[it][st] = mfma_f64(xf[kk][it], mf[st][kk], kk == 0 ? zero : hT[it][st]);
+                    if (m == 0) {
+                        if (kk == 0) wait_older();   // the T row of this pair (the M row of the next one may be in flight)
+                        if (kk < 2) {
+#pragma unroll
+                            for (int k2 = 0; k2 < KS; ++k2) tf[kk][k2] = lds_ld(fa[kk][k2] + kPdRB);
+                        }
+                        if (kk == 2) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            dma_row(SB, e + 4, rowT);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ------------------------------------------------------------ Y += mult(e) T_e H^T  (+ M fragments of pair e + 4)
+            // (one wave-uniform branch per phase selects the accumulator set; idle slots of the last tile move data only)
+            auto yphase = [&](auto live_tag, d4 (&y)[NT][NT]) {
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+                    for (int m = 0; m < NT * NT; ++m) {
+                        const int ti = m / NT, ta = m % NT;
+                        if constexpr (decltype(live_tag)::value)
+                            y[ti][ta] = mfma_f64(tf[ti][kk], hT[kk / 4][ta][kk % 4], y[ti][ta]);
+                        if (m == 0) {
+                            if (kk == 0) wait_older();   // the M row of the next pair
+                            if (kk < 2) {
+#pragma unroll
+                                for (int k2 = 0; k2 < KS; ++k2) mf[kk][k2] = lds_ld(fa[kk][k2]);
+                            }
+                            if (kk == 2) {
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                dma_row(M1, e + 8, rowM);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            if (!live) yphase(std::false_type{}, yD);
+            else if (diag) yphase(std::true_type{}, yD);
+            else yphase(std::true_type{}, yO);
+            qq += 4;
+            while (qq > pp) {
+                qq -= pp + 1;
+                ++pp;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // cross-wave sum (every workgroup writes its slab, workgroups without tiles a zero one)
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(lds);   // [4][NPAD][NPAD + 1], over the rows once they are done with
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(wave * NPAD + ti * 16 + l4 + 4 * r) * (NPAD + 1) + ta * 16 + l15] = yD[ti][ta][r] + 2.0 * yO[ti][ta][r];
+    __syncthreads();
+    double *dst = partial + (int64_t)blockIdx.x * n * n;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, aa = idx % n;
+        const int o = i * (NPAD + 1) + aa;
+        constexpr int WS = NPAD * (NPAD + 1);
+        dst[idx] = (red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o]);
+    }
+}
+
+bool y2_dma_applicable(int n) {
+    static const bool on = !(getenv("EVC_PT_DMA") && atoi(getenv("EVC_PT_DMA")) == 0);
+    return on && n > 16 && n <= kPdMaxN;
+}
+
+int launch_y2_dma(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial, int64_t sws,
+                  int count, int slabs, int tiles_per_wg, int ppt, hipStream_t st) {
+    constexpr unsigned ldsb = 8 * kPdRB > 4 * 32 * 33 * 8 ? 8 * kPdRB : 4 * 32 * 33 * 8;
+    hipLaunchKernelGGL(y2d_kernel, dim3((unsigned)slabs, (unsigned)count), dim3(256), ldsb, st, SB, M1, X, sX, n, partial,
+                       sws, tiles_per_wg, ppt);
+    note_kernel(EVC_PROF_Y2, "y2d_kernel");
+    EVC_LAUNCH_CHECK("y2_dma");
+    return 0;
+}
+
 bool pair_transform_dma_applicable(const PairTransformArgs &a, int count) {
     static const bool on = !(getenv("EVC_PT_DMA") && atoi(getenv("EVC_PT_DMA")) == 0);
     const int npairs = a.n * (a.n + 1) / 2;

@@ -102,21 +102,13 @@ struct Ws {
     RowProblem rp2, rp1;
 };
 
-// n <= 32: the four-index rotations run as two fused pair steps (transform.hip pt_kernel); larger n
-// (or EVC_NO_PAIR_TRANSFORM=1, for A/B timing) as four quarter steps.
-static bool use_pair_transform(int n) {
-    static const bool off = getenv("EVC_NO_PAIR_TRANSFORM") != nullptr;
-    return !off && n <= kPairTransformMaxN;
-}
+// n <= 32: the four-index rotations run as two fused pair steps (transform.hip / pair_dma.hip); larger n as four
+// quarter steps.
+static bool use_pair_transform(int n) { return n <= kPairTransformMaxN; }
 
-// Geometries per pass of the multi-kernel stages of a batched call (integral rotation, gradient tail).  With
-// EVC_STAGE_CHUNK=16 the N^4-sized intermediates a stage hands from kernel to kernel stay closer to the 256 MB
-// Infinity Cache; measured at H30, 32 geometries: -4 % step time on one stream, within noise (+-3 %) with two
-// streams in flight, so the default is one pass over the whole batch.
-static int stage_chunk(int count) {
-    static const int c = getenv("EVC_STAGE_CHUNK") ? atoi(getenv("EVC_STAGE_CHUNK")) : 0;
-    return (c < 1 || c > count) ? count : c;
-}
+// Geometries per pass of the multi-kernel stages of a batched call (integral rotation, gradient tail): one pass over
+// the whole batch (chunks of 16, which keep the intermediates closer to the Infinity Cache, measured within noise).
+static int stage_chunk(int count) { return count; }
 
 // Many spans: sum the partials in a multi-workgroup launch instead of inside the eigensolver kernel.
 static bool reduce_in_own_launch(const Ws &w) { return w.rp2.nspans > 48; }

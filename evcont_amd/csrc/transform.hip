@@ -1055,7 +1055,7 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     const int n = a.n;
     const int npad = (n + 15) / 16 * 16;
     const int ntq = (n + 7) / 8;
-    static const int tpw_env = getenv("EVC_PT_TILES") ? atoi(getenv("EVC_PT_TILES")) : 4;
+    constexpr int tpw_env = 4;   // (2/3/5/8 tiles per workgroup measured slower, round 2 and again with ptd_kernel in round 4)
     // few geometries: keep one tile per workgroup so that there are enough workgroups for the chip
     a.tiles_per_wg = (count < 4 || tpw_env < 1) ? 1 : (tpw_env > ntq ? ntq : tpw_env);
     const int ntiles = a.lead_sym ? (n * (n + 1) / 2 + 7) / 8 : n * ntq;
@@ -1069,7 +1069,7 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
         const int mode = a.k3 ? -1 : (a.out && a.out_pairs && !a.packed) ? 0 : (a.packed && a.sym8 && !a.out) ? 1 : -1;
         const size_t npairs = (size_t)n * (n + 1) / 2;
         const size_t lds = sizeof(double) * ((size_t)4 * kPtRowLen + npairs * 16 + 16);
-        static const bool pipe4_on = !(getenv("EVC_PT_PIPE4") && atoi(getenv("EVC_PT_PIPE4")) == 0);
+        constexpr bool pipe4_on = true;
         if (pipe4_on && mode >= 0 && count < 4 && npairs >= 8) {
             // a few geometries: tiles of 4 pairs, one per workgroup (twice the workgroups, half the length)
             a.tiles_per_wg = 1;
@@ -1104,7 +1104,7 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
         }
     }
     // dense (pair, pair) operand: coalesced row fetch through a wave-private LDS row (EVC_PT_ROWBUF=0: gather)
-    static const bool rowbuf_on = !(getenv("EVC_PT_ROWBUF") && atoi(getenv("EVC_PT_ROWBUF")) == 0);
+    constexpr bool rowbuf_on = true;
     const bool rowbuf = rowbuf_on && a.in_pairs;
     const size_t rowbuf_doubles = rowbuf ? (size_t)4 * kPtRowLen + 2 : 0;
     if (npad == 16) {
@@ -1424,8 +1424,7 @@ int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t 
 // number of K slabs = partial results per geometry (fixed for the life of the process: it sizes the workspace)
 static int y2_slab_count() {
     static const int v = [] {
-        const int e = getenv("EVC_Y2_SLABS") ? atoi(getenv("EVC_Y2_SLABS")) : 64;
-        return (e >= 8 && e <= 512) ? e : 64;
+        return 64;
     }();
     return v;
 }
@@ -1729,6 +1728,9 @@ int y2_fused_slabs(int n, int count) {
 }
 int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial,
                     int64_t sws, int count, hipStream_t st) {
+    if (y2_dma_applicable(n))
+        return launch_y2_dma(SB, M1, X, sX, n, partial, sws, count, y2_fused_slabs(n, count), y2_fused_tiles(n, count),
+                             y2_fused_ppt(count), st);
     const dim3 grid((unsigned)y2_fused_slabs(n, count), (unsigned)count);
     const int npad = (n + 15) / 16 * 16;
     const size_t rows = sizeof(double) * (size_t)8 * kPtRowLen;
@@ -1744,6 +1746,7 @@ int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t
         set_error("y2_fused: n=%d not supported (1..32)", n);
         return -1;
     }
+    note_kernel(EVC_PROF_Y2, "y2_fused_kernel<%d>", npad);
     EVC_LAUNCH_CHECK("y2_fused");
     return 0;
 }
@@ -1785,12 +1788,10 @@ int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64
 // GsAO[m,b,c,d] = G[m,b,c,d] + G[b,m,d,c] + G[c,d,m,b] + G[d,c,b,m]   (G = 2-RDM in the AO basis)
 // Blocks [nb1, nb1 + 3A): term3[A*3+x] = sum_ab dhcore[A,x,a,b] * Pao[a,b].
 // Remaining blocks: y2[e] = sum_slab y2part[slab][e].
-// elements of the (b,c,d) range per thread (EVC_IP1_PT = 4, 8 or 16; fixed for the life of the process: it sizes
-// the t2part workspace)
+// elements of the (b,c,d) range per thread (sizes the t2part workspace)
 static int ip1_per_thread() {
     static const int pt = [] {
-        const int v = getenv("EVC_IP1_PT") ? atoi(getenv("EVC_IP1_PT")) : 8;
-        return (v == 4 || v == 16) ? v : 8;
+        return 8;
     }();
     return pt;
 }
@@ -1825,13 +1826,32 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
         const double *__restrict__ ql = ip1 + ((int64_t)lo * n + hi) * npr;
         const bool both = hi != lo;
         double ah[3] = {0.0, 0.0, 0.0}, al[3] = {0.0, 0.0, 0.0};
-        for (int v = threadIdx.x; v < npr; v += 256) {
-            const int vc = tri_row_small(v);
-            const double gv = gr[v] * (v == vc * (vc + 3) / 2 ? 1.0 : 2.0);   // multiplicity of the pair (c,d), c >= d
+        // two adjacent elements per lane: seven 16-byte loads in flight per lane (the int2e_ip1 rows of the caller's s2kl
+        // array start on any multiple of 8 bytes: loads typed with 8-byte alignment)
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        for (int v = 2 * threadIdx.x; v < npr; v += 512) {
+            const int vc = tri_row_small(v), vc1 = tri_row_small(v + 1);
+            // multiplicity of the pair (c,d), c >= d: 1 on the diagonal, else 2
+            const double w0 = v == vc * (vc + 3) / 2 ? 1.0 : 2.0, w1 = (v + 1) == vc1 * (vc1 + 3) / 2 ? 1.0 : 2.0;
+            if (v + 1 < npr) {
+                const d2u gg = *reinterpret_cast<const d2u *>(gr + v);
+                const double g0 = gg[0] * w0, g1 = gg[1] * w1;
 #pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                ah[x] = fma(qh[(int64_t)x * n * len + v], gv, ah[x]);
-                if (both) al[x] = fma(ql[(int64_t)x * n * len + v], gv, al[x]);
+                for (int x = 0; x < 3; ++x) {
+                    const d2u q = *reinterpret_cast<const d2u *>(qh + (int64_t)x * n * len + v);
+                    ah[x] = fma(q[1], g1, fma(q[0], g0, ah[x]));
+                    if (both) {
+                        const d2u r = *reinterpret_cast<const d2u *>(ql + (int64_t)x * n * len + v);
+                        al[x] = fma(r[1], g1, fma(r[0], g0, al[x]));
+                    }
+                }
+            } else {
+                const double g0 = gr[v] * w0;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    ah[x] = fma(qh[(int64_t)x * n * len + v], g0, ah[x]);
+                    if (both) al[x] = fma(ql[(int64_t)x * n * len + v], g0, al[x]);
+                }
             }
         }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

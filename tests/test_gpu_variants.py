@@ -19,11 +19,7 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
 @pytest.mark.parametrize("env", [
     {"EVC_PT_PIPE": "0", "EVC_PT_DMA": "0"}, # phase-alternating pair transform (pt_kernel) instead of ptd_kernel / pt_pipe_kernel
     {"EVC_PT_DMA": "0"},                      # pt_pipe_kernel (operand rows through registers) instead of ptd_kernel (LDS-DMA)
-    {"EVC_PT_PIPE": "0", "EVC_PT_DMA": "0", "EVC_PT_ROWBUF": "0"},   # pt_kernel with the per-lane gather
-    {"EVC_PT_PIPE4": "0"},                    # a few geometries through pt_pipe_kernel (8-pair tiles) instead of pt_pipe4_kernel
-    {"EVC_PT_TILES": "1"},                    # pipelined pair transform, one tile per workgroup (two matrices per wave)
-    {"EVC_PT_TILES": "3"},                    # ... an odd number of tiles (last workgroup ragged)
-    {"EVC_SUBSPACE_FEW": "0"},                # large-T subspace kernel: every call through the Jacobi sweeps
+    {"EVC_SUBSPACE_FEW": "0"},                # subspace kernels: no few-roots route (full eigensolver / Jacobi sweeps always)
     {"EVC_EIGH_F32": "0"},                    # FP64 Jacobi eigensolvers
     {"EVC_EIGH_F32": "1"},                    # FP32 Jacobi start + refinement
     {"EVC_ROWS_LDS": "0"},                    # batched K5 with fragment-shaped loads (gemv_rows_mfma_pipe_kernel)
@@ -39,7 +35,7 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
 def test_variant_passes_parity_subset(env):
     e = dict(os.environ)
     e.update(env)
-    subset = LARGE_T if "EVC_SUBSPACE_FEW" in env else SUBSET
+    subset = LARGE_T + SUBSET if "EVC_SUBSPACE_FEW" in env else SUBSET
     if "EVC_ROWS_LDS_NT" in env or "EVC_ROWS_LDS" in env or "EVC_COLS_LDS" in env:   # (the kernels behind these knobs: batches of >= 12)
         subset = ["tests/test_gpu_bench_config.py::test_k5_every_row_group_body",
                   "tests/test_gpu_bench_config.py::test_k5_row_groups_wide_matrix", "tests/test_gpu_sym8.py::test_sym8_batched"]
