@@ -691,7 +691,8 @@ def main():
                     "best": max(reps_a), "first_call_s": first_s,
                     "compressed_evaluator_used": bool(sc._hev is not None and sc._hev.packed),
                     "compression_mode": aec.get_trdm_compression(),
-                    "uploads_from_producer_buffers": all(v is not None for v in sc._hev._direct.values()),
+                    "uploads_from_producer_buffers": bool(sc._hev._direct_slabs is not None
+                                                          or all(v is not None for v in sc._hev._direct.values())),
                     "host_two_rdm_bytes": int(two_h.nbytes),
                     "energy_difference_vs_headline": abs(e0_again - m["check_energy"]),
                     "vs_md_hosted": (val_a / out["md_hosted"]["value"]) if "md_hosted" in out else None,

@@ -30,6 +30,29 @@ from . import _lib
 from .evaluator import BatchedEvaluator, DeviceAOBatch, DeviceTRDMs, F64
 
 _LATE = ("dhcore", "eri_ip1")
+_GROUPS = (("S", "hcore", "enuc", "ipovlp", "gnuc", "eri"), _LATE)
+
+
+def staging_layout(n: int, natm: int, packed: bool):
+    """The two staging slabs of a geometry (the early arrays and int2e; dhcore and int2e_ip1): per slab a list of
+    (field, shape with a leading batch axis of 1, offset in doubles) and its length.  Every array starts on a 16-byte
+    boundary.  ``packed``: int2e as the (Ms, Ms) matrix of ``aosym="s4"``, int2e_ip1 as (3,N,N,Ms) of ``"s2kl"``.
+    An integral producer that lays its output out like this in PINNED memory (``synthetic.AOArrays.pinned_packed``)
+    is uploaded from there as it stands: two copies per step, no staging copy on the host."""
+    npr = n * (n + 1) // 2
+    shapes = {"S": (1, n, n), "hcore": (1, n, n), "enuc": (1,), "ipovlp": (1, 3, n, n), "gnuc": (1, natm, 3),
+              "dhcore": (1, natm, 3, n, n),
+              "eri": (1, npr, npr) if packed else (1, n, n, n, n),
+              "eri_ip1": (1, 3, n, n, npr) if packed else (1, 3, n, n, n, n)}
+    out = []
+    for grp in _GROUPS:
+        off, fields = 0, []
+        for k in grp:
+            size = int(np.prod(shapes[k]))
+            fields.append((k, shapes[k], off))
+            off += (size + 1) // 2 * 2
+        out.append((fields, off))
+    return out
 
 
 class HostedEvaluator:
@@ -45,11 +68,8 @@ class HostedEvaluator:
         self.t, self.natm = trdms, int(natm)
         d, n = trdms.device, trdms.n
         self.packed = trdms.layout == _lib.LAYOUT_SYM8 and n <= 32
-        npr = n * (n + 1) // 2
-        shapes = {"S": (1, n, n), "hcore": (1, n, n), "enuc": (1,), "ipovlp": (1, 3, n, n), "gnuc": (1, self.natm, 3),
-                  "dhcore": (1, self.natm, 3, n, n),
-                  "eri": (1, npr, npr) if self.packed else (1, n, n, n, n),
-                  "eri_ip1": (1, 3, n, n, npr) if self.packed else (1, 3, n, n, n, n)}
+        layout = staging_layout(n, self.natm, self.packed)
+        shapes = {k: shp for fields, _ in layout for k, shp, _ in fields}
         # two slabs = two H2D copies per step (a copy costs ~12 us before its first byte moves): the early arrays (the
         # small ones and int2e) and the late pair (dhcore, int2e_ip1); every array is a 16-byte aligned view of its slab
         # SMALL systems (all inputs together below EVCONT_AMD_ZERO_COPY_BYTES, default 1 MiB): no copies at all -- the
@@ -62,19 +82,18 @@ class HostedEvaluator:
             lim = int(os.environ.get("EVCONT_AMD_ZERO_COPY_BYTES", str(1 << 20)))
             zero_copy = 8 * sum(int(np.prod(v)) for v in shapes.values()) <= lim
         self.zero_copy = bool(zero_copy)
-        self._groups = (("S", "hcore", "enuc", "ipovlp", "gnuc", "eri"), _LATE)
+        self._groups = _GROUPS
         self.host: Dict[str, torch.Tensor] = {}
         self.dev: Dict[str, torch.Tensor] = {}
         self._slabs = []
-        for grp in self._groups:
-            sizes = [int(np.prod(shapes[k])) for k in grp]
-            offs = np.concatenate([[0], np.cumsum([(x + 1) // 2 * 2 for x in sizes])])
-            hs = torch.zeros(int(offs[-1]), dtype=F64).pin_memory()
-            ds = hs if self.zero_copy else torch.zeros(int(offs[-1]), dtype=F64, device=d)
+        for fields, total in layout:
+            hs = torch.zeros(total, dtype=F64).pin_memory()
+            ds = hs if self.zero_copy else torch.zeros(total, dtype=F64, device=d)
             self._slabs.append((hs, ds))
-            for k, o, x in zip(grp, offs[:-1], sizes):
-                self.host[k] = hs[int(o): int(o) + x].view(shapes[k])
-                self.dev[k] = ds[int(o): int(o) + x].view(shapes[k])
+            for k, shp, o in fields:
+                x = int(np.prod(shp))
+                self.host[k] = hs[o: o + x].view(shp)
+                self.dev[k] = ds[o: o + x].view(shp)
         sl = torch.from_numpy(np.ascontiguousarray(np.asarray(aoslices, dtype=np.int64).reshape(-1, 2))).to(d)
         self.aob = DeviceAOBatch(S=self.dev["S"], hcore=self.dev["hcore"], eri=self.dev["eri"], enuc=self.dev["enuc"],
                                  natm=self.natm, ipovlp=self.dev["ipovlp"], dhcore=self.dev["dhcore"],
@@ -99,7 +118,8 @@ class HostedEvaluator:
         # the two large arrays of the staged geometry, when the producer already holds them packed in PINNED memory:
         # uploaded straight from there (no staging copy on the host -- 12 MB per step at H30)
         self._direct: Dict[str, Optional[torch.Tensor]] = {"eri": None, "eri_ip1": None}
-        self._slab_prefix = [sum(((int(np.prod(shapes[k])) + 1) // 2 * 2) for k in grp[:-1]) for grp in self._groups]
+        self._direct_slabs = None   # ... or the whole geometry, when the producer laid it out as `staging_layout` does
+        self._slab_prefix = [fields[-1][2] for fields, _ in layout]
 
     # -- staging ------------------------------------------------------------------------------------
     def staging(self) -> Dict[str, np.ndarray]:
@@ -112,6 +132,18 @@ class HostedEvaluator:
         the host when the device side wants them packed and they arrive full."""
         st = self.staging()
         n = self.t.n
+        self._direct_slabs = None
+        slabs = getattr(ao, "_staging_slabs", None)
+        if (slabs is not None and not self.zero_copy and getattr(ao, "_staging_key", None) == (n, self.natm, self.packed)
+                and all(a.numel() == b[0].numel() and a.is_pinned() for a, b in zip(slabs, self._slabs))):
+            if self.packed and not self._sym_checked:
+                from .evaluator import _CHECK_SYM, check_integral_symmetry
+                if _CHECK_SYM != "0" and not getattr(ao, "integral_symmetry", False):
+                    check_integral_symmetry(np.asarray(ao.eri), np.asarray(ao.eri_ip1), n, what="HostedEvaluator.stage")
+                self._sym_checked = True
+            self._direct_slabs = slabs      # the producer's two pinned slabs ARE the staging buffers of this step
+            self._direct = {"eri": None, "eri_ip1": None}
+            return
         for k in ("S", "hcore", "ipovlp", "dhcore", "gnuc"):
             np.copyto(st[k], np.asarray(getattr(ao, k), dtype=np.float64).reshape(st[k].shape))
         st["enuc"][0] = float(ao.enuc)
@@ -158,6 +190,8 @@ class HostedEvaluator:
         #  enqueue replayed as a HIP graph: 555-590 us.)
         p0, p2 = self._slab_prefix
         e_src, i_src = self._direct["eri"], self._direct["eri_ip1"]
+        if self._direct_slabs is not None:
+            h0, h2 = self._direct_slabs
         with torch.cuda.stream(main):                     # submitted FIRST: the copy engine works in submission order
             if e_src is None:
                 d0.copy_(h0, non_blocking=True)

@@ -57,18 +57,30 @@ class AOArrays:
         (``MD_utils.get_scanner``), which then uploads them without a staging copy.  Needs integrals with the
         symmetries of real ones (declared by the result)."""
         import torch
-        n = self.nao
+        from .hosted import staging_layout
+        n, natm = self.nao, self.natm
         iu, ju = np.tril_indices(n)
         eri, ip1 = np.asarray(self.eri), np.asarray(self.eri_ip1)
         if eri.ndim == 4:
             eri = eri[iu, ju][:, iu, ju]
         if ip1.ndim == 5:
             ip1 = ip1[:, :, :, iu, ju]
-        pe = torch.from_numpy(np.ascontiguousarray(eri, dtype=np.float64)).pin_memory()
-        pi = torch.from_numpy(np.ascontiguousarray(ip1, dtype=np.float64)).pin_memory()
-        out = AOArrays(self.S, self.hcore, pe.numpy(), self.ipovlp, self.dhcore, pi.numpy(), self.aoslices, self.enuc,
-                       self.gnuc, integral_symmetry=True)
-        out._pinned = (pe, pi)       # (keeps the pinned allocations alive)
+        src = {"S": self.S, "hcore": self.hcore, "enuc": np.array([float(self.enuc)]), "ipovlp": self.ipovlp,
+               "gnuc": self.gnuc, "eri": eri, "dhcore": self.dhcore, "eri_ip1": ip1}
+        # ALL arrays in two pinned slabs laid out as the MD scanner's staging buffers are (hosted.staging_layout): the
+        # scanner then uploads the slabs as they stand -- two copies per step, no host-side copy at all
+        slabs, views = [], {}
+        for fields, total in staging_layout(n, natm, True):
+            t = torch.zeros(total, dtype=torch.float64).pin_memory()
+            for k, shp, off in fields:
+                v = t[off: off + int(np.prod(shp))].view(shp[1:] if k != "enuc" else shp).numpy()
+                np.copyto(v, np.asarray(src[k], dtype=np.float64).reshape(v.shape))
+                views[k] = v
+            slabs.append(t)
+        out = AOArrays(views["S"], views["hcore"], views["eri"], views["ipovlp"], views["dhcore"], views["eri_ip1"],
+                       self.aoslices, float(self.enuc), views["gnuc"], integral_symmetry=True)
+        out._staging_slabs = tuple(slabs)            # (keeps the pinned allocations alive)
+        out._staging_key = (n, natm, True)
         return out
 
 

@@ -228,6 +228,16 @@ def test_default_call_uses_the_compressed_path(n, T, A):
     np.testing.assert_allclose(gs, go, rtol=0, atol=1e-9)
     np.testing.assert_allclose(sc.base.predicted_one_rdm, Do, rtol=0, atol=1e-10)
     np.testing.assert_allclose(sc.base.predicted_two_rdm, np.asarray(Go).reshape(G.shape), rtol=0, atol=1e-10)
+    # an integral producer that leaves its output packed (s4 / s2kl) in pinned memory, laid out as the scanner's staging
+    # slabs are: uploaded from there as it stands (two copies per step when the geometry is copied at all)
+    mp = mol.pinned_packed()
+    assert mp.eri.shape == (n * (n + 1) // 2,) * 2 and mp.eri_ip1.shape == (3, n, n, n * (n + 1) // 2)
+    Ep, gp = sc(mp)
+    assert sc._hev.zero_copy or sc._hev._direct_slabs is not None
+    assert abs(Ep - Eo) < 1e-10
+    np.testing.assert_allclose(gp, go, rtol=0, atol=1e-9)
+    Ep2, gp2 = sc(mol)                                  # ... and back to a molecule that is staged by copying
+    assert sc._hev._direct_slabs is None and abs(Ep2 - Eo) < 1e-10
     # a general eri_ip1 (what the golden fixtures hold): the same call stays on the caller's layout, and is right
     gen = make_ao_arrays(n, A, 79 + n)
     S2, one2, two2 = make_trdms(n, T, 80 + n)
