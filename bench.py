@@ -382,6 +382,16 @@ def main():
     aos_run = run_view(aos, pairs_first)
     m = measure(trd, aos_run, G, 1 if pairs_first else S, a.steps, a.warmup, pairs_first, repeats=max(1, a.repeats))
 
+    # The headline is quoted on the LDS-ring K5 kernel, which needs >= 250 CUs (csrc/gemv_lds.hip: lds_device_fits); on a
+    # smaller or partitioned device the library falls back to the fragment-shaped kernel.  That is a different measurement:
+    # refuse to print a headline for it unless the fallback was asked for by name.
+    if (a.workload == "H30" and a.layout == "sym8" and G >= 12 and not pairs_first and not os.environ.get("EVC_ROWS_LDS")
+            and not os.environ.get("EVC_BENCH_ALLOW_FALLBACK") and not m["k5_kernel"].startswith("gemv_rows_lds_kernel")):
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        raise SystemExit(f"bench.py: K5 ran as `{m['k5_kernel']}` instead of gemv_rows_lds_kernel on rank {rank} "
+                         f"({cus} CUs visible; the LDS-ring kernel needs >= 250): this is not the configuration the "
+                         f"headline is defined on.  Set EVC_BENCH_ALLOW_FALLBACK=1 to measure the fallback anyway.")
+
     out = None
     if rank == 0:
         # HBM traffic of one K5 launch: PMC counters cannot be read from inside this process, so the figure comes from

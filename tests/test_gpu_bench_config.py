@@ -2,14 +2,18 @@
 batched K5 kernel.
 
 bench.py's default is H30 (N=30, A=30, T=20), compressed sym8 layout, 32 geometries per batch, int2e / int2e_ip1
-handed over packed (aosym s4 / s2kl): 210 rows = 14 row tiles -> ``gemv_rows_mfma_pipe_kernel<2,7,1,true>`` with
-two groups of seven tiles; its ``reference_layout`` leg is pack2 at 32 geometries (``<2,3,2,true>``, five groups).
+handed over packed (aosym s4 / s2kl): 210 rows = 14 row tiles -> the LDS-ring kernel ``gemv_rows_lds_kernel<2,7,2>``
+(two row groups of seven tiles), the pair transform ``ptd_kernel<1>`` / ``ptd_kernel<0>`` and ``y2d_kernel``
+(csrc/pair_dma.hip); its ``reference_layout`` leg is pack2 at 32 geometries (same K5 kernel over 810 000 columns).  The
+kernel names are ASSERTED below from what the library reports having launched (``evc_profile_kernel``), not assumed.
 Both are held here to ``oracle.energy_with_grad`` on the ORIGINAL pack2 rows and the full integral arrays
 (get_energy_with_grad, ab_initio_gradients_loewdin.py:308-379).  The same for BASELINE configs[4] (Zundel shape:
 N=28, AO slices 9,2,2,2,9,2,2, T=30 -> 465 rows) and configs[3] (H2O shape at T=10).
 
 Tolerances: |dE| <= 1e-8 Ha, |dgrad| <= 1e-6 Ha/Bohr (BASELINE.json north_star); the observed differences are
 three to four orders of magnitude below them."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -51,7 +55,9 @@ def _full_size_case(n, A, T, sizes, seed, G, slots, packed_inputs=True):
     be = BatchedEvaluator(trd, A, G)
     run = [a.packed_ip1(eri=True) for a in aos] if packed_inputs else aos
     got["sym8"] = be.energies_with_grads(DeviceAOBatch.stack(run))
-    worst = {}
+    from evcont_amd import _lib
+    ran = {k: _lib.load().evc_profile_kernel(i).decode() for i, k in enumerate(("k5", "k8", "pair_transform"))}
+    worst = {"kernels": ran}
     for leg, (E, grad) in got.items():
         de = max(abs(E[k] - want[k][0]) for k in slots)
         dg = max(float(np.abs(grad[k] - want[k][1]).max()) for k in slots)
@@ -62,8 +68,13 @@ def _full_size_case(n, A, T, sizes, seed, G, slots, packed_inputs=True):
 
 def test_h30_bench_default_against_oracle():
     """BASELINE configs[2] = the metric's configuration, exactly as bench.py runs it: G=32, sym8 + packed s4/s2kl
-    inputs (K5 <2,7,1>: ntile 7+7; row-split K8 over 210 rows) and pack2 (K5 <2,3,2>: five row groups)."""
+    inputs (K5 gemv_rows_lds_kernel<2,7,2>: row groups 7+7; pair transform ptd_kernel) and pack2."""
     worst = _full_size_case(30, 30, 20, None, 1236, 32, (0, 15, 16, 17, 31))
+    ran = worst.pop("kernels")
+    if not any(k.startswith("EVC_ROWS_LDS") for k in os.environ):
+        assert ran["k5"].startswith("gemv_rows_lds_kernel<2,7,2>"), ran
+    if not os.environ.get("EVC_PT_DMA"):
+        assert ran["pair_transform"].startswith("ptd_kernel"), ran
     for leg, (de, dg) in worst.items():
         assert de < 1e-10 and dg < 1e-9, (leg, de, dg)     # what the kernels actually deliver
 
@@ -98,8 +109,9 @@ def test_h2o_shape_t10_against_oracle():
 @pytest.mark.parametrize("T", [3, 7, 9, 10, 12, 13, 14, 15, 17, 18, 20])
 @pytest.mark.parametrize("G", [13, 17, 32])
 def test_k5_every_row_group_body(T, G):
-    """Small N (cheap oracle), many training states: every ``ntile`` body (1..7) of
-    ``gemv_rows_mfma_pipe_kernel`` for one (G=13) and two (G=17, 32) geometry sets, the row-split K8 with the same
+    """Small N (cheap oracle, 441 columns: below the 4096 the LDS-ring kernel asks for), many training states: every
+    ``ntile`` body (1..7) of the fragment-shaped ``gemv_rows_mfma_pipe_kernel`` for one (G=13) and two (G=17, 32)
+    geometry sets, the row-split K8 with the same
     row counts, energies AND forces of the first, a middle and the last slot against the oracle."""
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, DeviceAOBatch, BatchedEvaluator
     dev = torch.device("cuda:0")
@@ -122,9 +134,9 @@ def test_k5_every_row_group_body(T, G):
 
 @pytest.mark.parametrize("T,G", [(14, 32), (20, 32), (20, 17), (9, 32)])
 def test_k5_row_groups_wide_matrix(T, G):
-    """Matrices with more than 200 000 columns take the K5 shapes with row groups of <= 3 tiles (``<2,3,2,true>``,
-    ``<1,4,2,true>``) and the column-tiled K8: N = 26 in the pack2 layout has 228 826 columns; 105 / 210 / 45 rows
-    give 3+2+2, 3+3+3+3+2 and one group of 3 tiles."""
+    """Wide matrices in the reference's own layout: N = 26 in pack2 has 228 826 columns; 105 / 210 / 45 rows = 7 / 14 / 3
+    row tiles take the LDS-ring K5 shapes (csrc/gemv_lds.hip lds_pick_nt) and the column-tiled K8 (with EVC_ROWS_LDS=0,
+    tests/test_gpu_variants.py, the fragment-shaped kernels with row groups of <= 3 tiles)."""
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, BatchedEvaluator
     from evcont_amd.synthetic import make_device_ao, make_device_trdm_rows
     dev = torch.device("cuda:0")
