@@ -64,7 +64,7 @@ size_t rows_ws_doubles(int64_t rows, int64_t cols);
 int launch_gemv_rows(RowProblem p0, RowProblem p1, int count, hipStream_t st);
 int launch_gemv_cols(ColProblem p0, ColProblem p1, int count, hipStream_t st);
 
-// ---- transform.hip -----------------------------------------------------------------
+// ---- transform.hip, pack.hip, y2.hip, ip1.hip ----------------------------------------
 int launch_quarter_transform(const double *in, int64_t sin, const double *C, int64_t sC, int c_transposed, int n,
                              double *out, int64_t sout, int count, hipStream_t st);
 // Two quarter steps fused (n <= 32): out[r'][s'][p][q] = sum_rs in[p][q][r][s] C[r][r'] C[s][s'].
@@ -91,6 +91,9 @@ struct PairTransformArgs {
 // Row pitch of the pipeline's dense (pair, pair) intermediates: n(n+1)/2 rounded up to 16 doubles.
 __host__ __device__ inline int pair_ld(int n) { return (n * (n + 1) / 2 + 15) & ~15; }
 constexpr int kPairTransformMaxN = 32;
+// one packed operand row of the pair kernels in LDS (transform.hip pt_kernel, y2.hip y2_fused_kernel)
+constexpr int kPtRawMax = (kPairTransformMaxN * (kPairTransformMaxN + 1) / 2 + 1 + 127) / 128;   // double2 per lane: 5
+constexpr int kPtRowLen = kPtRawMax * 128 + 4;   // + two zero slots (padding fragments), 16-byte multiple
 int launch_pair_transform(const PairTransformArgs &a, int count, hipStream_t st);
 // pair_dma.hip: the fully symmetric dense (pair, pair) -> dense (pair, pair) step, 16 < n <= 30, operand rows by LDS-DMA
 bool pair_transform_dma_applicable(const PairTransformArgs &a, int count);

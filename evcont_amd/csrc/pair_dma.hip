@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void ptd_kernel(PairTransformArgs a) {
 }
 
 // ---------------------------------------------------------------------------------- Y2 with LDS-DMA operand rows
-// y2_fused_kernel (transform.hip) with the machinery above: per pair v one wave computes H^T = X^T M1_v (32 MFMAs) and
+// y2_fused_kernel (y2.hip) with the machinery above: per pair v one wave computes H^T = X^T M1_v (32 MFMAs) and
 // Y += mult(v) T_v H^T (32 MFMAs), M1_v = row v of the first pair step's intermediate, T_v = row v of SB, both dense
 // (pair, pair) forms at the pitch pair_ld(n).  The two rows come by LDS-DMA into two wave-private LDS rows; the T
 // fragments are read during the H phase and the next T row requested, the next M fragments during the Y phase and

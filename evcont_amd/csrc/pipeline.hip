@@ -114,7 +114,7 @@ static int stage_chunk(int count) { return count; }
 static bool reduce_in_own_launch(const Ws &w) { return w.rp2.nspans > 48; }
 
 static bool is_sym8(int layout) { return layout == EVC_LAYOUT_SYM8; }
-// Y2 with the half-transformed integrals recomputed (transform.hip y2_fused_kernel): the energy phase then keeps the
+// Y2 with the half-transformed integrals recomputed (y2.hip y2_fused_kernel): the energy phase then keeps the
 // dense (pair, pair) intermediate of its first pair step in the K3 buffer instead of writing K3 (EVC_Y2_FUSED=0: K3)
 static bool use_fused_y2(bool sym8, int n) {
     return sym8 && use_pair_transform(n) && y2_fused_available(n);

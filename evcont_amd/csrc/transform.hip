@@ -1,9 +1,9 @@
-// Four-index basis rotations on the FP64 matrix cores and the N^4-sized helpers around them.
+// Four-index basis rotations on the FP64 matrix cores.
 //   K3/K14  quarter transform (v_mfma_f64_16x16x4_f64)          electron_integral_utils.py:136,
 //                                                              gradients_loewdin.py:224-232,339
-//   a4/a5   pack / unpack of the electron-exchange symmetry     electron_integral_utils.py:38-88
-//   K13     Gs^T symmetrisation + Y2 = K3 . Gs contraction      gradients_loewdin.py:210-222
-//   K15     int2e_ip1 diagonal contraction                      gradients_loewdin.py:234-252
+//   pair transform of the compressed pipeline (pt_kernel and its pipelined forms: every N <= 32 the LDS-DMA kernel of
+//   pair_dma.hip does not take)
+// The N^4-sized helpers around them: pack.hip (pack / unpack), y2.hip (K13), ip1.hip (K15).
 // blockIdx.y = geometry of the batch (kernels.hpp).
 #include <stdlib.h>
 
@@ -153,8 +153,6 @@ int launch_quarter_transform(const double *in, int64_t sin, const double *C, int
 // doubles.  The wave fetches it with coalesced 16-byte loads (4-5 instructions of 1 KiB instead of 16 eight-byte
 // gathers that touch 64 cache lines each), parks it in a wave-private LDS row and reads its MFMA fragments from there
 // at lane-constant offsets tri(max(r,s), min(r,s)): triangular numbers of 16 consecutive r fall on 16 different banks.
-constexpr int kPtRawMax = (kPairTransformMaxN * (kPairTransformMaxN + 1) / 2 + 1 + 127) / 128;   // double2 per lane: 5
-constexpr int kPtRowLen = kPtRawMax * 128 + 4;   // + two zero slots (padding fragments), 16-byte multiple
 
 // Timing experiments (tools/micro/pt_stamps.py; build with EVC_DEBUG_STAMPS=1): the four waves of one workgroup in the
 // middle of the grid stamp their phases with the 100 MHz wall clock.  Compiled out of the product library.
@@ -1128,880 +1126,6 @@ int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t 
     }
     note_kernel(EVC_PROF_PAIR_TRANSFORM, "pt_kernel<%d,%d>", npad, rowbuf ? 1 : 0);
     EVC_LAUNCH_CHECK("pair_transform");
-    return 0;
-}
-
-// ------------------------------------------------------------------ pack / unpack
-__global__ void pack_kernel(const double *__restrict__ h2, int64_t sh2, int n, double mult, double *__restrict__ out,
-                            int64_t sout, int64_t M, int64_t out_len) {
-    const int64_t n2 = (int64_t)n * n;
-    h2 += (int64_t)blockIdx.y * sh2;
-    out += (int64_t)blockIdx.y * sout;
-    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < out_len;
-         m += (int64_t)gridDim.x * blockDim.x) {
-        double v = 0.0;
-        if (m < M) {
-            const int64_t R = tri_row(m), Cc = m - R * (R + 1) / 2;
-            v = h2[R * n2 + Cc];
-            if (R == Cc) v *= mult;
-        }
-        out[m] = v;
-    }
-}
-
-__global__ void unpack_kernel(const double *__restrict__ p, int64_t sp, int n, double *__restrict__ out,
-                              int64_t sout) {
-    const int64_t n2 = (int64_t)n * n, n4 = n2 * n2;
-    p += (int64_t)blockIdx.y * sp;
-    out += (int64_t)blockIdx.y * sout;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t R = idx / n2, Cc = idx - R * n2;
-        out[idx] = R >= Cc ? p[tri_index(R, Cc)] : p[tri_index(Cc, R)];
-    }
-}
-
-// 8-fold compressed form (EVC_LAYOUT_SYM8) of a tensor with the symmetries of real two-electron integrals
-__global__ void pack_sym8_kernel(const double *__restrict__ h2, int64_t sh2, int n, double mult,
-                                 double *__restrict__ out, int64_t sout, int64_t M, int64_t out_len) {
-    const int64_t n2 = (int64_t)n * n;
-    h2 += (int64_t)blockIdx.y * sh2;
-    out += (int64_t)blockIdx.y * sout;
-    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < out_len;
-         m += (int64_t)gridDim.x * blockDim.x) {
-        double v = 0.0;
-        if (m < M) {
-            const int64_t u = tri_row(m), w = m - u * (u + 1) / 2;
-            const int64_t i = tri_row(u), j = u - i * (i + 1) / 2;
-            const int64_t k = tri_row(w), l = w - k * (k + 1) / 2;
-            v = h2[(i * n + j) * n2 + k * n + l] *
-                ((u == w ? mult : 1.0) * (i != j ? 2.0 : 1.0) * (k != l ? 2.0 : 1.0));
-        }
-        out[m] = v;
-    }
-}
-
-static unsigned grid_for(int64_t work, int block) {
-    int64_t g = (work + block - 1) / block;
-    if (g > 8192) g = 8192;
-    if (g < 1) g = 1;
-    return (unsigned)g;
-}
-
-int launch_pack(const double *h2, int64_t sh2, int n, double mult, double *out, int64_t sout, int64_t out_len,
-                int count, hipStream_t st) {
-    const int64_t n2 = (int64_t)n * n, M = n2 * (n2 + 1) / 2;
-    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(out_len, 256), (unsigned)count), dim3(256), 0, st, h2, sh2, n, mult,
-                       out, sout, M, out_len);
-    EVC_LAUNCH_CHECK("pack_pair_sym");
-    return 0;
-}
-
-int launch_pack_sym8(const double *h2, int64_t sh2, int n, double mult, double *out, int64_t sout, int64_t out_len,
-                     int count, hipStream_t st) {
-    const int64_t mm = (int64_t)n * (n + 1) / 2, M = mm * (mm + 1) / 2;
-    hipLaunchKernelGGL(pack_sym8_kernel, dim3(grid_for(out_len, 256), (unsigned)count), dim3(256), 0, st, h2, sh2, n,
-                       mult, out, sout, M, out_len);
-    EVC_LAUNCH_CHECK("pack_sym8");
-    return 0;
-}
-
-int launch_unpack(const double *p, int64_t sp, int n, double *out, int64_t sout, int count, hipStream_t st) {
-    const int64_t n4 = (int64_t)n * n * n * n;
-    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(n4, 256), (unsigned)count), dim3(256), 0, st, p, sp, n, out, sout);
-    EVC_LAUNCH_CHECK("unpack_pair_sym");
-    return 0;
-}
-
-// ------------------------------------------------------------------ OAO symmetrisation (transposed)
-// GsT[(j,k,l)][i] = G[i,j,k,l] + G[j,i,k,l] + G[l,k,j,i] + G[k,l,i,j]
-__global__ void sym_oao_t_kernel(const double *__restrict__ G, int64_t sG, int n, double *__restrict__ out,
-                                 int64_t sout) {
-    const int64_t n2 = (int64_t)n * n, n3 = n2 * n, n4 = n2 * n2;
-    G += (int64_t)blockIdx.y * sG;
-    out += (int64_t)blockIdx.y * sout;
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n4;
-         o += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(o % n);
-        int64_t r = o / n;
-        const int l = (int)(r % n);
-        r /= n;
-        const int k = (int)(r % n);
-        const int j = (int)(r / n);
-        out[o] = G[i * n3 + j * n2 + k * n + l] + G[j * n3 + i * n2 + k * n + l] +
-                 G[l * n3 + k * n2 + j * n + i] + G[k * n3 + l * n2 + i * n + j];
-    }
-}
-
-int launch_sym_oao_t(const double *G, int64_t sG, int n, double *out, int64_t sout, int count, hipStream_t st) {
-    const int64_t n4 = (int64_t)n * n * n * n;
-    hipLaunchKernelGGL(sym_oao_t_kernel, dim3(grid_for(n4, 256), (unsigned)count), dim3(256), 0, st, G, sG, n, out,
-                       sout);
-    EVC_LAUNCH_CHECK("sym_oao_t");
-    return 0;
-}
-
-// ------------------------------------------------------------------ packed fast path: unpack + both symmetrisations
-// One workgroup per (j,k); its n*n elements (i,l) are produced with l fastest (coalesced SB/G rows),
-// staged in LDS and written to GsT with i fastest ((j,k) fixes a contiguous n*n block of GsT).
-__global__ __launch_bounds__(256) void unpack_sym_kernel(const double *__restrict__ p, int64_t sp, int n,
-                                                         double *__restrict__ GsT, double *__restrict__ SB,
-                                                         int64_t sws, double *__restrict__ Gout, int64_t sG,
-                                                         int count) {
-    extern __shared__ __align__(16) double tile[];  // [l][i], row length n+1
-    const int64_t n2 = (int64_t)n * n, n3 = n2 * n;
-    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; the blocks an XCD receives work
-    // through ONE geometry at a time, so that geometry's packed vector (3.2 MB at N=30) stays in the
-    // XCD's 4 MB L2 for the three gathers per element.
-    // The first count - count%8 geometries are laid out that way; the remainder (and any batch of fewer
-    // than 8) is spread over all XCDs in plain (geometry, jk) order.
-    const int nx = count & ~7;
-    const int64_t nxblocks = (int64_t)nx * n * n;
-    int geom, jk;
-    if ((int64_t)blockIdx.x < nxblocks) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        geom = (slot / (n * n)) * 8 + xcd;
-        jk = slot % (n * n);
-    } else {
-        const int64_t b = (int64_t)blockIdx.x - nxblocks;
-        geom = nx + (int)(b / (n * n));
-        jk = (int)(b % (n * n));
-    }
-    p += (int64_t)geom * sp;
-    GsT += (int64_t)geom * sws;
-    SB += (int64_t)geom * sws;
-    if (Gout) Gout += (int64_t)geom * sG;
-    const int j = jk / n, k = jk - j * n;
-    auto P = [&](int64_t a, int64_t b) { return a >= b ? p[tri_index(a, b)] : p[tri_index(b, a)]; };
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int i = idx / n, l = idx - i * n;
-        const int64_t o = i * n3 + j * n2 + k * n + l;
-        const int64_t R = (int64_t)i * n + j, Rt = (int64_t)j * n + i, Cc = (int64_t)k * n + l, Ct = (int64_t)l * n + k;
-        const double p1 = P(R, Cc), p2 = P(Rt, Cc), p3 = P(Rt, Ct);
-        SB[o] = 2.0 * (p1 + p3);
-        if (Gout) Gout[o] = p1;
-        tile[l * (n + 1) + i] = 2.0 * p1 + p2 + p3;
-    }
-    lds_barrier();
-    double *dst = GsT + ((int64_t)j * n + k) * n2;
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int l = idx / n, i = idx - l * n;
-        dst[idx] = tile[l * (n + 1) + i];
-    }
-}
-
-int launch_unpack_sym(const double *packed, int64_t sp, int n, double *GsT, double *SB, int64_t sws, double *G,
-                      int64_t sG, int count, hipStream_t st) {
-    const size_t lds = sizeof(double) * (size_t)n * (n + 1);
-    hipLaunchKernelGGL(unpack_sym_kernel, dim3((unsigned)(n * n * count)), dim3(256), lds, st, packed, sp, n, GsT, SB,
-                       sws, G, sG, count);
-    EVC_LAUNCH_CHECK("unpack_sym");
-    return 0;
-}
-
-// 8-fold compressed vector p8 of a fully symmetric 2-RDM (EVC_LAYOUT_SYM8) -> SB[i][j][k][l] = 4 p8(ijkl), the
-// operand of both the Y2 contraction and the OAO->AO rotation (every image of (i,j,k,l) is the same element, so
-// the two symmetrisations of the general path coincide), and optionally G = p8(ijkl).  One workgroup per (i,j)
-// writes a contiguous n*n block; same XCD-aware geometry order as above (0.87 MB per geometry at N = 30).
-// lead_half: SB is only needed for i >= j and l <= k (its consumers fold both symmetries).
-__global__ __launch_bounds__(256) void unpack8_kernel(const double *__restrict__ p, int64_t sp, int n,
-                                                      double *__restrict__ SB, int64_t sws,
-                                                      double *__restrict__ Gout, int64_t sG, int count,
-                                                      int lead_half) {
-    const int64_t n2 = (int64_t)n * n;
-    const int nx = count & ~7;
-    const int64_t nxblocks = (int64_t)nx * n * n;
-    int geom, ij;
-    if ((int64_t)blockIdx.x < nxblocks) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        geom = (slot / (n * n)) * 8 + xcd;
-        ij = slot % (n * n);
-    } else {
-        const int64_t b = (int64_t)blockIdx.x - nxblocks;
-        geom = nx + (int)(b / (n * n));
-        ij = (int)(b % (n * n));
-    }
-    const int i = ij / n, j = ij - i * n;
-    const bool want_sb = !(lead_half && i < j);
-    if (!want_sb && !Gout) return;
-    p += (int64_t)geom * sp;
-    double *sb = SB + (int64_t)geom * sws + (int64_t)ij * n2;
-    double *go = Gout ? Gout + (int64_t)geom * sG + (int64_t)ij * n2 : nullptr;
-    const int64_t u = i >= j ? tri_index(i, j) : tri_index(j, i);
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int k = idx / n, l = idx - k * n;
-        const int64_t v = k >= l ? tri_index(k, l) : tri_index(l, k);
-        const double val = u >= v ? p[tri_index(u, v)] : p[tri_index(v, u)];
-        if (want_sb && !(lead_half && l > k)) sb[idx] = 4.0 * val;
-        if (go) go[idx] = val;
-    }
-}
-
-// The same for lead_half without G: only the quarter i >= j, l <= k of SB is written.  One WAVE per pair (i,j),
-// its lanes run over v = tri(k,l) (the order of the compressed vector: the gather p8[tri(u,v)] is contiguous for
-// v <= u); 4 pairs per workgroup instead of one workgroup per (i,j) with half of them idle.
-__global__ __launch_bounds__(256) void unpack8_half_kernel(const double *__restrict__ p, int64_t sp, int n,
-                                                           double *__restrict__ SB, int64_t sws, int count) {
-    const int64_t n2 = (int64_t)n * n;
-    const int npairs = n * (n + 1) / 2;
-    const int bpg = (npairs + 3) / 4;   // workgroups per geometry
-    const int nx = count & ~7;
-    const int64_t nxblocks = (int64_t)nx * bpg;
-    int geom, blk;
-    if ((int64_t)blockIdx.x < nxblocks) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        geom = (slot / bpg) * 8 + xcd;
-        blk = slot % bpg;
-    } else {
-        const int64_t b = (int64_t)blockIdx.x - nxblocks;
-        geom = nx + (int)(b / bpg);
-        blk = (int)(b % bpg);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int u = blk * 4 + wave;
-    if (u >= npairs) return;
-    const int i = (int)tri_row(u), j = u - i * (i + 1) / 2;
-    p += (int64_t)geom * sp;
-    double *sb = SB + (int64_t)geom * sws + ((int64_t)i * n + j) * n2;
-    for (int v = lane; v < npairs; v += 64) {
-        const int k = (int)tri_row(v), l = v - k * (k + 1) / 2;
-        const double val = u >= v ? p[tri_index(u, v)] : p[tri_index(v, u)];
-        sb[k * n + l] = 4.0 * val;
-    }
-}
-
-// Dense (pair, pair) form of the same: SB[u][v] = 4 p8[tri(max(u,v), min(u,v))], u = tri(i,j), v = tri(k,l) -- the
-// symmetric matrix the compressed vector is the lower triangle of.  One wave per row u.
-__global__ __launch_bounds__(256) void unpack8_pairs_kernel(const double *__restrict__ p, int64_t sp, int n,
-                                                            double *__restrict__ SB, int64_t sws, int count, int ld) {
-    const int npairs = n * (n + 1) / 2;
-    const int bpg = (npairs + 3) / 4;   // workgroups per geometry
-    const int nx = count & ~7;
-    const int64_t nxblocks = (int64_t)nx * bpg;
-    int geom, blk;
-    if ((int64_t)blockIdx.x < nxblocks) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        geom = (slot / bpg) * 8 + xcd;
-        blk = slot % bpg;
-    } else {
-        const int64_t b = (int64_t)blockIdx.x - nxblocks;
-        geom = nx + (int)(b / bpg);
-        blk = (int)(b % bpg);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int u = blk * 4 + wave;
-    if (u >= npairs) return;
-    p += (int64_t)geom * sp;
-    double *sb = SB + (int64_t)geom * sws + (int64_t)u * ld;   // (rows at the pitch pair_ld(n) of the pipeline's dense forms)
-    for (int v = lane; v < npairs; v += 64) sb[v] = 4.0 * (u >= v ? p[tri_index(u, v)] : p[tri_index(v, u)]);
-}
-
-int launch_unpack8(const double *packed, int64_t sp, int n, double *SB, int64_t sws, double *G, int64_t sG, int count,
-                   int lead_half, hipStream_t st) {
-    if (lead_half == 2 && !G) {
-        const int bpg = (n * (n + 1) / 2 + 3) / 4;
-        hipLaunchKernelGGL(unpack8_pairs_kernel, dim3((unsigned)(bpg * count)), dim3(256), 0, st, packed, sp, n, SB,
-                           sws, count, pair_ld(n));
-        EVC_LAUNCH_CHECK("unpack8_pairs");
-        return 0;
-    }
-    if (lead_half && !G) {
-        const int bpg = (n * (n + 1) / 2 + 3) / 4;
-        hipLaunchKernelGGL(unpack8_half_kernel, dim3((unsigned)(bpg * count)), dim3(256), 0, st, packed, sp, n, SB, sws,
-                           count);
-        EVC_LAUNCH_CHECK("unpack8_half");
-        return 0;
-    }
-    hipLaunchKernelGGL(unpack8_kernel, dim3((unsigned)(n * n * count)), dim3(256), 0, st, packed, sp, n, SB, sws, G, sG,
-                       count, lead_half);
-    EVC_LAUNCH_CHECK("unpack8");
-    return 0;
-}
-
-// ------------------------------------------------------------------ Y2 contraction (split-K MFMA GEMM)
-// partial[slab][i][a] = sum_{k in slab} GsT[k][i] * K3[k][a],  k = (j,k,l) flattened, n^3 long.
-// Both operands are [k][n] row-major, so each MFMA fragment load is 16 contiguous doubles.
-// number of K slabs = partial results per geometry (fixed for the life of the process: it sizes the workspace)
-static int y2_slab_count() {
-    static const int v = [] {
-        return 64;
-    }();
-    return v;
-}
-int y2_slabs(int) { return y2_slab_count(); }
-// slabs the partial buffer of the pipeline is sized for (the fused kernel below uses up to that many workgroups)
-int y2_slab_capacity(int) { return y2_slab_count() > 128 ? y2_slab_count() : 128; }
-
-template <int NT>
-__global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT, const double *__restrict__ K3,
-                                                 int n, int64_t ktot, double *__restrict__ partial, int64_t sws) {
-    __shared__ double red[4][NT * 16][NT * 16 + 1];
-    GsT += (int64_t)blockIdx.y * sws;
-    K3 += (int64_t)blockIdx.y * sws;
-    partial += (int64_t)blockIdx.y * sws;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int64_t ksteps = (ktot + 3) / 4;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    const int64_t per = (ksteps + nw - 1) / nw;
-    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t ks0 = w * per, ks1 = min(ksteps, ks0 + per);
-    // n > 64: the (n, n) result is produced in 64 x 64 quadrants, one per blockIdx.z
-    const int ioff = (int)(blockIdx.z >> 1) * 64, aoff = (int)(blockIdx.z & 1) * 64;
-    d4 acc[NT][NT];
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int64_t ks = ks0; ks < ks1; ++ks) {
-        const int64_t k = ks * 4 + l4;
-        const bool kok = k < ktot;
-        double af[NT], bf[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int c = t * 16 + l15;
-            af[t] = (kok && ioff + c < n) ? GsT[k * n + ioff + c] : 0.0;
-            bf[t] = (kok && aoff + c < n) ? K3[k * n + aoff + c] : 0.0;
-        }
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(af[ti], bf[ta], acc[ti][ta]);
-    }
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
-    __syncthreads();
-    double *dst = partial + (int64_t)blockIdx.x * n * n;
-    for (int idx = threadIdx.x; idx < NT * 16 * NT * 16; idx += 256) {
-        const int il = idx / (NT * 16), al = idx % (NT * 16);
-        const int i = ioff + il, a = aoff + al;
-        if (i < n && a < n) dst[(int64_t)i * n + a] = (red[0][il][al] + red[1][il][al]) + (red[2][il][al] + red[3][il][al]);
-    }
-}
-
-// Same contraction with the first operand given as SB[i][k] (row i = n^3 contiguous doubles), i.e.
-// partial[slab][i][a] = sum_{k in slab} SB[i][k] * K3[k][a]: for a fully symmetric 2-RDM the transposed operand GsT
-// of the general path is SB itself read row-wise.  A lane fetches two consecutive k of "its" row i with one 16-byte
-// load and feeds them to two MFMAs (the K slot of a lane can be any k as long as both operands agree).
-template <int NT>
-__global__ __launch_bounds__(256) void y2_sb_kernel(const double *__restrict__ SB, const double *__restrict__ K3,
-                                                    int n, int64_t ktot, double *__restrict__ partial, int64_t sws) {
-    __shared__ double red[4][NT * 16][NT * 16 + 1];
-    SB += (int64_t)blockIdx.y * sws;
-    K3 += (int64_t)blockIdx.y * sws;
-    partial += (int64_t)blockIdx.y * sws;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int64_t ksteps = (ktot + 7) / 8;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    const int64_t per = (ksteps + nw - 1) / nw;
-    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t ks0 = w * per, ks1 = min(ksteps, ks0 + per);
-    const bool even = (ktot & 1) == 0;  // rows of SB start 16-byte aligned
-    // n > 64: the (n, n) result is produced in 64 x 64 quadrants, one per blockIdx.z
-    const int ioff = (int)(blockIdx.z >> 1) * 64, aoff = (int)(blockIdx.z & 1) * 64;
-    const double *__restrict__ arow[NT];
-    bool cok[NT], bok[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int c = t * 16 + l15;
-        cok[t] = ioff + c < n;
-        bok[t] = aoff + c < n;
-        arow[t] = SB + (int64_t)(cok[t] ? ioff + c : 0) * ktot;
-    }
-    d4 acc[NT][NT];
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int64_t ks = ks0; ks < ks1; ++ks) {
-        const int64_t k = ks * 8 + 2 * l4;
-        const bool k0ok = k < ktot, k1ok = k + 1 < ktot;
-        double2 af[NT];
-        double b0[NT], b1[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (even)
-                af[t] = (cok[t] && k0ok) ? *reinterpret_cast<const double2 *>(arow[t] + k) : make_double2(0.0, 0.0);
-            else
-                af[t] = make_double2((cok[t] && k0ok) ? arow[t][k] : 0.0, (cok[t] && k1ok) ? arow[t][k + 1] : 0.0);
-            const int c = aoff + t * 16 + l15;
-            b0[t] = (bok[t] && k0ok) ? K3[k * n + c] : 0.0;
-            b1[t] = (bok[t] && k1ok) ? K3[(k + 1) * n + c] : 0.0;
-        }
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(af[ti].x, b0[ta], acc[ti][ta]);
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int ta = 0; ta < NT; ++ta) acc[ti][ta] = mfma_f64(af[ti].y, b1[ta], acc[ti][ta]);
-    }
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][ti * 16 + l4 + 4 * r][ta * 16 + l15] = acc[ti][ta][r];
-    __syncthreads();
-    double *dst = partial + (int64_t)blockIdx.x * n * n;
-    for (int idx = threadIdx.x; idx < NT * 16 * NT * 16; idx += 256) {
-        const int il = idx / (NT * 16), al = idx % (NT * 16);
-        const int i = ioff + il, a = aoff + al;
-        if (i < n && a < n) dst[(int64_t)i * n + a] = (red[0][il][al] + red[1][il][al]) + (red[2][il][al] + red[3][il][al]);
-    }
-}
-
-// ------------------------------------------------------------------ Y2 with the half-transformed integrals recomputed
-// The reference's Y2 = sum K3 . Gamma~ needs K3p[j][v][a] = mult(v) (M1_v X)[a][j]; rounds 1-2 had the second pair step of
-// the energy phase store it (107 MB per 32 geometries at N = 30: +18 us there) and a split-K contraction read it back
-// (y2_pairs_kernel, removed in round 4).  M1_v -- row v of
-// the dense (pair, pair) intermediate of the FIRST pair step, a symmetric N x N matrix -- is 16x smaller, and
-// SB[tri(i,j)][v] = SB[v][tri(i,j)] is a contiguous row of the symmetric SB as well, so one wave per pair v does
-//   H^T = X^T M1_v            (32 MFMAs at N <= 32; X fragments as A operand, the fragments of the symmetric M1_v as B)
-//   Y  += mult(v) T_v H^T     (32 MFMAs; T_v = row v of SB as A operand, the accumulator tiles of H^T as B operand:
-//                              row 4 kk + (l >> 4) of H^T lives in register kk % 4 of its row tile kk / 4)
-// with both rows fetched like the operand rows of the pair transform (coalesced 16-byte loads, wave-private LDS row,
-// lane-constant triangle offsets) one pair ahead.  No stage, no stores but the (N, N) partial of the workgroup.
-template <int NPAD>
-__global__ __launch_bounds__(256) void y2_fused_kernel(const double *__restrict__ SB, const double *__restrict__ M1,
-                                                       const double *__restrict__ X, int64_t sX, int n,
-                                                       double *__restrict__ partial, int64_t sws, int tiles_per_wg,
-                                                       int ppt) {
-    constexpr int KS = NPAD / 4;
-    constexpr int NT = NPAD / 16;
-    constexpr int RAWN = (NPAD * (NPAD + 1) / 2 + 1 + 127) / 128;
-    extern __shared__ __align__(16) double sm[];
-    const int npairs = n * (n + 1) / 2, ld = pair_ld(n);   // both operands are dense (pair, pair) forms of the pipeline
-    const int64_t g = blockIdx.y;
-    SB += g * sws;
-    M1 += g * sws;
-    X += g * sX;
-    partial += g * sws;
-    const int ntiles = (npairs + ppt - 1) / ppt;   // ppt = 8 or 4 pairs per tile (two / one matrix per wave)
-    const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    double *rowM = sm + wave * kPtRowLen;             // the wave's two operand rows
-    double *rowT = sm + (4 + wave) * kPtRowLen;
-    double *red = sm;                                 // [4][NPAD][NPAD + 1], over the rows once they are done with
-    d4 yacc[NT][NT];
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta) yacc[ti][ta] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (t_begin < t_end) {
-        const int niter = (ppt / 4) * (t_end - t_begin);
-        int foff[NT][KS];   // fragment (rt, kk) of a symmetric n x n matrix in its packed row
-#pragma unroll
-        for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const int r = rt * 16 + l15, s = 4 * kk + l4;
-                const int hi = s > r ? s : r, lo = s > r ? r : s;
-                foff[rt][kk] = (r < n && s < n) ? hi * (hi + 1) / 2 + lo : kPtRawMax * 128;   // else: a zero slot
-            }
-        if (lane < 4) {
-            rowM[kPtRawMax * 128 + lane] = 0.0;
-            rowT[kPtRawMax * 128 + lane] = 0.0;
-        }
-        d2 rawM[RAWN], rawT[RAWN];
-        auto fetch = [&](const double *base, int e, d2 (&raw)[RAWN]) -> int {
-            const double *row = base + (int64_t)(e < npairs ? e : 0) * ld;
-            const int d_ = (int)((reinterpret_cast<uintptr_t>(row) >> 3) & 1);
-            const double *w0 = row - d_;
-            const int lim = npairs + d_;
-#pragma unroll
-            for (int u = 0; u < RAWN; ++u) {
-                const int j = 128 * u + 2 * lane;
-                raw[u] = *reinterpret_cast<const d2 *>(w0 + (j < lim ? j : 0));
-            }
-            return d_;
-        };
-        auto park = [&](double *row, const d2 (&raw)[RAWN]) {
-#pragma unroll
-            for (int u = 0; u < RAWN; ++u) *reinterpret_cast<d2 *>(row + 128 * u + 2 * lane) = raw[u];
-        };
-        auto is_diag = [&](int x) -> bool {
-            const int r = tri_row_small(x);
-            return x == r * (r + 3) / 2;
-        };
-        const int e0 = ppt * t_begin + wave;   // this wave's pair of iteration i: e0 + 4 i
-        int dM = fetch(M1, e0, rawM), dT = fetch(SB, e0, rawT);
-        double xf[KS][NT];
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int d = 4 * kk + l4, c = t * 16 + l15;
-                const bool ok = d < n && c < n;
-                const double v = X[ok ? d * n + c : 0];
-                xf[kk][t] = ok ? v : 0.0;
-            }
-        double mf[NT][KS], tf[NT][KS];
-        park(rowM, rawM);
-#pragma unroll
-        for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = rowM[foff[rt][kk] + dM];
-        dM = fetch(M1, e0 + 4, rawM);
-        // Iteration i: the T row (fetched one iteration ago) goes to LDS and comes back as fragments behind the MFMAs of
-        // the H^T phase (which does not use them) and the next T row is requested; the next M row goes to LDS and comes
-        // back behind the MFMAs of the Y phase (which does not use the M fragments), then the M row after that is
-        // requested.  No branches in the body: idle slots of the last tile run on row 0 with multiplicity 0.
-        for (int i = 0; i < niter; ++i) {
-            const int e = e0 + 4 * i;
-            const double km = e < npairs ? (is_diag(e) ? 1.0 : 2.0) : 0.0;   // multiplicity of the pair (p,q)
-            park(rowT, rawT);
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) tf[rt][kk] = rowT[foff[rt][kk] + dT];
-            dT = fetch(SB, e + 4, rawT);
-            d4 hT[NT][NT];   // H^T = X^T M: tile (it, st) = rows s' of tile it, columns r of tile st
-#pragma unroll
-            for (int it = 0; it < NT; ++it)
-#pragma unroll
-                for (int st = 0; st < NT; ++st) hT[it][st] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                for (int it = 0; it < NT; ++it)
-#pragma unroll
-                    for (int st = 0; st < NT; ++st) hT[it][st] = mfma_f64(xf[kk][it], mf[st][kk], hT[it][st]);
-            park(rowM, rawM);
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) mf[rt][kk] = rowM[foff[rt][kk] + dM];
-            dM = fetch(M1, e + 8, rawM);
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                for (int ti = 0; ti < NT; ++ti) {
-                    const double tv = tf[ti][kk] * km;
-#pragma unroll
-                    for (int ta = 0; ta < NT; ++ta)
-                        yacc[ti][ta] = mfma_f64(tv, hT[kk / 4][ta][kk % 4], yacc[ti][ta]);
-                }
-        }
-    }
-    // cross-wave sum (every workgroup writes its slab, workgroups without tiles a zero one)
-    __syncthreads();
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                red[(wave * NPAD + ti * 16 + l4 + 4 * r) * (NPAD + 1) + ta * 16 + l15] = yacc[ti][ta][r];
-    __syncthreads();
-    double *dst = partial + (int64_t)blockIdx.x * n * n;
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int i = idx / n, aa = idx % n;
-        const int o = i * (NPAD + 1) + aa;
-        constexpr int WS = NPAD * (NPAD + 1);
-        dst[idx] = (red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o]);
-    }
-}
-
-// 8-pair tiles per workgroup: 4 for batches (as the pair transform), 1 for a few geometries (enough workgroups for the
-// chip), never more workgroups than the partial buffer has slabs
-static int y2_fused_ppt(int count) { return count < 4 ? 4 : 8; }   // pairs per tile: 4 (one matrix per wave) for a few geometries
-static int y2_fused_tiles(int n, int count) {
-    const int ppt = y2_fused_ppt(count);
-    const int ntiles = (n * (n + 1) / 2 + ppt - 1) / ppt;
-    int t = count < 4 ? 1 : 4;
-    while ((ntiles + t - 1) / t > y2_slab_capacity(n)) ++t;
-    return t;
-}
-bool y2_fused_available(int n) { return n >= 1 && n <= kPairTransformMaxN; }
-int y2_fused_slabs(int n, int count) {
-    const int ppt = y2_fused_ppt(count);
-    const int ntiles = (n * (n + 1) / 2 + ppt - 1) / ppt, t = y2_fused_tiles(n, count);
-    return (ntiles + t - 1) / t;
-}
-int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial,
-                    int64_t sws, int count, hipStream_t st) {
-    if (y2_dma_applicable(n))
-        return launch_y2_dma(SB, M1, X, sX, n, partial, sws, count, y2_fused_slabs(n, count), y2_fused_tiles(n, count),
-                             y2_fused_ppt(count), st);
-    const dim3 grid((unsigned)y2_fused_slabs(n, count), (unsigned)count);
-    const int npad = (n + 15) / 16 * 16;
-    const size_t rows = sizeof(double) * (size_t)8 * kPtRowLen;
-    if (npad == 16) {
-        const size_t redb = sizeof(double) * 4 * 16 * 17;
-        hipLaunchKernelGGL(y2_fused_kernel<16>, grid, dim3(256), rows > redb ? rows : redb, st, SB, M1, X, sX, n, partial,
-                           sws, y2_fused_tiles(n, count), y2_fused_ppt(count));
-    } else if (npad == 32) {
-        const size_t redb = sizeof(double) * 4 * 32 * 33;
-        hipLaunchKernelGGL(y2_fused_kernel<32>, grid, dim3(256), rows > redb ? rows : redb, st, SB, M1, X, sX, n, partial,
-                           sws, y2_fused_tiles(n, count), y2_fused_ppt(count));
-    } else {
-        set_error("y2_fused: n=%d not supported (1..32)", n);
-        return -1;
-    }
-    note_kernel(EVC_PROF_Y2, "y2_fused_kernel<%d>", npad);
-    EVC_LAUNCH_CHECK("y2_fused");
-    return 0;
-}
-
-int launch_y2_sb(const double *SB, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
-    const int64_t ktot = (int64_t)n * n * n;
-    const int nt = (n + 15) / 16;
-    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count, nt > 4 ? 4u : 1u);   // n > 64: four 64 x 64 quadrants
-    switch (nt) {
-        case 1: hipLaunchKernelGGL(y2_sb_kernel<1>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
-        case 2: hipLaunchKernelGGL(y2_sb_kernel<2>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
-        case 3: hipLaunchKernelGGL(y2_sb_kernel<3>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
-        case 4: case 5: case 6: case 7: case 8:
-            hipLaunchKernelGGL(y2_sb_kernel<4>, grid, dim3(256), 0, st, SB, K3, n, ktot, partial, sws); break;
-        default: set_error("y2: n=%d not supported by the gradient path (1..128)", n); return -1;
-    }
-    EVC_LAUNCH_CHECK("y2_sb");
-    return 0;
-}
-
-int launch_y2(const double *GsT, const double *K3, int n, double *partial, int64_t sws, int count, hipStream_t st) {
-    const int64_t ktot = (int64_t)n * n * n;
-    const int nt = (n + 15) / 16;
-    const dim3 grid((unsigned)y2_slab_count(), (unsigned)count, nt > 4 ? 4u : 1u);   // n > 64: four 64 x 64 quadrants
-    switch (nt) {
-        case 1: hipLaunchKernelGGL(y2_kernel<1>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
-        case 2: hipLaunchKernelGGL(y2_kernel<2>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
-        case 3: hipLaunchKernelGGL(y2_kernel<3>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
-        case 4: case 5: case 6: case 7: case 8:
-            hipLaunchKernelGGL(y2_kernel<4>, grid, dim3(256), 0, st, GsT, K3, n, ktot, partial, sws); break;
-        default: set_error("y2: n=%d not supported by the gradient path (1..128)", n); return -1;
-    }
-    EVC_LAUNCH_CHECK("y2");
-    return 0;
-}
-
-// ------------------------------------------------------------------ ip1 contraction + dhcore dots + slab sums
-// t2part[(m*3+x)*nchunk + ch] = sum_{e in chunk ch} ip1[x][m][e] * GsAO[m][e],  e = (b,c,d)
-// GsAO[m,b,c,d] = G[m,b,c,d] + G[b,m,d,c] + G[c,d,m,b] + G[d,c,b,m]   (G = 2-RDM in the AO basis)
-// Blocks [nb1, nb1 + 3A): term3[A*3+x] = sum_ab dhcore[A,x,a,b] * Pao[a,b].
-// Remaining blocks: y2[e] = sum_slab y2part[slab][e].
-// elements of the (b,c,d) range per thread (sizes the t2part workspace)
-static int ip1_per_thread() {
-    static const int pt = [] {
-        return 8;
-    }();
-    return pt;
-}
-int ip1_chunks(int n) {
-    // (at least n: the pair-block form of the packed contraction files its partials under the partner index b)
-    const int64_t n3 = (int64_t)n * n * n;
-    const int c = (int)ceil_div(n3, 256 * ip1_per_thread());
-    return c > n ? c : n;
-}
-
-template <int kIp1PerThread>
-__global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
-    __shared__ double scr[3][4];
-    __shared__ double part[4][64];
-    const int n = a.n, nchunk = a.nchunk;
-    const int64_t n2 = (int64_t)n * n, n3 = n2 * n, n4 = n2 * n2;
-    const int64_t g = blockIdx.y;
-    const bool pair_blocks = a.presym && a.fold_cd && a.ip1_s2kl;
-    const int nb1 = pair_blocks ? n * (n + 1) / 2 : n * nchunk;
-    if (pair_blocks && (int)blockIdx.x < nb1) {
-        // int2e_ip1 packed in (c,d), c >= d, against the dense (pair, pair) AO-basis 2-RDM G[tri(m,b)][v] (rows at the
-        // pitch pair_ld(n); the weight 2 of c != d is applied here): one block per unordered pair {m, b} -- the row G[tri(hi,lo)][:]
-        // is read once and contracted with ip1[x][hi][lo][:] (-> t2[x][hi], filed under partner lo) and, for
-        // hi != lo, with ip1[x][lo][hi][:] (-> t2[x][lo], partner hi): 7 contiguous streams of n(n+1)/2 doubles
-        const double *__restrict__ ip1 = a.ip1 + g * a.sip1;
-        const double *__restrict__ G = a.Gao + g * a.sws;
-        const int npr = n * (n + 1) / 2;
-        const int pidx = blockIdx.x, hi = tri_row_small(pidx), lo = pidx - hi * (hi + 1) / 2;
-        const int64_t len = (int64_t)n * npr;          // one (x, m) block of ip1
-        const double *__restrict__ gr = G + (int64_t)pidx * pair_ld(n);
-        const double *__restrict__ qh = ip1 + ((int64_t)hi * n + lo) * npr;
-        const double *__restrict__ ql = ip1 + ((int64_t)lo * n + hi) * npr;
-        const bool both = hi != lo;
-        double ah[3] = {0.0, 0.0, 0.0}, al[3] = {0.0, 0.0, 0.0};
-        // two adjacent elements per lane: seven 16-byte loads in flight per lane (the int2e_ip1 rows of the caller's s2kl
-        // array start on any multiple of 8 bytes: loads typed with 8-byte alignment)
-        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-        for (int v = 2 * threadIdx.x; v < npr; v += 512) {
-            const int vc = tri_row_small(v), vc1 = tri_row_small(v + 1);
-            // multiplicity of the pair (c,d), c >= d: 1 on the diagonal, else 2
-            const double w0 = v == vc * (vc + 3) / 2 ? 1.0 : 2.0, w1 = (v + 1) == vc1 * (vc1 + 3) / 2 ? 1.0 : 2.0;
-            if (v + 1 < npr) {
-                const d2u gg = *reinterpret_cast<const d2u *>(gr + v);
-                const double g0 = gg[0] * w0, g1 = gg[1] * w1;
-#pragma unroll
-                for (int x = 0; x < 3; ++x) {
-                    const d2u q = *reinterpret_cast<const d2u *>(qh + (int64_t)x * n * len + v);
-                    ah[x] = fma(q[1], g1, fma(q[0], g0, ah[x]));
-                    if (both) {
-                        const d2u r = *reinterpret_cast<const d2u *>(ql + (int64_t)x * n * len + v);
-                        al[x] = fma(r[1], g1, fma(r[0], g0, al[x]));
-                    }
-                }
-            } else {
-                const double g0 = gr[v] * w0;
-#pragma unroll
-                for (int x = 0; x < 3; ++x) {
-                    ah[x] = fma(qh[(int64_t)x * n * len + v], g0, ah[x]);
-                    if (both) al[x] = fma(ql[(int64_t)x * n * len + v], g0, al[x]);
-                }
-            }
-        }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        __shared__ double pr6[6][4];
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            const double sh = wave_sum(ah[x]), sl = wave_sum(al[x]);
-            if (lane == 0) {
-                pr6[x][wave] = sh;
-                pr6[3 + x][wave] = sl;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 6) {
-            const int x = threadIdx.x % 3, role = threadIdx.x / 3;
-            const double t = (pr6[threadIdx.x][0] + pr6[threadIdx.x][1]) + (pr6[threadIdx.x][2] + pr6[threadIdx.x][3]);
-            double *tp = a.t2part + g * a.sws;
-            if (role == 0) tp[((int64_t)hi * 3 + x) * nchunk + lo] = t;
-            else if (both) tp[((int64_t)lo * 3 + x) * nchunk + hi] = t;
-        }
-        if (lo == 0 && nchunk > n) {   // slots behind the n partners (only if the chunk count exceeds n)
-            double *tp = a.t2part + g * a.sws;
-            for (int idx = threadIdx.x; idx < 3 * (nchunk - n); idx += 256)
-                tp[((int64_t)hi * 3 + idx / (nchunk - n)) * nchunk + n + idx % (nchunk - n)] = 0.0;
-        }
-    } else if ((int)blockIdx.x < nb1) {
-        const double *__restrict__ ip1 = a.ip1 + g * a.sip1;
-        const double *__restrict__ G = a.Gao + g * a.sws;
-        const int m = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        const int64_t e0 = (int64_t)ch * 256 * kIp1PerThread;
-        if (a.presym && a.fold_cd && (n & 1) == 0) {
-            // symmetrised operand that is only valid for d <= c (and symmetric in c <-> d, like ip1 itself): the
-            // dot runs over the lower triangles with weight 2 off the diagonal.  The 16-byte pairs (d, d+1), d even,
-            // d <= c, of one b are numbered row by row (rows 2h and 2h+1 hold h+1 pairs each, h(h+1) pairs precede
-            // row 2h), so every lane of the chunk has a live pair; n is even here.
-            const int hp = n / 2, ppb = hp * (hp + 1);
-            const int64_t npairs = (int64_t)n * ppb;
-            const int64_t per = (npairs + nchunk - 1) / nchunk;
-            const int64_t pe = min(npairs, (int64_t)(ch + 1) * per);
-            for (int64_t ep = (int64_t)ch * per + threadIdx.x; ep < pe; ep += 256) {
-                const int b = (int)(ep / ppb), t = (int)(ep - (int64_t)b * ppb);
-                int h = (int)sqrt((double)t);
-                while (h * (h + 1) > t) --h;
-                while ((h + 1) * (h + 2) <= t) ++h;
-                const int tp = t - h * (h + 1);
-                const int up = tp >= h + 1 ? 1 : 0;
-                const int c = 2 * h + up, d = 2 * (tp - up * (h + 1));
-                const int64_t off = m * n3 + (int64_t)b * n2 + c * n + d;
-                // the operand is also symmetric in m <-> b and only stored for b <= m
-                const int64_t goff = b <= m ? off : (int64_t)b * n3 + (int64_t)m * n2 + c * n + d;
-                const double2 gr = *reinterpret_cast<const double2 *>(G + goff);
-                const double2 p0 = *reinterpret_cast<const double2 *>(ip1 + off);
-                const double2 p1 = *reinterpret_cast<const double2 *>(ip1 + n4 + off);
-                const double2 p2 = *reinterpret_cast<const double2 *>(ip1 + 2 * n4 + off);
-                const double gx = d < c ? 2.0 * gr.x : gr.x;
-                const double gy = d + 1 < c ? 2.0 * gr.y : (d + 1 == c ? gr.y : 0.0);
-                a0 = fma(p0.y, gy, fma(p0.x, gx, a0));
-                a1 = fma(p1.y, gy, fma(p1.x, gx, a1));
-                a2 = fma(p2.y, gy, fma(p2.x, gx, a2));
-            }
-        } else if (a.presym && (n3 & 1) == 0) {
-            // symmetrised operand: a plain streaming dot, 16-byte loads
-#pragma unroll
-            for (int u = 0; u < kIp1PerThread / 2; ++u) {
-                const int64_t e = e0 + ((int64_t)u * 256 + threadIdx.x) * 2;
-                if (e < n3) {
-                    const int64_t off = m * n3 + e;
-                    const double2 gs = *reinterpret_cast<const double2 *>(G + off);
-                    const double2 p0 = *reinterpret_cast<const double2 *>(ip1 + off);
-                    const double2 p1 = *reinterpret_cast<const double2 *>(ip1 + n4 + off);
-                    const double2 p2 = *reinterpret_cast<const double2 *>(ip1 + 2 * n4 + off);
-                    a0 = fma(p0.y, gs.y, fma(p0.x, gs.x, a0));
-                    a1 = fma(p1.y, gs.y, fma(p1.x, gs.x, a1));
-                    a2 = fma(p2.y, gs.y, fma(p2.x, gs.x, a2));
-                }
-            }
-        } else
-#pragma unroll
-        for (int u = 0; u < kIp1PerThread; ++u) {
-            const int64_t e = e0 + u * 256 + threadIdx.x;
-            if (e < n3) {
-                const int d = (int)(e % n);
-                const int c = (int)((e / n) % n);
-                const int b = (int)(e / n2);
-                if (a.fold_cd && d > c) continue;
-                double gs = a.presym ? (a.fold_cd && b > m ? G[(int64_t)b * n3 + (int64_t)m * n2 + c * n + d] : G[m * n3 + e])
-                                     : G[m * n3 + e] + G[b * n3 + m * n2 + d * n + c] +
-                                           G[c * n3 + d * n2 + m * n + b] + G[d * n3 + c * n2 + b * n + m];
-                if (a.fold_cd && d < c) gs *= 2.0;
-                const int64_t off = m * n3 + e;
-                a0 = fma(ip1[off], gs, a0);
-                a1 = fma(ip1[n4 + off], gs, a1);
-                a2 = fma(ip1[2 * n4 + off], gs, a2);
-            }
-        }
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        a2 = wave_sum(a2);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) {
-            scr[0][wave] = a0;
-            scr[1][wave] = a1;
-            scr[2][wave] = a2;
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            const int x = threadIdx.x;
-            a.t2part[g * a.sws + ((int64_t)m * 3 + x) * nchunk + ch] =
-                (scr[x][0] + scr[x][1]) + (scr[x][2] + scr[x][3]);
-        }
-    } else if ((int)blockIdx.x < nb1 + a.natm * 3) {
-        const int ax = blockIdx.x - nb1;  // A*3 + x
-        const double *p = a.dh + g * a.sdh + (int64_t)ax * n2;
-        const double *Pao = a.Pao + g * a.sws;
-        double s = 0.0;
-        for (int64_t e = threadIdx.x; e < n2; e += 256) s = fma(p[e], Pao[e], s);
-        s = block_sum<4>(s, &scr[0][0]);
-        if (threadIdx.x == 0) a.term3[g * a.sws + ax] = s;
-    } else {
-        // 64 elements per block, 4 slab groups per element
-        const int b = blockIdx.x - nb1 - a.natm * 3;
-        const int e = b * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-        const double *y2part = a.y2part + g * a.sws;
-        double s0 = 0.0, s1 = 0.0;
-        if (e < n2) {
-            int sl = grp;
-            for (; sl + 4 < a.nslab; sl += 8) {
-                s0 += y2part[(int64_t)sl * n2 + e];
-                s1 += y2part[(int64_t)(sl + 4) * n2 + e];
-            }
-            if (sl < a.nslab) s0 += y2part[(int64_t)sl * n2 + e];
-        }
-        part[grp][threadIdx.x & 63] = s0 + s1;
-        __syncthreads();
-        if (grp == 0 && e < n2)
-            a.y2[g * a.sws + e] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
-                                  (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    }
-}
-
-int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st) {
-    const bool pair_blocks = a.presym && a.fold_cd && a.ip1_s2kl;
-    const int blocks = (pair_blocks ? a.n * (a.n + 1) / 2 : a.n * a.nchunk) + a.natm * 3 + (a.n * a.n + 63) / 64;
-    switch (ip1_per_thread()) {
-        case 16: hipLaunchKernelGGL(ip1_dh_kernel<16>, dim3(blocks, (unsigned)count), dim3(256), 0, st, a); break;
-        case 8: hipLaunchKernelGGL(ip1_dh_kernel<8>, dim3(blocks, (unsigned)count), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(ip1_dh_kernel<4>, dim3(blocks, (unsigned)count), dim3(256), 0, st, a); break;
-    }
-    EVC_LAUNCH_CHECK("ip1_dh");
     return 0;
 }
 
