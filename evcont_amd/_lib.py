@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libevcont_hip.so")
 LAYOUT_FULL6, LAYOUT_PAIR5, LAYOUT_ELEC3, LAYOUT_PACK2 = 6, 5, 3, 2
 LAYOUT_SYM8 = 8   # device-side 8-fold compressed layout (include/evcont_hip.h EVC_LAYOUT_SYM8)
 FLAG_ENERGY_ONLY, FLAG_PARTIAL_RANK, FLAG_WARM_START, FLAG_IP1_S2KL, FLAG_ERI_S4, FLAG_LOEWDIN_DONE = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_double_p = C.c_void_p  # device pointers travel as integers
 
@@ -116,6 +116,7 @@ SIGNATURES = {
     "evc_profile_stage": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "evc_profile_select": (C.c_int, [C.c_uint]),
     "evc_profile_kernel": (C.c_char_p, [C.c_int]),
+    "evc_release_workspace": (C.c_int, [C.c_void_p]),
 }
 # stages of evc_profile_stage (include/evcont_hip.h EVC_PROF_*)
 PROF_STAGES = {"k5_rows": 0, "k8_cols": 1, "pair_transform": 2, "ip1": 3, "y2": 4, "unpack": 5, "loewdin": 6,

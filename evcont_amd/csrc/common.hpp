@@ -28,6 +28,15 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
         }                                 \
     } while (0)
 
+#define EVC_HIP(call)                                                               \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            evc::set_error("%s: %s", #call, hipGetErrorString(e_));                 \
+            return (int)e_;                                                         \
+        }                                                                           \
+    } while (0)
+
 #define EVC_LAUNCH_CHECK(name)                                                      \
     do {                                                                            \
         hipError_t e_ = hipGetLastError();                                          \

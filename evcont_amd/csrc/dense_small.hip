@@ -1096,6 +1096,182 @@ __device__ __forceinline__ bool warm_start_rotate(double *A, double *V, double *
     return true;
 }
 
+// ------------------------------------------------------------------ Loewdin: S^-1/2 without the eigensolver
+// X = S^-1/2 and h1 = X h X are all the ENERGY phase needs from the Loewdin step (the eigenvectors and eigenvalues of S
+// only enter the response term at the very end of the gradient, launch_grad_final).  The coupled Newton-Schulz iteration
+//     Y_0 = S / c,  Z_0 = I,  T_k = (3 I - Z_k Y_k) / 2,  Y_k+1 = Y_k T_k,  Z_k+1 = Z_k T_k      (c = ||S||_inf >= lambda_max)
+// (Higham, Functions of Matrices, eq. 6.35: Y -> (S/c)^1/2, Z -> (S/c)^-1/2, quadratically; all iterates are polynomials
+// in S, hence symmetric and commuting) is three 32^3 products per step on the FP64 matrix cores, one 16 x 16 output tile
+// per wave: ~0.8 us per step, 10-14 steps for cond(S) ~ 10^2-10^3, against ~65 us for the full eigendecomposition.
+// One more step of the uncoupled form X <- X (3 I - X S X) / 2 on the ORIGINAL S removes what the coupled iterates have
+// drifted and yields the residual max |I - X S X| the result is accepted on; anything else (S not positive definite,
+// cond(S) beyond ~10^8, NaNs) returns false and the caller takes the eigensolver.
+//
+// LDS: 32 x 32 matrices at pitch 48 doubles -- the four rows a fragment read touches (k = lane >> 4) are 16 doubles
+// apart modulo 32, i.e. on disjoint halves of the 64 banks; a symmetric A operand is read along the rows of A^T = A
+// (lane & 15 -> consecutive addresses), so no operand is ever read with a stride.
+constexpr int kNsP = 48;
+constexpr int kNsSz = 32 * kNsP;
+constexpr int kNsMaxIter = 64;
+constexpr int kNsDoubles = 6 * kNsSz + 8;
+
+__device__ __forceinline__ d4s ns_tile(const double *A, const double *B, int ao, int bo) {
+    d4s acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk * 4 * kNsP + ao], B[kk * 4 * kNsP + bo], acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ bool loewdin_ns(const double *__restrict__ S, const double *__restrict__ h, double *__restrict__ X,
+                           double *__restrict__ h1, int n, double *sm) {
+    double *S0 = sm, *Yc = S0 + kNsSz, *Zc = Yc + kNsSz, *Yn = Zc + kNsSz, *Zn = Yn + kNsSz, *Tm = Zn + kNsSz;
+    double *red = Tm + kNsSz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int ti = wave >> 1, tj = wave & 1;
+    const int ao = l4 * kNsP + 16 * ti + l15, bo = l4 * kNsP + 16 * tj + l15;
+    const int oi = 16 * ti + l4, oj = 16 * tj + l15;   // output element of register r: (oi + 4 r, oj)
+    double hreg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = tid + u * kThreads, i = idx >> 5, j = idx & 31;
+        const bool in = i < n && j < n;
+        // (LAPACK's eigh reads the lower triangle: so does this)
+        S0[i * kNsP + j] = in ? S[i >= j ? i * n + j : j * n + i] : (i == j ? 1.0 : 0.0);
+        hreg[u] = (in && h) ? h[i * n + j] : 0.0;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double cs = 0.0;
+        if (lane < 32)
+            for (int i = 0; i < 32; ++i) cs += fabs(S0[i * kNsP + lane]);
+        cs = wave_max_nan(cs);
+        if (lane == 0) red[4] = cs;
+    }
+    __syncthreads();
+    const double c = red[4];
+    if (!(c > 0.0) || !(c < 1.0e300)) return false;   // (uniform: zero matrix, NaN, Inf)
+    const double rc = 1.0 / c;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = tid + u * kThreads, i = idx >> 5, j = idx & 31;
+        const bool in = i < n && j < n;
+        Yc[i * kNsP + j] = in ? S0[i * kNsP + j] * rc : (i == j ? 1.0 : 0.0);
+        Zc[i * kNsP + j] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    bool ok = false;
+    double eprev = 2.0;
+    int it = 0;
+#pragma unroll 1
+    for (; it < kNsMaxIter; ++it) {
+        const d4s p = ns_tile(Zc, Yc, ao, bo);
+        double e = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double dlt = (oi + 4 * r == oj) ? 1.0 : 0.0;
+            e = nanmax(e, fabs(dlt - p[r]));
+            Tm[(oi + 4 * r) * kNsP + oj] = 1.5 * dlt - 0.5 * p[r];
+        }
+        e = wave_max_nan(e);
+        if (lane == 0) red[wave] = e;
+        __syncthreads();
+        e = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
+        d4s yn = {0.0, 0.0, 0.0, 0.0}, zn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const double b = Tm[kk * 4 * kNsP + bo];
+            yn = __builtin_amdgcn_mfma_f64_16x16x4f64(Yc[kk * 4 * kNsP + ao], b, yn, 0, 0, 0);
+            zn = __builtin_amdgcn_mfma_f64_16x16x4f64(Zc[kk * 4 * kNsP + ao], b, zn, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Yn[(oi + 4 * r) * kNsP + oj] = yn[r];
+            Zn[(oi + 4 * r) * kNsP + oj] = zn[r];
+        }
+        __syncthreads();
+        double *t0 = Yc;
+        Yc = Yn;
+        Yn = t0;
+        t0 = Zc;
+        Zc = Zn;
+        Zn = t0;
+        if (e != e) break;
+        // e = max |I - Z Y| BEFORE this step; the step squares it (3/4 e^2).  Below 1e-3 a step that does not even halve
+        // it has reached the rounding floor of an ill-conditioned S: the residual test below decides.
+        if (e < 1.0e-8 || (e < 1.0e-3 && e > 0.5 * eprev)) {
+            ok = true;
+            ++it;
+            break;
+        }
+        eprev = e;
+    }
+    EVC_DBGVAL(50, it);
+    if (!ok) return false;
+    // X = Z / sqrt(c), then one step on the original S:  W = S X,  P = X W,  X <- X (3 I - P) / 2
+    const double rsq = sqrt(rc);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = tid + u * kThreads, i = idx >> 5, j = idx & 31;
+        if (i < n && j < n) Zc[i * kNsP + j] *= rsq;
+    }
+    __syncthreads();
+    {
+        const d4s wv = ns_tile(S0, Zc, ao, bo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tm[(oi + 4 * r) * kNsP + oj] = wv[r];
+    }
+    __syncthreads();
+    double res;
+    {
+        const d4s p = ns_tile(Zc, Tm, ao, bo);
+        double e = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double dlt = (oi + 4 * r == oj) ? 1.0 : 0.0;
+            e = nanmax(e, fabs(dlt - p[r]));
+            Yn[(oi + 4 * r) * kNsP + oj] = 1.5 * dlt - 0.5 * p[r];
+        }
+        e = wave_max_nan(e);
+        if (lane == 0) red[wave] = e;
+        __syncthreads();
+        res = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
+    }
+    EVC_DBGVAL(51, res);
+    if (!(res < 1.0e-7)) return false;   // (after the step: ~res^2)
+    {
+        const d4s xv = ns_tile(Zc, Yn, ao, bo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Zn[(oi + 4 * r) * kNsP + oj] = xv[r];
+    }
+    __syncthreads();
+    // symmetrised X -> Yc and the caller; h^T -> Tm (the A operand is read along rows of its transpose)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = tid + u * kThreads, i = idx >> 5, j = idx & 31;
+        const bool in = i < n && j < n;
+        const double v = in ? 0.5 * (Zn[i * kNsP + j] + Zn[j * kNsP + i]) : (i == j ? 1.0 : 0.0);
+        Yc[i * kNsP + j] = v;
+        if (in) X[i * n + j] = v;
+        Tm[j * kNsP + i] = hreg[u];
+    }
+    if (!(h && h1)) return true;
+    __syncthreads();
+    {
+        const d4s wv = ns_tile(Tm, Yc, ao, bo);   // W = h X
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Yn[(oi + 4 * r) * kNsP + oj] = wv[r];
+    }
+    __syncthreads();
+    {
+        const d4s hv = ns_tile(Yc, Yn, ao, bo);   // h1 = X W
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (oi + 4 * r < n && oj < n) h1[(oi + 4 * r) * n + oj] = hv[r];
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------ Loewdin
 __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     const int n = a.n;
@@ -1108,6 +1284,13 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     double *__restrict__ h1 = a.h1 ? a.h1 + g * a.sws : nullptr;
     extern __shared__ __align__(16) double sm[];
     const int m = (n + 1) & ~1;
+    // part = 1: X and h1 only, by Newton-Schulz (the eigensolver below only if that declines, and then without touching
+    // U and s, which a part = 2 launch on another stream is writing); part = 2: U and s only; 0: everything
+    const bool want_x = a.part != 2, want_u = a.part != 1;
+    if (a.part == 1 && m <= kJwMax && a.fast) {
+        if (loewdin_ns(S, h, X, h1, n, sm)) return;
+        __syncthreads();
+    }
     double *A = sm;              // m*m   (later: hcore)
     double *V = A + m * m;       // m*m   (later: T = h X)
     double *Xs = V + m * m;      // m*m   (uses n*n)
@@ -1156,7 +1339,7 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     if (tid < m) {
         const double s = A[tid * m + tid];
         f[tid] = (tid < n && s > 1.0e-15) ? 1.0 / sqrt(s) : 0.0;
-        if (tid < n) sv[tid] = s;
+        if (tid < n && want_u) sv[tid] = s;
     }
     __syncthreads();
     if (m <= kJwMax && a.fast) {
@@ -1174,9 +1357,10 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
                 hp[idx] = hpre[u];
                 Xp[idx] = 0.0;
                 Tt[idx] = 0.0;
-                if (in) U[i * n + j] = v;
+                if (in && want_u) U[i * n + j] = v;
             }
         }
+        if (!want_x) return;
         __syncthreads();
         mm_rowrow(m, Vf, Vp, [&](int i, int j, double v) {
             if (i < n && j < n) {
@@ -1236,13 +1420,22 @@ static int eigh_fast_enabled() {
     return on;
 }
 
+bool loewdin_split_available(int n) { return n >= 1 && n <= kJwMax && eigh_fast_enabled() != 0; }
+
 int launch_loewdin(const LoewdinArgs &a_in, int count, hipStream_t st) {
     // 32 < n <= 64: three matrices in LDS; up to 96 with two of them in the caller's scratch (a_in.scratch)
     if (a_in.n > kJwMax && (a_in.n <= 64 || a_in.scratch)) return launch_loewdin_big(a_in, count, st);
     LoewdinArgs a = a_in;
     a.fast = eigh_fast_enabled();
     const int m = (a.n + 1) & ~1;
-    const size_t lds = sizeof(double) * (size_t)3 * m * m + jacobi_aux_bytes(m);
+    size_t lds = sizeof(double) * (size_t)3 * m * m + jacobi_aux_bytes(m);
+    if (a.part) {
+        if (!loewdin_split_available(a.n)) {
+            set_error("loewdin: part=%d needs n <= %d and the FP32-started eigensolver", a.part, kJwMax);
+            return -1;
+        }
+        if (a.part == 1 && lds < sizeof(double) * kNsDoubles) lds = sizeof(double) * kNsDoubles;
+    }
     static LdsAttr attr;
     if (int rc = allow_dynamic_lds(loewdin_kernel, attr, 160 * 1024, "loewdin")) return rc;
     hipLaunchKernelGGL(loewdin_kernel, dim3(count), dim3(kThreads), lds, st, a);

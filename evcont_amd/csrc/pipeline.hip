@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -97,6 +98,10 @@ struct Ws {
     double *sbig;     // T > kSubspaceSmallT: scratch of the large-T subspace kernel (subspace_big.hip)
     bool warm;
     bool loewdin_done;   // X, U, s, h1 are already in the workspace (EVC_FLAG_LOEWDIN_DONE)
+    void *base;          // the caller's workspace pointer (key of its side stream, side_of)
+    int split;           // Loewdin step of this call: 0 = one kernel; 1 = X, h1 by Newton-Schulz on the call's stream and
+                         // U, s by the eigensolver on the workspace's side stream, joined in front of launch_grad_final;
+                         // 2 = X, h1 alone (energy only)
     size_t bytes;    // of ONE geometry
     int64_t stride;  // the same in doubles
     RowProblem rp2, rp1;
@@ -203,6 +208,8 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.sbig = take(bigT ? subspace_big_scratch_doubles((int)T) : 0);
     w.warm = false;
     w.loewdin_done = false;
+    w.base = base;
+    w.split = 0;
     w.bytes = off;
     w.stride = (int64_t)(off / sizeof(double));
 }
@@ -234,6 +241,86 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const double *partial,
         for (int k = 0; k < 16; ++k) s += part[k][rl];   // fixed order
         y[r] = alpha * s;
     }
+}
+
+// ---- the Loewdin step in two halves (n <= 32) -------------------------------------------------------------
+// The energy phase needs X = S^-1/2 and h1 only; the eigenvectors and eigenvalues of S enter at the very end of the
+// gradient (the response term, launch_grad_final).  A full call therefore computes X and h1 by Newton-Schulz on the
+// matrix cores (dense_small.hip loewdin_ns, ~12 us) on its own stream and sends the eigensolver (~65 us) to a side
+// stream, forked at the start of the call and joined in front of launch_grad_final: one geometry at a time (MD) the
+// eigensolver leaves the critical path altogether (H30: 3 780 -> 4 440 steps/s).
+// One side stream per device and two events per workspace, created at the workspace's first such call; the events live
+// until evc_release_workspace.  Not used while the stream is being captured into a graph, nor by the phase calls, nor
+// by large batches (loewdin_split_mode).
+struct Side {
+    hipStream_t s;           // the device's side stream (shared by all workspaces on it: one more hardware queue in use,
+                             // not one per workspace -- the runtime multiplexes all streams onto four of them, and a
+                             // process whose streams outnumber them sees unrelated streams serialised)
+    hipEvent_t fork, join;   // of this workspace
+    int dev;
+};
+struct SideStream {
+    hipStream_t s;
+    int users;               // workspaces holding events on it; destroyed with the last one
+};
+static std::mutex g_side_mu;
+static std::unordered_map<void *, Side> g_side;
+static std::unordered_map<int, SideStream> g_side_stream;   // by device
+
+static Side *side_of(void *ws) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    auto it = g_side.find(ws);
+    if (it != g_side.end()) return &it->second;
+    int dev = 0;
+    Side sd{};
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    auto ds = g_side_stream.find(dev);
+    if (ds == g_side_stream.end()) {
+        hipStream_t ns;
+        if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) != hipSuccess) {
+            set_error("side stream: %s", hipGetErrorString(hipGetLastError()));
+            return nullptr;
+        }
+        ds = g_side_stream.emplace(dev, SideStream{ns, 0}).first;
+    }
+    sd.s = ds->second.s;
+    sd.dev = dev;
+    if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) {
+        set_error("side stream events: %s", hipGetErrorString(hipGetLastError()));
+        return nullptr;
+    }
+    ++ds->second.users;
+    return &g_side.emplace(ws, sd).first->second;
+}
+
+extern "C" int evc_release_workspace(void *ws) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    auto it = g_side.find(ws);
+    if (it == g_side.end()) return 0;
+    (void)hipEventSynchronize(it->second.join);   // (the last eigensolver launch that writes into this workspace)
+    (void)hipEventDestroy(it->second.fork);
+    (void)hipEventDestroy(it->second.join);
+    auto ds = g_side_stream.find(it->second.dev);
+    if (ds != g_side_stream.end() && --ds->second.users == 0) {
+        (void)hipStreamDestroy(ds->second.s);   // (idle: every launch on it was followed by a join event, all waited for)
+        g_side_stream.erase(ds);
+    }
+    g_side.erase(it);
+    return 0;
+}
+
+// which form the Loewdin step of a FULL call (evc_energy_with_grad[_batch]) takes
+static int loewdin_split_mode(int n, int count, bool loewdin_done, bool energy_only, hipStream_t st) {
+    // EVC_LOEWDIN_SPLIT: calls of fewer than that many geometries take the split form (default 12: the latency regime --
+    // MD, small scans; 0: never).  Not the large batches: with several of them in flight on different streams the chip
+    // is full anyway and the extra stream costs more than the shorter critical path gains (measured at H30, 32
+    // geometries per call: one stream 58 900 -> 64 200 geometries/s, but three streams 87 000 -> 73 700).
+    static const int below = getenv("EVC_LOEWDIN_SPLIT") ? atoi(getenv("EVC_LOEWDIN_SPLIT")) : 12;
+    if (count >= below || loewdin_done || !loewdin_split_available(n)) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;
+    return energy_only ? 2 : 1;
 }
 
 // Span plan of this call (never more spans than the buffers were carved for).
@@ -276,6 +363,18 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
     la.scratch = w.B1;   // (free until the integral rotation; n > 64 only)
     la.sscratch = sw;
     if (!w.loewdin_done) {
+        if (w.split == 1) {
+            // the eigendecomposition of S (U, s: read by launch_grad_final alone) on the side stream, forked here: the
+            // inputs are ready, U of the previous call has been consumed
+            Side *sd = side_of(w.base);
+            if (!sd) return -1;
+            EVC_HIP(hipEventRecord(sd->fork, st));
+            EVC_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
+            la.part = 2;
+            if ((rc = launch_loewdin(la, cnt, sd->s))) return rc;
+            EVC_HIP(hipEventRecord(sd->join, sd->s));
+        }
+        la.part = w.split ? 1 : 0;
         const int pr = prof_start(EVC_PROF_LOEWDIN, st);
         if ((rc = launch_loewdin(la, cnt, st))) return rc;
         prof_stop(pr, st);
@@ -612,6 +711,11 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
         else gao = w.B2;
     }
     if (!ip1_done && (rc = ip1_stage(gao, 0, cnt))) return rc;
+    if (w.split == 1) {   // U and s come from the side stream (phase_hamiltonian)
+        Side *sd = side_of(w.base);
+        if (!sd) return -1;
+        EVC_HIP(hipStreamWaitEvent(st, sd->join, 0));
+    }
     GradFinalArgs f;
     f.n = n;
     f.natm = g.natm;
@@ -881,6 +985,7 @@ extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g
     const Out o = out_single(out);
     int rc;
     w.warm = (flags & EVC_FLAG_WARM_START) != 0;
+    w.split = loewdin_split_mode(t->n, 1, false, energy_only, st);
     Geo gg = geo;
     gg.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
     if ((rc = phase_hamiltonian(t, gg, w, false, st))) return rc;
@@ -959,6 +1064,7 @@ extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geome
     int rc;
     w.warm = (flags & EVC_FLAG_WARM_START) != 0;
     w.loewdin_done = (flags & EVC_FLAG_LOEWDIN_DONE) != 0;
+    w.split = loewdin_split_mode(t->n, g.count, w.loewdin_done, energy_only, st);
     g.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
     if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
     if ((rc = phase_solve(t, g, nullptr, 0, o, nroots, w, st))) return rc;

@@ -12,6 +12,8 @@ PyTorch is used for device memory and streams only.
 """
 from __future__ import annotations
 
+import weakref
+
 import ctypes as C
 import os
 from dataclasses import dataclass
@@ -467,6 +469,8 @@ class BatchedEvaluator:
         # block must not look like a hit)
         self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=d)
         self.ws_bytes = nbytes
+        # (the library may attach a side stream to the workspace, include/evcont_hip.h evc_release_workspace)
+        weakref.finalize(self, self.lib.evc_release_workspace, self.ws.data_ptr()).atexit = False
         G = self.count
         # energies and gradients share one buffer: a caller that wants both on the host fetches them with ONE copy
         na = max(self.natm, 1)
@@ -652,6 +656,7 @@ class ContinuationEvaluator:
             raise _lib.EvcontHipError("evc_workspace_bytes: " + self.lib.evc_last_error().decode())
         self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=d)   # (zero-filled: see BatchedEvaluator)
         self.ws_bytes = nbytes
+        weakref.finalize(self, self.lib.evc_release_workspace, self.ws.data_ptr()).atexit = False
         self.energy = torch.zeros(T, dtype=F64, device=d)
         self.coeffs = torch.zeros((T, T), dtype=F64, device=d)
         self.grad = torch.zeros((max(self.natm, 1), 3), dtype=F64, device=d)

@@ -29,13 +29,14 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 8 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
+#define EVC_ABI_VERSION 9 /* 2: batched phases, evc_subspace_solve_batch, evc_integrals_oao_batch, EVC_FLAG_WARM_START;
                              3: EVC_LAYOUT_SYM8; 4: evc_profile_stage/_select, EVC_FLAG_IP1_S2KL, EVC_FLAG_ERI_S4;
                              5: evc_phase_set_coeffs; 6: evc_phase_loewdin_batch, EVC_FLAG_LOEWDIN_DONE;
                              7: training sets of up to 512 states (evc_subspace_solve[_batch] take a workspace,
                                 evc_subspace_solve_ws_bytes), `flags` argument of the phase A / B entry points;
                              8: evc_profile_kernel; the workspace of the compressed layout's pipeline holds its dense
-                                (pair, pair) intermediates at the pitch N(N+1)/2 rounded up to 16 doubles */
+                                (pair, pair) intermediates at the pitch N(N+1)/2 rounded up to 16 doubles;
+                             9: evc_release_workspace (a workspace may own a side stream) */
 
 /* t-RDM storage layouts = ndim of the reference's two_RDM argument
  * (ab_initio_eigenvector_continuation.py:41-68). */
@@ -287,6 +288,16 @@ typedef struct evc_outputs_batch {
 } evc_outputs_batch;
 
 size_t evc_workspace_bytes_batch(const evc_trdm_set *t, int natm, int count);
+/* For N <= 32, full calls (evc_energy_with_grad, evc_energy_with_grad_batch) of fewer than 12 geometries -- the latency
+ * regime: MD, small scans -- compute the Loewdin transformation X = S^-1/2 (electron_integral_utils.py:6-18) by a
+ * Newton-Schulz iteration on `stream` and run the eigendecomposition of S, which only the response term of the
+ * gradient needs (ab_initio_gradients_loewdin.py:41-134,300-303), on a side stream the library creates per device; the
+ * side stream is forked from and joined into `stream` inside the call (two events per workspace, created at its first
+ * such call), so the stream semantics of the call are unchanged.  Before freeing a workspace, hand its pointer to
+ * evc_release_workspace: it waits for the last such launch into the workspace and destroys the events (a pointer that
+ * owns none: no-op, returns 0).  While `stream` is being captured into a graph the step is one kernel on `stream`;
+ * EVC_LOEWDIN_SPLIT=<count> moves the threshold (0: never). */
+int evc_release_workspace(void *ws);
 int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
                                const evc_outputs_batch *ob, int nroots, int flags, void *ws,
                                size_t ws_bytes, void *stream);

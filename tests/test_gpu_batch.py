@@ -156,7 +156,8 @@ def test_h30_batch16_matches_single_full_size():
 
 def test_phase_loewdin_then_flagged_call_equals_fused():
     """evc_phase_loewdin_batch + EVC_FLAG_LOEWDIN_DONE (the Loewdin kernel of a batch run ahead of time, e.g. on
-    another stream beside the previous batch) gives bit-identical results to the fused call."""
+    another stream beside the previous batch) gives the results of the fused call -- to rounding: a fused call of fewer
+    than 12 geometries takes X = S^-1/2 from the Newton-Schulz iteration, the phase from the eigendecomposition."""
     import torch
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, BatchedEvaluator
     from evcont_amd.synthetic import make_ao_arrays, make_trdms, pack_rows
@@ -173,7 +174,8 @@ def test_phase_loewdin_then_flagged_call_equals_fused():
     be.phase_loewdin(aob, stream=side)
     side.synchronize()
     E1, g1 = be.energies_with_grads(aob)
-    assert np.array_equal(E0, E1) and np.array_equal(g0, g1)
+    np.testing.assert_allclose(E1, E0, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(g1, g0, rtol=0, atol=1e-11)
     E2, g2 = be.energies_with_grads(aob)          # the flag is consumed by one call
     assert np.array_equal(E0, E2) and np.array_equal(g0, g2)
 

@@ -20,6 +20,8 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
     {"EVC_PT_PIPE": "0", "EVC_PT_DMA": "0"}, # phase-alternating pair transform (pt_kernel) instead of ptd_kernel / pt_pipe_kernel
     {"EVC_PT_DMA": "0"},                      # pt_pipe_kernel (operand rows through registers) instead of ptd_kernel (LDS-DMA)
     {"EVC_SUBSPACE_FEW": "0"},                # subspace kernels: no few-roots route (full eigensolver / Jacobi sweeps always)
+    {"EVC_LOEWDIN_SPLIT": "0"},               # Loewdin step as one kernel always (no Newton-Schulz X, no side stream)
+    {"EVC_LOEWDIN_SPLIT": "4096"},            # ... in two halves for batches of every size
     {"EVC_EIGH_F32": "0"},                    # FP64 Jacobi eigensolvers
     {"EVC_EIGH_F32": "1"},                    # FP32 Jacobi start + refinement
     {"EVC_ROWS_LDS": "0"},                    # batched K5 with fragment-shaped loads (gemv_rows_mfma_pipe_kernel)
@@ -36,6 +38,9 @@ def test_variant_passes_parity_subset(env):
     e = dict(os.environ)
     e.update(env)
     subset = LARGE_T + SUBSET if "EVC_SUBSPACE_FEW" in env else SUBSET
+    if "EVC_LOEWDIN_SPLIT" in env:
+        subset = SUBSET + ["tests/test_gpu_loewdin_split.py::test_small_batches_take_the_split_form",
+                           "tests/test_gpu_warm_start.py::test_warm_start_matches_cold_start"]
     if "EVC_ROWS_LDS_NT" in env or "EVC_ROWS_LDS" in env or "EVC_COLS_LDS" in env:   # (the kernels behind these knobs: batches of >= 12)
         subset = ["tests/test_gpu_bench_config.py::test_k5_every_row_group_body",
                   "tests/test_gpu_bench_config.py::test_k5_row_groups_wide_matrix", "tests/test_gpu_sym8.py::test_sym8_batched"]
