@@ -47,3 +47,5 @@ def pstep(k):
         pe.results(tk.pop(0))
     tk.append(pe.enqueue(b32[k % 2]))
 print("pipelined      %9.0f" % rate(pstep, steps, G), flush=True)
+ew = BatchedEvaluator(trd, A, 1, warm_start=True)
+print("md_warm        %9.0f" % rate(lambda k: ew.enqueue(b1[0]), steps * 4, 1), flush=True)
