@@ -20,6 +20,7 @@ run stats_sym8_md      --kernel-trace --stats --output-format csv -d $O/stats_sy
 run stats_pack2_md     --kernel-trace --stats --output-format csv -d $O/stats_pack2_md -- $BENCH --layout pack2 --batch 1 --streams 1 --steps 60
 run stats_zundel100_b32s1 --kernel-trace --stats --output-format csv -d $O/stats_zundel100_b32s1 -- $BENCH --workload Zundel100 --streams 1 --steps 6 --warmup 2
 run stats_zundel100_md --kernel-trace --stats --output-format csv -d $O/stats_zundel100_md -- $BENCH --workload Zundel100 --batch 1 --streams 1 --steps 20 --warmup 2
+run stats_h10_md        --kernel-trace --stats --output-format csv -d $O/stats_h10_md -- $BENCH --workload H10 --batch 1 --streams 1 --steps 200
 run stats_h2ovtz_b4s1  --kernel-trace --stats --output-format csv -d $O/stats_h2ovtz_b4s1 -- $BENCH --workload H2Ovtz --batch 4 --streams 1 --geoms 8 --steps 6 --warmup 2
 for lay in sym8 pack2; do
 run pmc_fetch_${lay}_b32 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_${lay}_b32 -- $BENCH --layout $lay --streams 1 --steps 8
