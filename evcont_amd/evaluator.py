@@ -76,6 +76,38 @@ def check_integral_symmetry(eri, eri_ip1, n: int, tol: float = 1.0e-9, what: str
             "for such tensors; EVCONT_AMD_CHECK_SYM=0 disables this check.")
 
 
+def spot_check_integral_symmetry(eri, eri_ip1, n: int, samples: int = 4096, tol: float = 1.0e-9, what: str = "") -> None:
+    """The same test on ``samples`` random index quadruples of full host arrays (numpy): what the host-side packing
+    helpers run on EVERY call after their first, complete check -- packing keeps one triangle, so a later geometry (or
+    another integral source) without the symmetries could not be noticed afterwards (EVCONT_AMD_CHECK_SYM=0: never)."""
+    if n < 2:
+        return
+    rng = np.random.default_rng()
+    p, q, r, t = (rng.integers(0, n, samples) for _ in range(4))
+    bad = []
+    e = np.asarray(eri)
+    if e.ndim >= 4 and e.shape[-1] == n and e.shape[-4] == n:
+        e = e.reshape(-1, n, n, n, n)[0]
+        v = e[p, q, r, t]
+        scale = max(float(np.abs(v).max()), 1e-300)
+        if max(np.abs(v - e[q, p, r, t]).max(), np.abs(v - e[p, q, t, r]).max(), np.abs(v - e[r, t, p, q]).max()) > tol * scale:
+            bad.append("eri is not 8-fold symmetric")
+    if eri_ip1 is not None:
+        x = np.asarray(eri_ip1)
+        if x.ndim >= 5 and x.shape[-1] == n and x.shape[-2] == n:
+            x = x.reshape(-1, n, n, n, n)
+            c = rng.integers(0, x.shape[0], samples)
+            v = x[c, p, q, r, t]
+            scale = max(float(np.abs(v).max()), 1e-300)
+            if np.abs(v - x[c, p, q, t, r]).max() > tol * scale:
+                bad.append("eri_ip1[x,p,q,r,s] != eri_ip1[x,p,q,s,r]")
+    if bad:
+        raise _lib.EvcontHipError(
+            "AO integrals without the index symmetries of real two-electron integrals (" + "; ".join(bad) + ")"
+            + (f" in {what}" if what else "") + ": packing them (s4 / s2kl) would give wrong energies / forces.  Use the "
+            "reference layouts (compress=None) for such tensors; EVCONT_AMD_CHECK_SYM=0 disables this check.")
+
+
 def _host_check_once(tag: str) -> bool:
     """Whether a host-side packing helper should verify the symmetries now (EVCONT_AMD_CHECK_SYM)."""
     if _CHECK_SYM == "0":
@@ -328,8 +360,12 @@ class DeviceAO:
         npr = n * (n + 1) // 2
         eri = np.asarray(ao.eri)
         s4 = eri.ndim == 2 and eri.shape == (npr, npr) and n > 1
-        if (pack_eri or pack_ip1) and not energy_only and _host_check_once("DeviceAO.from_arrays"):
-            check_integral_symmetry(eri, np.asarray(ao.eri_ip1), n, what="DeviceAO.from_arrays(pack_...=True)")
+        if (pack_eri or pack_ip1) and not energy_only:
+            # complete check at the first use (per orbital count), a random sample on every later call
+            if _host_check_once(f"DeviceAO.from_arrays/{n}"):
+                check_integral_symmetry(eri, np.asarray(ao.eri_ip1), n, what="DeviceAO.from_arrays(pack_...=True)")
+            elif _CHECK_SYM != "0":
+                spot_check_integral_symmetry(eri, ao.eri_ip1, n, what="DeviceAO.from_arrays(pack_...=True)")
         if pack_eri and not s4:
             iu, ju = np.tril_indices(n)
             eri = eri.reshape(n, n, n, n)[iu, ju][:, iu, ju]

@@ -149,12 +149,16 @@ class HostedEvaluator:
         st["enuc"][0] = float(ao.enuc)
         eri, ip1 = np.asarray(ao.eri), np.asarray(ao.eri_ip1)
         if self.packed:
-            from .evaluator import _CHECK_SYM, check_integral_symmetry
-            # (packing below keeps one triangle: it must be THE triangle; once per evaluator, EVCONT_AMD_CHECK_SYM=2:
-            #  every call, unless the molecule declares the symmetry itself)
-            if _CHECK_SYM == "2" or (_CHECK_SYM != "0" and not self._sym_checked
-                                     and not getattr(ao, "integral_symmetry", False)):
-                check_integral_symmetry(eri, ip1, n, what="HostedEvaluator.stage")
+            from .evaluator import _CHECK_SYM, check_integral_symmetry, spot_check_integral_symmetry
+            # (packing below keeps one triangle: it must be THE triangle; complete check once per evaluator -- with
+            #  EVCONT_AMD_CHECK_SYM=2 every call --, a random sample on every other call, unless the molecule declares
+            #  the symmetry itself)
+            if not getattr(ao, "integral_symmetry", False) and _CHECK_SYM != "0":
+                if _CHECK_SYM == "2" or not self._sym_checked:
+                    check_integral_symmetry(eri, ip1, n, what="HostedEvaluator.stage")
+                elif eri.size != st["eri"].size or ip1.size != st["eri_ip1"].size:   # (full arrays about to be packed)
+                    spot_check_integral_symmetry(eri, ip1, n, samples=1024,
+                                                 what="HostedEvaluator.stage")
             self._sym_checked = True
             iu, ju = np.tril_indices(n)
             if eri.size != st["eri"].size:

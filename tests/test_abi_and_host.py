@@ -333,3 +333,26 @@ def test_integral_symmetry_check_on_host():
     m[0, 3] += 1e-4
     with pytest.raises(EvcontHipError, match="packed s4"):
         check_integral_symmetry(m, None, n)
+
+
+def test_spot_check_of_the_integral_symmetries():
+    """The sampled test the host-side packing helpers run on every call after their first complete one
+    (evaluator.spot_check_integral_symmetry): silent on symmetric tensors (full or already packed), raises on a tensor
+    that lost a symmetry."""
+    import numpy as np
+    import pytest
+    from evcont_amd import _lib
+    from evcont_amd.evaluator import spot_check_integral_symmetry
+    from evcont_amd.synthetic import make_ao_arrays
+    n = 7
+    ao = make_ao_arrays(n, 2, 5, ip1_rs_symmetric=True)
+    spot_check_integral_symmetry(ao.eri, ao.eri_ip1, n)
+    iu, ju = np.tril_indices(n)
+    spot_check_integral_symmetry(ao.eri.reshape(n, n, n, n)[iu, ju][:, iu, ju], None, n)      # packed: nothing to sample
+    bad = make_ao_arrays(n, 2, 6, ip1_rs_symmetric=False)
+    with pytest.raises(_lib.EvcontHipError):
+        spot_check_integral_symmetry(bad.eri, bad.eri_ip1, n)
+    e = np.array(ao.eri, copy=True).reshape(n, n, n, n)
+    e += 1e-3 * np.random.default_rng(1).standard_normal(e.shape)
+    with pytest.raises(_lib.EvcontHipError):
+        spot_check_integral_symmetry(e, None, n)
