@@ -1272,6 +1272,190 @@ __device__ bool loewdin_ns(const double *__restrict__ S, const double *__restric
     return true;
 }
 
+// The same for 32 < n <= 64 (cc-pVTZ water: n = 58): 64 x 64 matrices, wave w owns the row strip 16 w ... 16 w + 15 of
+// every product (four 16 x 16 tiles: one A fragment serves four MFMAs), three matrices in LDS at pitch 64 with the 16-
+// double halves of odd rows swapped (idx below: the fragment rows of lane groups l4 and l4 + 1 fall on disjoint bank
+// halves, as the padding does at 32), the iterates updated in place between two barriers.  ~5 us per step (192 MFMAs
+// per wave), 12-16 steps.  One workgroup of 256 threads per geometry; the result flag goes to `flag[g]` (1 = X and h1
+// written), which the eigensolver launch that follows in the stream (loewdin_big_kernel, part 3) reads first.
+constexpr int kNs64Sz = 64 * 64;
+__device__ __forceinline__ int ns64_idx(int row, int col) { return row * 64 + (col ^ ((row & 1) << 4)); }
+
+// strip of A.B for symmetric A: acc[tj] (+)= sum_k A[k][16 w + i] B[k][16 tj + j]
+__device__ __forceinline__ void ns64_strip(const double *A, const double *B, int wave, int l15, int l4, d4s (&acc)[4]) {
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) acc[tj] = (d4s){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+        const int row = 4 * kk + l4;
+        const double av = A[ns64_idx(row, 16 * wave + l15)];
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B[ns64_idx(row, 16 * tj + l15)], acc[tj], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void loewdin_ns64_kernel(LoewdinArgs a) {
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n;
+    const int64_t g = blockIdx.x;
+    const double *__restrict__ S = a.S + g * a.sS;
+    const double *__restrict__ h = a.h ? a.h + g * a.sh : nullptr;
+    double *__restrict__ X = a.X + g * a.sws;
+    double *__restrict__ h1 = a.h1 ? a.h1 + g * a.sws : nullptr;
+    double *__restrict__ flag = a.flag + g * a.sws;
+    double *Y = sm, *Z = Y + kNs64Sz, *Tm = Z + kNs64Sz, *red = Tm + kNs64Sz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    auto fail = [&]() {
+        if (tid == 0) *flag = 0.0;
+    };
+    // S (lower triangle mirrored, identity in the padding) -> Tm; column sums -> c = ||S||_inf
+    for (int idx = tid; idx < kNs64Sz; idx += kThreads) {
+        const int i = idx >> 6, j = idx & 63;
+        Tm[ns64_idx(i, j)] = (i < n && j < n) ? S[i >= j ? i * n + j : j * n + i] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    {
+        double cs = 0.0;
+        if (wave == 0)
+            for (int i = 0; i < 64; ++i) cs += fabs(Tm[ns64_idx(i, lane)]);
+        cs = wave_max_nan(cs);
+        if (tid == 0) red[4] = cs;
+    }
+    __syncthreads();
+    const double c = red[4];
+    if (!(c > 0.0) || !(c < 1.0e300)) {
+        fail();
+        return;
+    }
+    const double rc = 1.0 / c;
+    for (int idx = tid; idx < kNs64Sz; idx += kThreads) {
+        const int i = idx >> 6, j = idx & 63;
+        const int k = ns64_idx(i, j);
+        Y[k] = (i < n && j < n) ? Tm[k] * rc : (i == j ? 1.0 : 0.0);
+        Z[k] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int oi = 16 * wave + l4;   // output element (register r of tile tj): (oi + 4 r, 16 tj + l15)
+    bool ok = false;
+    double eprev = 2.0;
+    int it = 0;
+    d4s acc[4], acc2[4];
+#pragma unroll 1
+    for (; it < kNsMaxIter; ++it) {
+        ns64_strip(Z, Y, wave, l15, l4, acc);
+        double e = 0.0;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = oi + 4 * r, j = 16 * tj + l15;
+                const double dlt = i == j ? 1.0 : 0.0;
+                e = nanmax(e, fabs(dlt - acc[tj][r]));
+                Tm[ns64_idx(i, j)] = 1.5 * dlt - 0.5 * acc[tj][r];
+            }
+        e = wave_max_nan(e);
+        if (lane == 0) red[wave] = e;
+        __syncthreads();
+        e = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
+        ns64_strip(Y, Tm, wave, l15, l4, acc);
+        ns64_strip(Z, Tm, wave, l15, l4, acc2);
+        __syncthreads();
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = ns64_idx(oi + 4 * r, 16 * tj + l15);
+                Y[k] = acc[tj][r];
+                Z[k] = acc2[tj][r];
+            }
+        __syncthreads();
+        if (e != e) break;
+        if (e < 1.0e-8 || (e < 1.0e-3 && e > 0.5 * eprev)) {
+            ok = true;
+            ++it;
+            break;
+        }
+        eprev = e;
+    }
+    EVC_DBGVAL(52, it);
+    if (!ok) {
+        fail();
+        return;
+    }
+    // X = Z / sqrt(c); one step on the original S:  W = S X,  P = X W,  X <- X (3 I - P) / 2
+    const double rsq = sqrt(rc);
+    for (int idx = tid; idx < kNs64Sz; idx += kThreads) {
+        const int i = idx >> 6, j = idx & 63;
+        const int k = ns64_idx(i, j);
+        const bool in = i < n && j < n;
+        if (in) Z[k] *= rsq;
+        Tm[k] = in ? S[i >= j ? i * n + j : j * n + i] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    ns64_strip(Tm, Z, wave, l15, l4, acc);   // W = S X
+    __syncthreads();
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tm[ns64_idx(oi + 4 * r, 16 * tj + l15)] = acc[tj][r];
+    __syncthreads();
+    ns64_strip(Z, Tm, wave, l15, l4, acc);   // P = X W
+    double res = 0.0;
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = oi + 4 * r, j = 16 * tj + l15;
+            const double dlt = i == j ? 1.0 : 0.0;
+            res = nanmax(res, fabs(dlt - acc[tj][r]));
+            Y[ns64_idx(i, j)] = 1.5 * dlt - 0.5 * acc[tj][r];
+        }
+    res = wave_max_nan(res);
+    if (lane == 0) red[wave] = res;
+    __syncthreads();
+    res = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
+    EVC_DBGVAL(53, res);
+    if (!(res < 1.0e-7)) {
+        fail();
+        return;
+    }
+    ns64_strip(Z, Y, wave, l15, l4, acc);    // X' = X T
+    __syncthreads();
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tm[ns64_idx(oi + 4 * r, 16 * tj + l15)] = acc[tj][r];
+    __syncthreads();
+    // symmetrised X -> Z and the caller; h^T -> Y
+    for (int idx = tid; idx < kNs64Sz; idx += kThreads) {
+        const int i = idx >> 6, j = idx & 63;
+        const bool in = i < n && j < n;
+        const double v = in ? 0.5 * (Tm[ns64_idx(i, j)] + Tm[ns64_idx(j, i)]) : (i == j ? 1.0 : 0.0);
+        Z[ns64_idx(i, j)] = v;
+        if (in) X[i * n + j] = v;
+        Y[ns64_idx(j, i)] = (in && h) ? h[i * n + j] : 0.0;
+    }
+    if (tid == 0) *flag = 1.0;
+    if (!(h && h1)) return;
+    __syncthreads();
+    ns64_strip(Y, Z, wave, l15, l4, acc);    // W = h X  (A operand read along the rows of h^T)
+    __syncthreads();
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tm[ns64_idx(oi + 4 * r, 16 * tj + l15)] = acc[tj][r];
+    __syncthreads();
+    ns64_strip(Z, Tm, wave, l15, l4, acc);   // h1 = X W
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = oi + 4 * r, j = 16 * tj + l15;
+            if (i < n && j < n) h1[i * n + j] = acc[tj][r];
+        }
+}
+
 // ------------------------------------------------------------------ Loewdin
 __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     const int n = a.n;
@@ -1420,11 +1604,29 @@ static int eigh_fast_enabled() {
     return on;
 }
 
-bool loewdin_split_available(int n) { return n >= 1 && n <= kJwMax && eigh_fast_enabled() != 0; }
+bool loewdin_split_available(int n) { return n >= 1 && n <= 64 && (n > kJwMax || eigh_fast_enabled() != 0); }
 
 int launch_loewdin(const LoewdinArgs &a_in, int count, hipStream_t st) {
     // 32 < n <= 64: three matrices in LDS; up to 96 with two of them in the caller's scratch (a_in.scratch)
-    if (a_in.n > kJwMax && (a_in.n <= 64 || a_in.scratch)) return launch_loewdin_big(a_in, count, st);
+    if (a_in.n > kJwMax && (a_in.n <= 64 || a_in.scratch)) {
+        if (a_in.part && (a_in.n > 64 || !a_in.flag)) {
+            set_error("loewdin: part=%d needs n <= 64 and a flag word per geometry", a_in.part);
+            return -1;
+        }
+        if (a_in.part == 1) {
+            // Newton-Schulz X and h1; then the eigensolver launch, which returns at once for every geometry whose flag
+            // says the iteration has delivered (part 3)
+            static LdsAttr attr;
+            const size_t lds = sizeof(double) * (3 * kNs64Sz + 8);
+            if (int rc = allow_dynamic_lds(loewdin_ns64_kernel, attr, 160 * 1024, "loewdin_ns64")) return rc;
+            hipLaunchKernelGGL(loewdin_ns64_kernel, dim3(count), dim3(kThreads), lds, st, a_in);
+            EVC_LAUNCH_CHECK("loewdin_ns64");
+            LoewdinArgs b = a_in;
+            b.part = 3;
+            return launch_loewdin_big(b, count, st);
+        }
+        return launch_loewdin_big(a_in, count, st);
+    }
     LoewdinArgs a = a_in;
     a.fast = eigh_fast_enabled();
     const int m = (a.n + 1) & ~1;

@@ -173,9 +173,11 @@ struct LoewdinArgs {
     int fast;  // set by launch_loewdin: FP32 Jacobi + FP64 refinement for n <= 32 (EVC_EIGH_F32=0: FP64 Jacobi)
     double *scratch;   // n > 64: 2 Tp^2 doubles (Tp = n rounded up to 16) + g*sscratch for two of the three work matrices
     int64_t sscratch;  // (NULL: the LDS-only kernels, n <= 80)
+    double *flag;      // + g*sws: one word per geometry (32 < n <= 64, part != 0): 1 = the Newton-Schulz launch wrote X, h1
     int part;          // 0: X, h1, U, s.  loewdin_split_available(n) only: 1 = X and h1 alone (Newton-Schulz on the matrix
                        // cores, no eigensolver; U and s are not touched), 2 = U and s alone (X, h1 are not touched) -- the
-                       // two halves of a step whose gradient tail alone needs the eigendecomposition (pipeline.hip)
+                       // two halves of a step whose gradient tail alone needs the eigendecomposition (pipeline.hip);
+                       // 3 (internal, 32 < n <= 64): X and h1 by the eigensolver for the geometries whose flag is 0
 };
 int launch_loewdin(const LoewdinArgs &a, int count, hipStream_t st);
 bool loewdin_split_available(int n);

@@ -82,6 +82,7 @@ struct Out {
 struct Ws {
     // N^2-sized
     double *X, *U, *s, *h1, *Dpred, *Pao, *Y1;
+    double *lflag;   // one word: the Newton-Schulz launch of a split Loewdin step delivered (32 < n <= 64)
     // N^4-sized
     double *B1, *B2, *K3, *G;
     double *vec2;  // ld2-long vector: packed h2 (phase A) / packed predicted 2-RDM (phase C)
@@ -163,6 +164,7 @@ static void carve(const evc_trdm_set *t, int natm, char *base, Ws &w) {
     w.X = take(n2);
     w.U = take(n2);
     w.s = take(n);
+    w.lflag = take(1);
     w.h1 = take(n2);
     w.Dpred = take(n2);
     w.Pao = take(n2);
@@ -362,6 +364,7 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
     la.warm = w.warm ? 1 : 0;
     la.scratch = w.B1;   // (free until the integral rotation; n > 64 only)
     la.sscratch = sw;
+    la.flag = w.lflag;
     if (!w.loewdin_done) {
         if (w.split == 1) {
             // the eigendecomposition of S (U, s: read by launch_grad_final alone) on the side stream, forked here: the

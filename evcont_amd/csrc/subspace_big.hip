@@ -820,9 +820,13 @@ __global__ __launch_bounds__(kBT) void loewdin_big_kernel(LoewdinArgs a) {
     double *A = ext ? a.scratch + g * a.sscratch : G + gsz, *B = A + Tp2;
     double *f = ext ? G + gsz : B + Tp2, *red = f + Tp;
     const int tid = threadIdx.x;
+    // part 2: U and s only (the response half of a split step, pipeline.hip); part 3: X and h1 only, and only where the
+    // Newton-Schulz launch in front of this one declined (its flag word)
+    const bool want_u = a.part != 1 && a.part != 3, want_x = a.part != 2;
+    if (a.part == 3 && a.flag[g * a.sws] != 0.0) return;
     // numpy.linalg.eigh reads the lower triangle
     bool warm = false;
-    if (a.warm) {   // A = Vt (rows = previous eigenvectors), B = S symmetrised; G0 = Vt S
+    if (a.warm && want_u) {   // A = Vt (rows = previous eigenvectors), B = S symmetrised; G0 = Vt S
         for (size_t idx = tid; idx < Tp2; idx += kBT) {
             const int i = (int)(idx / Tp), j = (int)(idx - (size_t)i * Tp);
             const bool in = i < n && j < n;
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(kBT) void loewdin_big_kernel(LoewdinArgs a) {
         }
         if (s == 0 && j < Tp) {
             f[j] = (j < n && l > 1.0e-15) ? 1.0 / sqrt(l) : 0.0;
-            if (j < n) sv[j] = l;
+            if (j < n && want_u) sv[j] = l;
         }
     }
     __syncthreads();
@@ -879,8 +883,9 @@ __global__ __launch_bounds__(kBT) void loewdin_big_kernel(LoewdinArgs a) {
         const double v = in ? G[(size_t)k * Pj + i] : 0.0;
         A[idx] = v;
         B[idx] = in ? v * f[k] : 0.0;
-        if (in) U[(size_t)i * n + k] = v;
+        if (in && want_u) U[(size_t)i * n + k] = v;
     }
+    if (!want_x) return;
     __syncthreads();
     // X = (V f) V^T, kept at pitch Tp in the G region (free now)
     for (size_t idx = tid; idx < Tp2; idx += kBT) G[idx] = 0.0;

@@ -288,7 +288,7 @@ typedef struct evc_outputs_batch {
 } evc_outputs_batch;
 
 size_t evc_workspace_bytes_batch(const evc_trdm_set *t, int natm, int count);
-/* For N <= 32, full calls (evc_energy_with_grad, evc_energy_with_grad_batch) of fewer than 12 geometries -- the latency
+/* For N <= 64, full calls (evc_energy_with_grad, evc_energy_with_grad_batch) of fewer than 12 geometries -- the latency
  * regime: MD, small scans -- compute the Loewdin transformation X = S^-1/2 (electron_integral_utils.py:6-18) by a
  * Newton-Schulz iteration on `stream` and run the eigendecomposition of S, which only the response term of the
  * gradient needs (ab_initio_gradients_loewdin.py:41-134,300-303), on a side stream the library creates per device; the
