@@ -343,7 +343,7 @@ def main():
         """Whole step against the two rooflines at once: ALGORITHMIC bytes (the resident t-RDMs twice, the AO inputs
         of every geometry once, the results) at the HBM peak PLUS the FP64 matrix work of the four-index rotations and
         the two batched contractions at the MFMA peak, over the measured time of a step on ONE GPU."""
-        packed_in = a.layout == "sym8" and a.integrals == "packed" and n <= 32
+        packed_in = a.layout == "sym8" and a.integrals == "packed" and n <= 64
         npr = n * (n + 1) // 2
         ao = (npr * npr + 3 * n * n * npr if packed_in else 4 * n ** 4) + (2 + 3 + 3 * A) * n * n + 3 * A
         passes = 1 if a.energy_only else 2
@@ -375,7 +375,7 @@ def main():
     aos = geometries(seed * 1000 + (0 if pairs_first else rank * a.geoms))
     # what the sym8 legs are fed: the same integrals with int2e_ip1 packed in (r,s), gathered on the device here,
     # outside every timed region -- the form PySCF delivers with aosym="s2kl"
-    packed_ip1 = a.layout == "sym8" and a.integrals == "packed" and n <= 32
+    packed_ip1 = a.layout == "sym8" and a.integrals == "packed" and n <= 64
     # (the phase entry points of the pair-sharded mode take the same packed arrays: flags since ABI 7)
     run_view = ((lambda lst, phases=False: [x.packed_ip1(eri=True) for x in lst]) if packed_ip1
                 else (lambda lst, phases=False: lst))

@@ -17,7 +17,7 @@ if os.environ.get("EVC_DEBUG_STAMPS") and not TAG:
     TAG = "stamps"
 LIB = os.path.join(HERE, f"libevcont_hip_{TAG}.so" if TAG else "libevcont_hip.so")
 OBJDIR = os.path.join(CSRC, f"_build_{TAG}") if TAG else CSRC
-SOURCES = ["gemv_stream.hip", "gemv_mfma.hip", "gemv_lds.hip", "transform.hip", "pack.hip", "y2.hip", "ip1.hip", "pair_dma.hip", "dense_small.hip", "subspace_big.hip", "response.hip", "pipeline.hip"]
+SOURCES = ["gemv_stream.hip", "gemv_mfma.hip", "gemv_lds.hip", "transform.hip", "pack.hip", "y2.hip", "ip1.hip", "pair_dma.hip", "pair64.hip", "dense_small.hip", "subspace_big.hip", "response.hip", "pipeline.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "few_roots.hpp", os.path.join("..", "..", "include", "evcont_hip.h")]
 ARCH = "gfx950"
 # EVC_DEBUG_STAMPS=1 builds the eigen-kernels with their phase stamps (tools/micro/loewdin_time.py); never shipped

@@ -164,6 +164,13 @@ struct Ip1Args {
 int launch_ip1_dh(const Ip1Args &a, int count, hipStream_t st);
 
 // ---- dense_small.hip ---------------------------------------------------------------
+// ---- pair64.hip: the symmetric pipeline's pair step and Y2 for 32 < n <= 64 ----------------------------
+bool pair64_applicable(const PairTransformArgs &a);
+int launch_pair_transform64(const PairTransformArgs &a, int count, hipStream_t st);
+bool y2_64_applicable(int n);
+int y2_64_slabs(int n, int count);
+int launch_y2_64(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial, int64_t sws,
+                 int count, hipStream_t st);
 struct LoewdinArgs {
     const double *S, *h;   // + g*sS, + g*sh   (h may be NULL)
     double *X, *U, *s, *h1;  // + g*sws        (h1 may be NULL)

@@ -111,6 +111,15 @@ struct Ws {
 // n <= 32: the four-index rotations run as two fused pair steps (transform.hip / pair_dma.hip); larger n as four
 // quarter steps.
 static bool use_pair_transform(int n) { return n <= kPairTransformMaxN; }
+// 32 < n <= 64 on the compressed layout with BOTH large arrays handed over packed (EVC_FLAG_ERI_S4 with the energy
+// phase, EVC_FLAG_IP1_S2KL with the gradient phase): the symmetric pipeline on 64 x 64 operand matrices (pair64.hip).
+// The two phases of one evaluation must agree (the gradient phase finds the first pair step's intermediate, not the
+// three-quarter-transformed integrals, in the K3 buffer): the fused entry points check it, callers of the phase entry
+// points pass both flags or neither.  EVC_PT64=0: the quarter-step route.
+static bool use_pair64(int layout, int n, bool packed_input) {
+    static const bool on = !(getenv("EVC_PT64") && atoi(getenv("EVC_PT64")) == 0);
+    return on && layout == EVC_LAYOUT_SYM8 && n > kPairTransformMaxN && n <= 64 && packed_input;
+}
 
 // Geometries per pass of the multi-kernel stages of a batched call (integral rotation, gradient tail): one pass over
 // the whole batch (chunks of 16, which keep the intermediates closer to the Infinity Cache, measured within noise).
@@ -123,7 +132,7 @@ static bool is_sym8(int layout) { return layout == EVC_LAYOUT_SYM8; }
 // Y2 with the half-transformed integrals recomputed (y2.hip y2_fused_kernel): the energy phase then keeps the
 // dense (pair, pair) intermediate of its first pair step in the K3 buffer instead of writing K3 (EVC_Y2_FUSED=0: K3)
 static bool use_fused_y2(bool sym8, int n) {
-    return sym8 && use_pair_transform(n) && y2_fused_available(n);
+    return sym8 && y2_fused_available(n);   // (callers have decided for the pair-step route: n <= 32 or use_pair64)
 }
 static bool is_packed(int layout) { return layout == EVC_LAYOUT_ELEC3 || layout == EVC_LAYOUT_PACK2 || is_sym8(layout); }
 static bool is_pairs(int layout) { return layout == EVC_LAYOUT_PAIR5 || layout == EVC_LAYOUT_PACK2 || is_sym8(layout); }
@@ -341,9 +350,10 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
                              double *rows_out = nullptr, int64_t srows_out = 0) {
     const int n = t->n, cnt = g_in.count;
     Geo g = g_in;
+    const bool p64 = use_pair64(t->layout, n, g.eri_s4 != 0);
     if (g.eri_s4) {
-        EVC_REQUIRE(is_sym8(t->layout) && use_pair_transform(n),
-                    "EVC_FLAG_ERI_S4 needs the compressed layout (EVC_LAYOUT_SYM8) and N <= 32");
+        EVC_REQUIRE(is_sym8(t->layout) && (use_pair_transform(n) || p64),
+                    "EVC_FLAG_ERI_S4 needs the compressed layout (EVC_LAYOUT_SYM8) and N <= 64");
         const int64_t npr = (int64_t)n * (n + 1) / 2;
         if (cnt > 1) g.seri = npr * npr;
     }
@@ -384,7 +394,7 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
     }
     // (ab|cd) -> K3[jkl][a] -> h2[ijkl]
     const double *v2;
-    if (use_pair_transform(n)) {
+    if (use_pair_transform(n) || p64) {
         // two fused pair steps; the second one emits K3 and writes h2 straight into the form the
         // streaming kernel consumes (packed with diag x 1/2, or full)
         // in chunks of geometries, so that the intermediate of a chunk (6.5 MB per geometry) is still in the
@@ -592,7 +602,10 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
     p.sD = sD;
     p.scale1 = scale1;
     if ((rc = launch_grad_prep(p, cnt, st))) return rc;
-    const bool fused_y2 = packed && use_fused_y2(sym8 != 0, n);
+    // 32 < n <= 64: the symmetric pipeline on 64 x 64 matrices when int2e_ip1 came packed (use_pair64)
+    const bool p64 = packed && use_pair64(sym8 ? EVC_LAYOUT_SYM8 : 0, n, ip1_s2kl != 0);
+    const bool pairs_route = use_pair_transform(n) || p64;
+    const bool fused_y2 = packed && pairs_route && use_fused_y2(sym8 != 0, n);
     int y2_slabs_used = y2_slabs(n);   // (the fused kernel: per chunk of geometries, set where it is launched)
     auto ip1_stage = [&](const double *gao_, int c0, int cc) -> int {
         const int64_t o = (int64_t)c0 * sw;
@@ -600,7 +613,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
         ia.ip1 = g.eri_ip1 + (int64_t)c0 * g.sip1;
         ia.Gao = gao_ + o;
         ia.presym = packed ? 1 : 0;
-        ia.fold_cd = (packed && sym8 && use_pair_transform(n)) ? 1 : 0;
+        ia.fold_cd = (packed && sym8 && pairs_route) ? 1 : 0;
         ia.ip1_s2kl = ip1_s2kl;
         ia.t2part = w.t2part + o;
         ia.dh = g.dhcore ? g.dhcore + (int64_t)c0 * g.sdh : nullptr;
@@ -619,7 +632,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
     };
     bool ip1_done = false;
     if (packed) {
-        if (use_pair_transform(n)) {
+        if (pairs_route) {
             // unpack+symmetrise -> Y2 -> B1 (symmetrised, OAO) -> B2 -> B1 (AO) -> ip1 contraction, in chunks of
             // geometries so that each kernel finds its predecessor's output in the Infinity Cache
             const int chunk = stage_chunk(cnt);
@@ -630,8 +643,13 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 if (sym8) {
                     // (K3 was written for l <= k only by the symmetric second step of phase A)
                     // (without a request for the unpacked 2-RDM, SB is the dense (pair, pair) matrix)
-                    if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, w.B1 + o, sw,
+                    // (p64 with the unpacked 2-RDM requested: the N^4-addressed SB that comes with it is not used -- it
+                    //  goes to B2, which the next step overwrites -- and B1 gets the dense form every step of this route reads)
+                    if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, (G && p64 ? w.B2 : w.B1) + o, sw,
                                              G ? G + (int64_t)c0 * sG : nullptr, sG, cc, G ? 1 : 2, st)))
+                        return rc;
+                    if (G && p64 &&
+                        (rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, w.B1 + o, sw, nullptr, 0, cc, 2, st)))
                         return rc;
                     prof_stop(pr, st);
                     pr = prof_start(EVC_PROF_Y2, st);
@@ -639,7 +657,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                         // (the K3 buffer holds the first pair step's intermediate; with the unpacked 2-RDM requested
                         //  SB above is N^4-addressed: the dense (pair, pair) form goes to B2, free until the next step)
                         const double *sbp = w.B1 + o;
-                        if (G) {
+                        if (G && !p64) {
                             if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, w.B2 + o, sw, nullptr, 0,
                                                      cc, 2, st)))
                                 return rc;
@@ -671,7 +689,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                 pa.out = w.B2 + o;
                 pa.sout = sw;
                 pa.lead_sym = pa.in_lower = pa.rs_lower = sym8;   // SB is fully symmetric
-                pa.in_pairs = (sym8 && !G) ? 1 : 0;
+                pa.in_pairs = (sym8 && (!G || p64)) ? 1 : 0;
                 pa.out_pairs = sym8;
                 pa.in_ld = pa.out_ld = pair_ld(n);   // (pitch of every dense (pair, pair) form of the pipeline)
                 pr = prof_start(EVC_PROF_PAIR_TRANSFORM, st);
@@ -746,8 +764,8 @@ static int phase_gradient(const evc_trdm_set *t, const Geo &g_in, const Out &out
     Geo g = g_in;
     const int s2kl = (flags & EVC_FLAG_IP1_S2KL) ? 1 : 0;
     if (s2kl) {
-        EVC_REQUIRE(is_sym8(t->layout) && use_pair_transform(n),
-                    "EVC_FLAG_IP1_S2KL needs the compressed layout (EVC_LAYOUT_SYM8) and N <= 32");
+        EVC_REQUIRE(is_sym8(t->layout) && (use_pair_transform(n) || use_pair64(t->layout, n, true)),
+                    "EVC_FLAG_IP1_S2KL needs the compressed layout (EVC_LAYOUT_SYM8) and N <= 64");
         if (cnt > 1) g.sip1 = (int64_t)3 * n * n * (n * (n + 1) / 2);
     }
     const int64_t sw = w.stride;
@@ -987,6 +1005,8 @@ extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g
     EVC_REQUIRE(energy_only || out->grad, "outputs.grad is required unless EVC_FLAG_ENERGY_ONLY");
     const Out o = out_single(out);
     int rc;
+    EVC_REQUIRE(energy_only || t->n <= kPairTransformMaxN || !(flags & EVC_FLAG_ERI_S4) == !(flags & EVC_FLAG_IP1_S2KL),
+                "N > 32: EVC_FLAG_ERI_S4 and EVC_FLAG_IP1_S2KL go together (both packed inputs, or neither)");
     w.warm = (flags & EVC_FLAG_WARM_START) != 0;
     w.split = loewdin_split_mode(t->n, 1, false, energy_only, st);
     Geo gg = geo;
@@ -1066,6 +1086,8 @@ extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geome
     hipStream_t st = as_stream(stream);
     int rc;
     w.warm = (flags & EVC_FLAG_WARM_START) != 0;
+    EVC_REQUIRE(energy_only || t->n <= kPairTransformMaxN || !(flags & EVC_FLAG_ERI_S4) == !(flags & EVC_FLAG_IP1_S2KL),
+                "N > 32: EVC_FLAG_ERI_S4 and EVC_FLAG_IP1_S2KL go together (both packed inputs, or neither)");
     w.loewdin_done = (flags & EVC_FLAG_LOEWDIN_DONE) != 0;
     w.split = loewdin_split_mode(t->n, g.count, w.loewdin_done, energy_only, st);
     g.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;

@@ -1049,6 +1049,11 @@ __global__ __launch_bounds__(256) void pt_pipe4_kernel(PairTransformArgs a) {
 }
 
 int launch_pair_transform(const PairTransformArgs &a_in, int count, hipStream_t st) {
+    if (a_in.n > kPairTransformMaxN) {   // 32 < n <= 64: the symmetric step alone exists (pair64.hip)
+        if (pair64_applicable(a_in)) return launch_pair_transform64(a_in, count, st);
+        set_error("pair transform: n=%d beyond %d needs the symmetric dense-pair form", a_in.n, kPairTransformMaxN);
+        return -1;
+    }
     PairTransformArgs a = a_in;
     const int n = a.n;
     const int npad = (n + 15) / 16 * 16;

@@ -314,14 +314,16 @@ static int y2_fused_tiles(int n, int count) {
     while ((ntiles + t - 1) / t > y2_slab_capacity(n)) ++t;
     return t;
 }
-bool y2_fused_available(int n) { return n >= 1 && n <= kPairTransformMaxN; }
+bool y2_fused_available(int n) { return n >= 1 && (n <= kPairTransformMaxN || y2_64_applicable(n)); }
 int y2_fused_slabs(int n, int count) {
+    if (y2_64_applicable(n)) return y2_64_slabs(n, count);
     const int ppt = y2_fused_ppt(count);
     const int ntiles = (n * (n + 1) / 2 + ppt - 1) / ppt, t = y2_fused_tiles(n, count);
     return (ntiles + t - 1) / t;
 }
 int launch_y2_fused(const double *SB, const double *M1, const double *X, int64_t sX, int n, double *partial,
                     int64_t sws, int count, hipStream_t st) {
+    if (y2_64_applicable(n)) return launch_y2_64(SB, M1, X, sX, n, partial, sws, count, st);
     if (y2_dma_applicable(n))
         return launch_y2_dma(SB, M1, X, sX, n, partial, sws, count, y2_fused_slabs(n, count), y2_fused_tiles(n, count),
                              y2_fused_ppt(count), st);

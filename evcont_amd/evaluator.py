@@ -476,9 +476,11 @@ def _ip1_flag(trdms: "DeviceTRDMs", ao) -> int:
     """EVC_FLAG_IP1_S2KL / EVC_FLAG_ERI_S4 for geometries whose integrals are handed over packed."""
     f = (_lib.FLAG_IP1_S2KL if getattr(ao, "ip1_s2kl", False) else 0) | \
         (_lib.FLAG_ERI_S4 if getattr(ao, "eri_s4", False) else 0)
-    if f and (trdms.layout != _lib.LAYOUT_SYM8 or trdms.n > 32):
+    if f and (trdms.layout != _lib.LAYOUT_SYM8 or trdms.n > 64):
         raise _lib.EvcontHipError("packed (s2kl / s4) integrals need training data in the compressed sym8 layout and "
-                                  "N <= 32 (DeviceAO.from_arrays(..., pack_ip1=False, pack_eri=False) otherwise)")
+                                  "N <= 64 (DeviceAO.from_arrays(..., pack_ip1=False, pack_eri=False) otherwise)")
+    if trdms.n > 32 and f not in (0, _lib.FLAG_IP1_S2KL | _lib.FLAG_ERI_S4) and getattr(ao, "eri_ip1", None) is not None:
+        raise _lib.EvcontHipError("N > 32: int2e and int2e_ip1 are handed over both packed (s4 and s2kl) or both full")
     return f
 
 

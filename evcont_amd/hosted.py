@@ -67,7 +67,7 @@ class HostedEvaluator:
             use_graph = os.environ.get("EVCONT_AMD_HOSTED_GRAPH", "0") not in ("", "0")
         self.t, self.natm = trdms, int(natm)
         d, n = trdms.device, trdms.n
-        self.packed = trdms.layout == _lib.LAYOUT_SYM8 and n <= 32
+        self.packed = trdms.layout == _lib.LAYOUT_SYM8 and n <= 64
         layout = staging_layout(n, self.natm, self.packed)
         shapes = {k: shp for fields, _ in layout for k, shp, _ in fields}
         # two slabs = two H2D copies per step (a copy costs ~12 us before its first byte moves): the early arrays (the
