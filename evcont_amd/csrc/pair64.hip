@@ -211,8 +211,7 @@ __global__ __launch_bounds__(256, 1) void pt64_kernel(PairTransformArgs a) {
 }
 
 bool pair64_applicable(const PairTransformArgs &a) {
-    static const bool on = !(getenv("EVC_PT64") && atoi(getenv("EVC_PT64")) == 0);
-    return on && a.n > kPairTransformMaxN && a.n <= 64 && a.lead_sym && a.in_lower && a.rs_lower && a.in_pairs &&
+    return a.n > kPairTransformMaxN && a.n <= 64 && a.lead_sym && a.in_lower && a.rs_lower && a.in_pairs &&
            !a.k3 && ((a.packed && a.sym8 && !a.out) || (a.out && a.out_pairs && !a.packed));
 }
 

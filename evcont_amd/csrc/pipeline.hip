@@ -115,10 +115,9 @@ static bool use_pair_transform(int n) { return n <= kPairTransformMaxN; }
 // phase, EVC_FLAG_IP1_S2KL with the gradient phase): the symmetric pipeline on 64 x 64 operand matrices (pair64.hip).
 // The two phases of one evaluation must agree (the gradient phase finds the first pair step's intermediate, not the
 // three-quarter-transformed integrals, in the K3 buffer): the fused entry points check it, callers of the phase entry
-// points pass both flags or neither.  EVC_PT64=0: the quarter-step route.
+// points pass both flags or neither.  (Full arrays take the quarter-step route.)
 static bool use_pair64(int layout, int n, bool packed_input) {
-    static const bool on = !(getenv("EVC_PT64") && atoi(getenv("EVC_PT64")) == 0);
-    return on && layout == EVC_LAYOUT_SYM8 && n > kPairTransformMaxN && n <= 64 && packed_input;
+    return layout == EVC_LAYOUT_SYM8 && n > kPairTransformMaxN && n <= 64 && packed_input;
 }
 
 // Geometries per pass of the multi-kernel stages of a batched call (integral rotation, gradient tail): one pass over
