@@ -101,8 +101,7 @@ struct Ws {
     bool loewdin_done;   // X, U, s, h1 are already in the workspace (EVC_FLAG_LOEWDIN_DONE)
     void *base;          // the caller's workspace pointer (key of its side stream, side_of)
     int split;           // Loewdin step of this call: 0 = one kernel; 1 = X, h1 by Newton-Schulz on the call's stream and
-                         // U, s by the eigensolver on the workspace's side stream, joined in front of launch_grad_final;
-                         // 2 = X, h1 alone (energy only)
+                         // U, s by the eigensolver on the device's side stream, joined in front of launch_grad_final
     size_t bytes;    // of ONE geometry
     int64_t stride;  // the same in doubles
     RowProblem rp2, rp1;
@@ -268,6 +267,7 @@ struct Side {
                              // process whose streams outnumber them sees unrelated streams serialised)
     hipEvent_t fork, join;   // of this workspace
     int dev;
+    bool pending;            // an eigensolver launch into this workspace has not been joined yet
 };
 struct SideStream {
     hipStream_t s;
@@ -304,6 +304,17 @@ static Side *side_of(void *ws) {
     return &g_side.emplace(ws, sd).first->second;
 }
 
+// The join: whoever reads U and s of a workspace next (launch_grad_final -- in the same call or, after an energy-only
+// call, in a later evc_phase_gradient on the same workspace) waits for the eigensolver launch that writes them.
+static int side_join(void *ws, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    auto it = g_side.find(ws);
+    if (it == g_side.end() || !it->second.pending) return 0;
+    EVC_HIP(hipStreamWaitEvent(st, it->second.join, 0));
+    it->second.pending = false;
+    return 0;
+}
+
 extern "C" int evc_release_workspace(void *ws) {
     std::lock_guard<std::mutex> lk(g_side_mu);
     auto it = g_side.find(ws);
@@ -330,7 +341,10 @@ static int loewdin_split_mode(int n, int count, bool loewdin_done, bool energy_o
     if (count >= below || loewdin_done || !loewdin_split_available(n)) return 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;
-    return energy_only ? 2 : 1;
+    // (energy-only calls as well: a later evc_phase_gradient on the same workspace reads U and s -- hosted.py uploads the
+    //  gradient's inputs in between)
+    (void)energy_only;
+    return 1;
 }
 
 // Span plan of this call (never more spans than the buffers were carved for).
@@ -385,6 +399,7 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
             la.part = 2;
             if ((rc = launch_loewdin(la, cnt, sd->s))) return rc;
             EVC_HIP(hipEventRecord(sd->join, sd->s));
+            sd->pending = true;
         }
         la.part = w.split ? 1 : 0;
         const int pr = prof_start(EVC_PROF_LOEWDIN, st);
@@ -731,11 +746,7 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
         else gao = w.B2;
     }
     if (!ip1_done && (rc = ip1_stage(gao, 0, cnt))) return rc;
-    if (w.split == 1) {   // U and s come from the side stream (phase_hamiltonian)
-        Side *sd = side_of(w.base);
-        if (!sd) return -1;
-        EVC_HIP(hipStreamWaitEvent(st, sd->join, 0));
-    }
+    if ((rc = side_join(w.base, st))) return rc;   // U and s may come from the side stream (phase_hamiltonian)
     GradFinalArgs f;
     f.n = n;
     f.natm = g.natm;

@@ -188,7 +188,9 @@ def test_scanner(load_golden):
     assert E0 == float(g["enuc"]) and np.array_equal(g0, g["gnuc"])
 
 
-@pytest.mark.parametrize("n,T,A", [(6, 3, 3), (10, 5, 10)])
+# (20: integrals beyond the zero-copy limit of the scanner -- uploads, energy-only call + gradient phase; 34: the same
+#  through the 64-wide kernels of csrc/pair64.hip)
+@pytest.mark.parametrize("n,T,A", [(6, 3, 3), (10, 5, 10), (20, 3, 4), (34, 2, 3)])
 def test_default_call_uses_the_compressed_path(n, T, A):
     """The reference's call, unchanged (ab_initio_gradients_loewdin.py:308-379 with the container's 6-index arrays,
     FCI_EVCont.py:106-131; no extra arguments, no environment): with integrals that have the symmetries of real ones

@@ -105,3 +105,29 @@ def test_small_batches_take_the_split_form(G):
             Eo, go = _oracle(aos[k], one, two_p, S)
             assert abs(E[k] - Eo) < 1e-10, (G, k)
             np.testing.assert_allclose(grad[k], go, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("n", [9, 30, 45])
+def test_energy_only_call_then_gradient_phase(n):
+    """EVC_FLAG_ENERGY_ONLY followed by evc_phase_gradient on the same workspace (what the hosted MD step does between
+    its two uploads, evcont_amd/hosted.py): the gradient phase finds U and s of the split Loewdin step -- joined there,
+    not in the call that forked the eigensolver -- and equals the fused call."""
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
+    dev = torch.device("cuda:0")
+    T, A = 3, 3
+    S, one, two = make_trdms(n, T, 70 + n)
+    two_p = pack_rows(two, True, True)
+    ev = ContinuationEvaluator(DeviceTRDMs(one, two_p, S, dev), A)
+    ref = ContinuationEvaluator(DeviceTRDMs(one, two_p, S, dev), A)
+    for rep in range(3):
+        ao = make_ao_arrays(n, A, 500 + n + rep)
+        dao = DeviceAO.from_arrays(ao, dev)
+        e, _ = ev.energies(dao, nroots=1)            # energy only
+        ev.phase_gradient(dao, False)
+        ev.synchronize()
+        g = ev.grad[:A].cpu().numpy()
+        E2, g2 = ref.energy_with_grad(dao)
+        Eo, go = _oracle(ao, one, two_p, S)
+        assert abs(e[0] - E2) < 1e-12 and abs(E2 - Eo) < 1e-10
+        np.testing.assert_allclose(g, g2, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(g, go, rtol=0, atol=1e-9)
