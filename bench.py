@@ -694,7 +694,10 @@ def main():
                     e_a, _ = sc(mols[k % 4])
                 reps_a.append(nst / (time.perf_counter() - t0))
             val_a = sorted(reps_a)[len(reps_a) // 2]
-            e0_again, _ = sc(mols[0])
+            e0_again, g_api = sc(mols[0])
+            # the forces of the same geometry from a device-resident evaluator (one fused call, no staging)
+            from evcont_amd.evaluator import BatchedEvaluator as _BE, DeviceAOBatch as _DB
+            _, g_res = _BE(trd, A, 1).energies_with_grads(_DB.stack([aos_run[0]]))
             if rank == 0:
                 out["api_default"] = {
                     "value": val_a, "unit": "geometries/s", "ms_per_step": 1e3 / val_a, "repeat_values": reps_a,
@@ -705,6 +708,7 @@ def main():
                                                           or all(v is not None for v in sc._hev._direct.values())),
                     "host_two_rdm_bytes": int(two_h.nbytes),
                     "energy_difference_vs_headline": abs(e0_again - m["check_energy"]),
+                    "force_difference_vs_resident": float(np.abs(np.asarray(g_api) - g_res[0]).max()),
                     "vs_md_hosted": (val_a / out["md_hosted"]["value"]) if "md_hosted" in out else None,
                     "note": "evcont_amd.MD_utils.get_scanner(mol, one_rdm, two_rdm, overlap)(mol) exactly as the "
                             "reference is called (6-index host arrays, default arguments, no environment): first call "
