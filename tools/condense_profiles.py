@@ -39,7 +39,7 @@ def kernel_means(tag):
 
 os.makedirs(OUT, exist_ok=True)
 for tag in ("stats_default", "stats_sym8_b32s1", "stats_pack2_b32s1", "stats_sym8_md", "stats_pack2_md",
-            "stats_zundel100_b32s1", "stats_zundel100_md", "stats_h2ovtz_b4s1", "stats_h10_md"):
+            "stats_zundel100_b32s1", "stats_zundel100_md", "stats_h2ovtz_b4s1", "stats_h2ovtz_b32s1", "stats_h10_md"):
     f = first(f"{tag}/*/*kernel_stats.csv")
     if f:
         rows = [r for r in csv.DictReader(open(f)) if "evc::" in r["Name"]]

@@ -22,6 +22,7 @@ run stats_zundel100_b32s1 --kernel-trace --stats --output-format csv -d $O/stats
 run stats_zundel100_md --kernel-trace --stats --output-format csv -d $O/stats_zundel100_md -- $BENCH --workload Zundel100 --batch 1 --streams 1 --steps 20 --warmup 2
 run stats_h10_md        --kernel-trace --stats --output-format csv -d $O/stats_h10_md -- $BENCH --workload H10 --batch 1 --streams 1 --steps 200
 run stats_h2ovtz_b4s1  --kernel-trace --stats --output-format csv -d $O/stats_h2ovtz_b4s1 -- $BENCH --workload H2Ovtz --batch 4 --streams 1 --geoms 8 --steps 6 --warmup 2
+run stats_h2ovtz_b32s1 --kernel-trace --stats --output-format csv -d $O/stats_h2ovtz_b32s1 -- $BENCH --workload H2Ovtz --batch 32 --streams 1 --geoms 32 --steps 4 --warmup 1
 for lay in sym8 pack2; do
 run pmc_fetch_${lay}_b32 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_${lay}_b32 -- $BENCH --layout $lay --streams 1 --steps 8
 run pmc_write_${lay}_b32 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_${lay}_b32 -- $BENCH --layout $lay --streams 1 --steps 8
