@@ -649,7 +649,7 @@ def main():
                                         "`graph`: whether the step is replayed as a HIP graph, "
                                         "EVCONT_AMD_HOSTED_GRAPH); cold start; PCIe-inclusive, never `value`"}
         del hevs
-    if world == 1 and not a.no_md_regime and not a.energy_only and a.layout == "sym8" and n <= 32 \
+    if world == 1 and not a.no_md_regime and not a.energy_only and a.layout == "sym8" and n <= 64 \
             and not os.environ.get("EVCONT_AMD_COMPRESS"):
         # The reference's call pattern, unchanged: `scanner = MD_utils.get_scanner(mol, one_rdm, two_rdm, overlap)`
         # with the container's 6-index arrays (FCI_EVCont.py:106-131; 2.6 GB on the HOST at H30 / T = 20) and then

@@ -20,8 +20,8 @@ constexpr int kThreads = 256;
 // ------------------------------------------------------------------ small LDS matmul
 // C[i][j] = sum_k a(i,k) * b(k,j),  i,j < n;  thread (tj,tk) owns i = tj+16*, j = tk+16*.
 typedef double d4s __attribute__((ext_vector_type(4)));
-// Small products on the FP64 matrix cores (n <= 32): wave w of the workgroup owns the 16 x 16 output tile
-// (w >> 1, w & 1); operand maps of v_mfma_f64_16x16x4_f64: A[i][k]: lane l holds i = l & 15, k = l >> 4; B[k][j]:
+// Small products on the FP64 matrix cores (n <= 64; up to 32: wave w of the workgroup owns the 16 x 16 output tile
+// (w >> 1, w & 1), beyond: sixteen tiles round-robin); operand maps of v_mfma_f64_16x16x4_f64: A[i][k]: lane l holds i = l & 15, k = l >> 4; B[k][j]:
 // k = l >> 4, j = l & 15; D[i][j]: j = l & 15, i = (l >> 4) + 4 reg.  One eighth of the LDS traffic of the 2 x 2
 // register-blocked vector version (which was LDS-bandwidth bound: ~1 us per 32^3 product against ~0.3 us).
 // EVC_SMALL_MM_VALU (build flag): the vector version everywhere.
@@ -33,15 +33,18 @@ typedef double d4s __attribute__((ext_vector_type(4)));
 template <typename FA, typename FB, typename FC>
 __device__ __forceinline__ void mm16(int n, FA a, FB b, FC store) {
 #ifdef EVC_SMALL_MM_MFMA
-    if (n <= 32) {
+    if (n <= 64) {
+        // (n <= 32: at most four tiles, one per wave -- tile (w >> 1, w & 1) at two tiles per side; up to 64: sixteen
+        //  tiles dealt round-robin, K up to 64)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
-        const int ti = wave >> 1, tj = wave & 1;
-        if (16 * ti < n && 16 * tj < n) {   // wave-uniform
+        const int nt = (n + 15) >> 4;
+        for (int t = wave; t < nt * nt; t += kThreads / 64) {   // wave-uniform
+            const int ti = t / nt, tj = t - ti * nt;
             const int i = 16 * ti + l15, j = 16 * tj + l15;
             const int ic = i < n ? i : 0, jc = j < n ? j : 0;   // (rows / columns beyond n: computed on row 0, never stored)
             d4s acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+            for (int kk = 0; kk < 16; ++kk)
                 if (4 * kk < n) {
                     const int k = 4 * kk + l4;
                     const bool kv = k < n;
