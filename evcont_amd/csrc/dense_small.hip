@@ -1751,16 +1751,21 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
     __syncthreads();
     // (2) two-body rows, placed as the reference does (evcont.py:41-68)
     for (int64_t r = tid; r < rows2; r += kThreads) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        // (eight loads in flight per thread: up to 64 spans are summed here instead of in a launch of their own)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
         int k = 0;
-        for (; k + 4 <= a.nsp2; k += 4) {
+        for (; k + 8 <= a.nsp2; k += 8) {
             s0 += a.h2part[(int64_t)(k + 0) * rows2 + r];
             s1 += a.h2part[(int64_t)(k + 1) * rows2 + r];
             s2 += a.h2part[(int64_t)(k + 2) * rows2 + r];
             s3 += a.h2part[(int64_t)(k + 3) * rows2 + r];
+            s4 += a.h2part[(int64_t)(k + 4) * rows2 + r];
+            s5 += a.h2part[(int64_t)(k + 5) * rows2 + r];
+            s6 += a.h2part[(int64_t)(k + 6) * rows2 + r];
+            s7 += a.h2part[(int64_t)(k + 7) * rows2 + r];
         }
         for (; k < a.nsp2; ++k) s0 += a.h2part[(int64_t)k * rows2 + r];
-        const double s = (s0 + s1) + (s2 + s3);
+        const double s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
         int ia, ib;
         if (pairs) {
             ia = (int)tri_row(r);
@@ -2060,11 +2065,10 @@ int launch_pair_weights(const double *c, int T, int layout, double *w1, double *
 
 // ------------------------------------------------------------------ gradient prep
 // Pao = X D X^T ; Y1 = scale1 * hcore X (D + D^T)
-__global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) {
+__device__ __forceinline__ void grad_prep_body(GradPrepArgs a, int64_t g) {
     extern __shared__ __align__(16) double sm[];
     const int n = a.n;
     {
-        const int64_t g = blockIdx.x;
         a.X += g * a.sws;
         a.hcore += g * a.sh;
         a.D += g * a.sD;
@@ -2140,9 +2144,58 @@ __global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) {
          [&](int i, int j, double v) { a.Y1[i * n + j] = a.scale1 * v; });
 }
 
+__global__ __launch_bounds__(kThreads) void grad_prep_kernel(GradPrepArgs a) { grad_prep_body(a, blockIdx.x); }
+
+// The same launch ALSO unpacks the packed predicted 2-RDM of the compressed layout into the dense symmetric (pair, pair)
+// matrix SB (pack.hip unpack8_pairs_kernel: SB[u][v] = 4 p[tri(max, min)], one wave per row u, four rows per workgroup):
+// both only need what K8 has just written, so the `count` workgroups of the one and the count * ceil(npairs / 4)
+// workgroups of the other share a launch instead of following each other (one kernel boundary and the shorter of the
+// two durations less on the critical path of a step).  Blocks [0, count): grad_prep; the rest: unpack.
+__global__ __launch_bounds__(kThreads) void unpack8_prep_kernel(GradPrepArgs a, const double *__restrict__ p, int64_t sp,
+                                                                double *__restrict__ SB, int64_t sws, int count, int ld) {
+    if ((int)blockIdx.x < count) {
+        grad_prep_body(a, blockIdx.x);
+        return;
+    }
+    const int n = a.n, npairs = n * (n + 1) / 2, bpg = (npairs + 3) / 4;
+    const int b = (int)blockIdx.x - count;
+    // (blocks of eight consecutive geometries interleaved: each XCD works through one geometry's packed vector at a time)
+    const int nx = count & ~7;
+    int geom, blk;
+    if (b < nx * bpg) {
+        const int xcd = b & 7, slot = b >> 3;
+        geom = (slot / bpg) * 8 + xcd;
+        blk = slot % bpg;
+    } else {
+        const int r = b - nx * bpg;
+        geom = nx + r / bpg;
+        blk = r % bpg;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = blk * 4 + wave;
+    if (u >= npairs) return;
+    p += (int64_t)geom * sp;
+    double *sb = SB + (int64_t)geom * sws + (int64_t)u * ld;
+    for (int v = lane; v < npairs; v += 64) sb[v] = 4.0 * (u >= v ? p[tri_index(u, v)] : p[tri_index(v, u)]);
+}
+
+static size_t grad_prep_lds(int n) {
+    return n <= 32 ? sizeof(double) * (size_t)6 * kRsz : sizeof(double) * (size_t)(n > 64 ? 1 : 4) * n * n;
+}
+
+int launch_unpack8_prep(const GradPrepArgs &a, const double *packed, int64_t sp, double *SB, int64_t sws, int count,
+                        hipStream_t st) {
+    const int npairs = a.n * (a.n + 1) / 2, bpg = (npairs + 3) / 4;
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(unpack8_prep_kernel, attr, 160 * 1024, "unpack8_prep")) return rc;
+    hipLaunchKernelGGL(unpack8_prep_kernel, dim3((unsigned)(count + bpg * count)), dim3(kThreads), grad_prep_lds(a.n), st, a,
+                       packed, sp, SB, sws, count, pair_ld(a.n));
+    EVC_LAUNCH_CHECK("unpack8_prep");
+    return 0;
+}
+
 int launch_grad_prep(const GradPrepArgs &a, int count, hipStream_t st) {
-    const size_t lds = a.n <= 32 ? sizeof(double) * (size_t)6 * kRsz
-                                 : sizeof(double) * (size_t)(a.n > 64 ? 1 : 4) * a.n * a.n;
+    const size_t lds = grad_prep_lds(a.n);
     static LdsAttr attr;
     if (int rc = allow_dynamic_lds(grad_prep_kernel, attr, 160 * 1024, "grad_prep")) return rc;
     hipLaunchKernelGGL(grad_prep_kernel, dim3(count), dim3(kThreads), lds, st, a);

@@ -242,6 +242,9 @@ struct GradPrepArgs {
     double scale1;        // 1 on the rank that owns the one-body part, else 0
 };
 int launch_grad_prep(const GradPrepArgs &a, int count, hipStream_t st);
+// grad_prep and the unpack of the packed predicted 2-RDM into the dense (pair, pair) SB in ONE launch (dense_small.hip)
+int launch_unpack8_prep(const GradPrepArgs &a, const double *packed, int64_t sp, double *SB, int64_t sws, int count,
+                        hipStream_t st);
 struct GradFinalArgs {
     int n, natm;
     const double *U, *s;          // eigen-decomposition of S_AO   + g*sws

@@ -124,7 +124,7 @@ static bool use_pair64(int layout, int n, bool packed_input) {
 static int stage_chunk(int count) { return count; }
 
 // Many spans: sum the partials in a multi-workgroup launch instead of inside the eigensolver kernel.
-static bool reduce_in_own_launch(const Ws &w) { return w.rp2.nspans > 48; }
+static bool reduce_in_own_launch(const Ws &w) { return w.rp2.nspans > 64; }
 
 static bool is_sym8(int layout) { return layout == EVC_LAYOUT_SYM8; }
 // Y2 with the half-transformed integrals recomputed (y2.hip y2_fused_kernel): the energy phase then keeps the
@@ -615,7 +615,9 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
     p.sh = g.sh;
     p.sD = sD;
     p.scale1 = scale1;
-    if ((rc = launch_grad_prep(p, cnt, st))) return rc;
+    // (symmetric pipeline without a request for the unpacked 2-RDM: grad_prep rides in the unpack launch below)
+    const bool prep_with_unpack = packed && sym8 && !G && (use_pair_transform(n) || use_pair64(EVC_LAYOUT_SYM8, n, ip1_s2kl != 0));
+    if (!prep_with_unpack && (rc = launch_grad_prep(p, cnt, st))) return rc;
     // 32 < n <= 64: the symmetric pipeline on 64 x 64 matrices when int2e_ip1 came packed (use_pair64)
     const bool p64 = packed && use_pair64(sym8 ? EVC_LAYOUT_SYM8 : 0, n, ip1_s2kl != 0);
     const bool pairs_route = use_pair_transform(n) || p64;
@@ -659,9 +661,14 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
                     // (without a request for the unpacked 2-RDM, SB is the dense (pair, pair) matrix)
                     // (p64 with the unpacked 2-RDM requested: the N^4-addressed SB that comes with it is not used -- it
                     //  goes to B2, which the next step overwrites -- and B1 gets the dense form every step of this route reads)
-                    if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, (G && p64 ? w.B2 : w.B1) + o, sw,
-                                             G ? G + (int64_t)c0 * sG : nullptr, sG, cc, G ? 1 : 2, st)))
-                        return rc;
+                    if (prep_with_unpack && c0 == 0 && cc == cnt) {
+                        if ((rc = launch_unpack8_prep(p, packed, spacked, w.B1, sw, cnt, st))) return rc;
+                    } else {
+                        if (prep_with_unpack && c0 == 0 && (rc = launch_grad_prep(p, cnt, st))) return rc;
+                        if ((rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, (G && p64 ? w.B2 : w.B1) + o, sw,
+                                                 G ? G + (int64_t)c0 * sG : nullptr, sG, cc, G ? 1 : 2, st)))
+                            return rc;
+                    }
                     if (G && p64 &&
                         (rc = launch_unpack8(packed + (int64_t)c0 * spacked, spacked, n, w.B1 + o, sw, nullptr, 0, cc, 2, st)))
                         return rc;
