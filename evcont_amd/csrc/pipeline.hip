@@ -332,13 +332,16 @@ extern "C" int evc_release_workspace(void *ws) {
 }
 
 // which form the Loewdin step of a FULL call (evc_energy_with_grad[_batch]) takes
-static int loewdin_split_mode(int n, int count, bool loewdin_done, bool energy_only, hipStream_t st) {
+static int loewdin_split_mode(int n, int count, bool loewdin_done, bool energy_only, bool warm, hipStream_t st) {
     // EVC_LOEWDIN_SPLIT: calls of fewer than that many geometries take the split form (default 12: the latency regime --
     // MD, small scans; 0: never).  Not the large batches: with several of them in flight on different streams the chip
     // is full anyway and the extra stream costs more than the shorter critical path gains (measured at H30, 32
     // geometries per call: one stream 58 900 -> 64 200 geometries/s, but three streams 87 000 -> 73 700).
     static const int below = getenv("EVC_LOEWDIN_SPLIT") ? atoi(getenv("EVC_LOEWDIN_SPLIT")) : 12;
     if (count >= below || loewdin_done || !loewdin_split_available(n)) return 0;
+    // warm-started calls at n <= 32: the eigensolver is three or four refinement passes from the previous call's vectors,
+    // cheaper than the fork and join around it (H10 along a trajectory: 9 970 steps/s split, 12 000 not)
+    if (warm && n <= kPairTransformMaxN) return 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;
     // (energy-only calls as well: a later evc_phase_gradient on the same workspace reads U and s -- hosted.py uploads the
@@ -1025,7 +1028,7 @@ extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g
     EVC_REQUIRE(energy_only || t->n <= kPairTransformMaxN || !(flags & EVC_FLAG_ERI_S4) == !(flags & EVC_FLAG_IP1_S2KL),
                 "N > 32: EVC_FLAG_ERI_S4 and EVC_FLAG_IP1_S2KL go together (both packed inputs, or neither)");
     w.warm = (flags & EVC_FLAG_WARM_START) != 0;
-    w.split = loewdin_split_mode(t->n, 1, false, energy_only, st);
+    w.split = loewdin_split_mode(t->n, 1, false, energy_only, w.warm, st);
     Geo gg = geo;
     gg.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
     if ((rc = phase_hamiltonian(t, gg, w, false, st))) return rc;
@@ -1106,7 +1109,7 @@ extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geome
     EVC_REQUIRE(energy_only || t->n <= kPairTransformMaxN || !(flags & EVC_FLAG_ERI_S4) == !(flags & EVC_FLAG_IP1_S2KL),
                 "N > 32: EVC_FLAG_ERI_S4 and EVC_FLAG_IP1_S2KL go together (both packed inputs, or neither)");
     w.loewdin_done = (flags & EVC_FLAG_LOEWDIN_DONE) != 0;
-    w.split = loewdin_split_mode(t->n, g.count, w.loewdin_done, energy_only, st);
+    w.split = loewdin_split_mode(t->n, g.count, w.loewdin_done, energy_only, w.warm, st);
     g.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
     if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
     if ((rc = phase_solve(t, g, nullptr, 0, o, nroots, w, st))) return rc;
