@@ -34,7 +34,8 @@ def _oracle(ao, one, two_p, S):
 
 @pytest.mark.parametrize("n,cond", [(n, c) for n in (1, 2, 3, 5, 8, 13, 16, 17, 24, 30, 31, 32) for c in (3.0, 1e3, 1e6)] +
                          # 32 < n <= 64: the 64 x 64 iteration (loewdin_ns64_kernel) in front of loewdin_big_kernel
-                         [(33, 3.0), (40, 1e3), (48, 1e6), (58, 1e3), (63, 3.0), (64, 1e3)])
+                         # (63 / 64: tests/test_gpu_pair64.py, whose single-geometry cases take the same split route)
+                         [(33, 3.0), (40, 1e3), (48, 1e6), (58, 1e3)])
 def test_split_call_equals_phase_calls_and_oracle(n, cond):
     from evcont_amd.evaluator import DeviceTRDMs, DeviceAO, ContinuationEvaluator
     dev = torch.device("cuda:0")

@@ -33,9 +33,10 @@ def _setup(n, T, A, sizes, seed, G):
     return trd, aos, (one_h, two_h, S_h)
 
 
-@pytest.mark.parametrize("n,T,A,sizes,G", [(33, 3, 3, (11, 11, 11), 1), (40, 4, 2, (25, 15), 2), (48, 3, 3, (16, 16, 16), 4),
+# (G = 13: a batch beyond the split threshold -- one-kernel Loewdin step, K5 / K8 on the matrix cores)
+@pytest.mark.parametrize("n,T,A,sizes,G", [(33, 3, 3, (11, 11, 11), 1), (40, 4, 2, (25, 15), 13), (48, 3, 3, (16, 16, 16), 4),
                                            (58, 8, 3, (30, 14, 14), 1), (58, 8, 3, (30, 14, 14), 4),
-                                           (63, 2, 3, (21, 21, 21), 1), (64, 3, 2, (40, 24), 13)])
+                                           (63, 2, 3, (21, 21, 21), 1), (64, 3, 2, (40, 24), 2)])
 def test_pair64_pipeline_against_oracle(n, T, A, sizes, G):
     from evcont_amd import _lib
     from evcont_amd.evaluator import DeviceAOBatch, BatchedEvaluator
