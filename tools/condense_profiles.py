@@ -89,4 +89,12 @@ if lds:
         fo.write("kernel," + ",".join(cols) + "\n")
         for k, d in lds.items():
             fo.write(k + "," + ",".join(f"{d.get(c, 0):.0f}" for c in cols) + "\n")
+for tag, name in (("pmc_sq_h2ovtz_b4", "pmc_sq_h2ovtz_batch4"), ("pmc_lds_h2ovtz_b4", "pmc_lds_h2ovtz_batch4")):
+    m = kernel_means(tag)   # the 64-wide kernels of csrc/pair64.hip (cc-pVTZ water shape, four geometries per batch)
+    if m:
+        cols = sorted({c for d in m.values() for c in d})
+        with open(os.path.join(OUT, f"{ROUND}_{name}.csv"), "w") as fo:
+            fo.write("kernel," + ",".join(cols) + "\n")
+            for k, d in m.items():
+                fo.write(k + "," + ",".join(f"{d.get(c, 0):.0f}" for c in cols) + "\n")
 print(json.dumps(traffic, indent=1))

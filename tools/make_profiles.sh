@@ -31,6 +31,9 @@ run pmc_write_${lay}_md  --kernel-trace --pmc WRITE_SIZE --output-format csv -d 
 done
 run pmc_sq_sym8_b32    --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_sq_sym8_b32 -- $BENCH --streams 1 --steps 8
 run pmc_lds_sym8_b32   --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_lds_sym8_b32 -- $BENCH --streams 1 --steps 8
+H2O="--workload H2Ovtz --batch 4 --streams 1 --geoms 8 --steps 4 --warmup 1"
+run pmc_sq_h2ovtz_b4   --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_sq_h2ovtz_b4 -- $BENCH $H2O
+run pmc_lds_h2ovtz_b4  --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_lds_h2ovtz_b4 -- $BENCH $H2O
 grep -h "\"metric\"" $O/stats_*.log | cut -c1-160; du -sh $O
 python3 $R/tools/condense_profiles.py ${ROUND:-r01} $R/gpurun_out/profiles_out > $R/gpurun_out/profiles_out.log 2>&1
 rm -rf $O
