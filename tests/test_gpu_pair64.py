@@ -75,3 +75,42 @@ def test_pair64_energy_only_and_predicted_rdms(n):
     np.testing.assert_allclose(D, D2, rtol=0, atol=1e-11)
     np.testing.assert_allclose(Gm, G2, rtol=0, atol=1e-11)
     np.testing.assert_allclose(g, g2, rtol=0, atol=1e-9)
+
+
+def test_pair64_phase_calls_on_row_slices():
+    """The three phase entry points on two row slices of the compressed set (emulated pair sharding, the collectives
+    laid out as distributed.PairShardedContinuation does) at N = 34 with packed inputs: the gradient phase of every
+    slice finds the first pair step's intermediate its energy phase left in the workspace; sum of the partial gradients
+    = the fused call."""
+    from evcont_amd.evaluator import DeviceTRDMs, DeviceAOBatch, BatchedEvaluator
+    from evcont_amd.distributed import shard_rows
+    from evcont_amd.synthetic import make_device_ao, make_device_trdm_rows
+    dev = torch.device(DEV)
+    n, T, A, G, world = 34, 4, 2, 2, 2
+    S, one, rows = make_device_trdm_rows(n, T, 2, 5300, dev)
+    aos = [make_device_ao(n, A, 5300000 + k, dev, None, ip1_rs_symmetric=True).packed_ip1(eri=True) for k in range(G)]
+    aob = DeviceAOBatch.stack(aos)
+    trd = DeviceTRDMs.from_device_rows(one, rows.clone(), S, 2)
+    trd.compress_sym8_()
+    Eref, gref = BatchedEvaluator(trd, A, G).energies_with_grads(aob)
+    nrows = T * (T + 1) // 2
+    chunk = -(-nrows // world)
+    evs, send = [], []
+    for r in range(world):
+        r0, r1 = shard_rows(nrows, world, r)
+        t_r = DeviceTRDMs.from_device_rows(one, rows[r0:r1].contiguous(), S, 2, row_offset=r0, rows_total=nrows)
+        t_r.compress_sym8_()
+        evs.append(BatchedEvaluator(t_r, A, G))
+        buf = torch.zeros((G, chunk), dtype=torch.float64, device=dev)
+        evs[-1].phase_hamiltonian(aob, buf)
+        send.append(buf)
+    rows_all = torch.stack(send).permute(1, 0, 2).reshape(G, world * chunk).contiguous()
+    total = torch.zeros_like(evs[0].grad)
+    for r, ev in enumerate(evs):
+        ev.phase_solve(aob, rows_all, 1)
+        ev.phase_gradient(aob, partial_rank=(r != 0))
+        total += ev.grad
+    torch.cuda.synchronize()
+    for ev in evs:
+        np.testing.assert_allclose(ev.energy[:, 0].cpu().numpy(), Eref, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(total.cpu().numpy()[:, :A], gref, rtol=0, atol=1e-10)
