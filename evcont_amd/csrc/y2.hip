@@ -24,7 +24,8 @@ static int y2_slab_count() {
 }
 int y2_slabs(int) { return y2_slab_count(); }
 // slabs the partial buffer of the pipeline is sized for (the fused kernel below uses up to that many workgroups)
-int y2_slab_capacity(int) { return y2_slab_count() > 128 ? y2_slab_count() : 128; }
+// (beyond 32 orbitals y2_64_kernel deals the pairs of ONE geometry to a full round of the chip)
+int y2_slab_capacity(int n) { return n > kPairTransformMaxN ? 256 : (y2_slab_count() > 128 ? y2_slab_count() : 128); }
 
 template <int NT>
 __global__ __launch_bounds__(256) void y2_kernel(const double *__restrict__ GsT, const double *__restrict__ K3,
