@@ -33,15 +33,37 @@ typedef double d4s __attribute__((ext_vector_type(4)));
 template <typename FA, typename FB, typename FC>
 __device__ __forceinline__ void mm16(int n, FA a, FB b, FC store) {
 #ifdef EVC_SMALL_MM_MFMA
-    if (n <= 64) {
-        // (n <= 32: at most four tiles, one per wave -- tile (w >> 1, w & 1) at two tiles per side; up to 64: sixteen
-        //  tiles dealt round-robin, K up to 64)
+    if (n <= 32) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+        const int ti = wave >> 1, tj = wave & 1;
+        if (16 * ti < n && 16 * tj < n) {   // wave-uniform
+            const int i = 16 * ti + l15, j = 16 * tj + l15;
+            const int ic = i < n ? i : 0, jc = j < n ? j : 0;   // (rows / columns beyond n: computed on row 0, never stored)
+            d4s acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (4 * kk < n) {
+                    const int k = 4 * kk + l4;
+                    const bool kv = k < n;
+                    const int kc = kv ? k : 0;
+                    const double av = a(ic, kc), bv = b(kc, jc);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kv ? av : 0.0, kv ? bv : 0.0, acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ii = 16 * ti + l4 + 4 * r;
+                if (ii < n && j < n) store(ii, j, acc[r]);
+            }
+        }
+        return;
+    }
+    if (n <= 64) {   // up to sixteen tiles, dealt round-robin to the four waves, K up to 64
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
         const int nt = (n + 15) >> 4;
         for (int t = wave; t < nt * nt; t += kThreads / 64) {   // wave-uniform
             const int ti = t / nt, tj = t - ti * nt;
             const int i = 16 * ti + l15, j = 16 * tj + l15;
-            const int ic = i < n ? i : 0, jc = j < n ? j : 0;   // (rows / columns beyond n: computed on row 0, never stored)
+            const int ic = i < n ? i : 0, jc = j < n ? j : 0;
             d4s acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk)
