@@ -1482,9 +1482,8 @@ __global__ __launch_bounds__(kThreads) void loewdin_ns64_kernel(LoewdinArgs a) {
 }
 
 // ------------------------------------------------------------------ Loewdin
-__global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
+__device__ __forceinline__ void loewdin_body(LoewdinArgs a, const int64_t g) {
     const int n = a.n;
-    const int64_t g = blockIdx.x;
     const double *__restrict__ S = a.S + g * a.sS;
     const double *__restrict__ h = a.h ? a.h + g * a.sh : nullptr;
     double *__restrict__ X = a.X + g * a.sws;
@@ -1608,6 +1607,8 @@ __global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) {
     }
 }
 
+__global__ __launch_bounds__(kThreads) void loewdin_kernel(LoewdinArgs a) { loewdin_body(a, blockIdx.x); }
+
 static size_t jacobi_aux_bytes(int m) {
     return sizeof(double) * (size_t)(2 * m + 8) + 32 +
            (m <= kJwMax ? sizeof(double) * ((size_t)kJwMax * kJwPitch + (size_t)6 * kRsz) + 16 : 0);
@@ -1721,10 +1722,10 @@ __device__ __forceinline__ void chol_inverse_wave(const double *Ssrc, int T, dou
 }
 
 // ------------------------------------------------------------------ subspace solve
-__global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
+__device__ __forceinline__ void subspace_body(SolveArgs a, const int64_t gblk) {
     extern __shared__ __align__(16) double sm[];
     {
-        const int64_t g = blockIdx.x;
+        const int64_t g = gblk;
         a.h1part += g * a.sh1;
         if (a.h2part) a.h2part += g * a.sh2;
         a.S += g * a.sS;
@@ -2014,7 +2015,7 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
             const double w = c0[ia] * c0[idx - ia * T];
             a.w1[idx] = w;
             // transposed copy for the batched K8: [row][slot] in the workspace of the group's first geometry
-            if (a.w1t) a.w1t[(int64_t)idx * kMaxBatchG + (int)(blockIdx.x % kMaxBatchG)] = w;
+            if (a.w1t) a.w1t[(int64_t)idx * kMaxBatchG + (int)(gblk % kMaxBatchG)] = w;
         }
     if (a.w2) {
         for (int64_t r = tid; r < a.w2_count; r += kThreads) {
@@ -2029,9 +2030,43 @@ __global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) {
             }
             a.w2[r] = w;
             // transposed copy for the batched K8: [row][slot] in the workspace of the group's first geometry
-            if (a.w2t) a.w2t[r * kMaxBatchG + (int)(blockIdx.x % kMaxBatchG)] = w;
+            if (a.w2t) a.w2t[r * kMaxBatchG + (int)(gblk % kMaxBatchG)] = w;
         }
     }
+}
+
+__global__ __launch_bounds__(kThreads) void subspace_kernel(SolveArgs a) { subspace_body(a, blockIdx.x); }
+
+// The subspace solve and the eigendecomposition half of the Loewdin step (part 2: U and s, which the gradient's last
+// kernel alone reads) in ONE launch: `count` workgroups each, both one workgroup per geometry and latency-bound, neither
+// depending on the other -- the eigensolver (~75 us) then runs beside the subspace solve (~54 us) instead of in front of
+// the whole energy phase, with no second stream (batches of 12 and more geometries; smaller calls send it to the side
+// stream, pipeline.hip).
+__global__ __launch_bounds__(kThreads) void subspace_loewdin_kernel(SolveArgs sa, LoewdinArgs la, int count) {
+    if ((int)blockIdx.x < count) subspace_body(sa, blockIdx.x);
+    else loewdin_body(la, (int64_t)blockIdx.x - count);
+}
+
+int launch_subspace_loewdin(const SolveArgs &s_in, const LoewdinArgs &l_in, int count, hipStream_t st) {
+    SolveArgs a = s_in;
+    LoewdinArgs l = l_in;
+    a.fast = l.fast = eigh_fast_enabled();
+    static const int few_on = getenv("EVC_SUBSPACE_FEW") ? atoi(getenv("EVC_SUBSPACE_FEW")) : 1;
+    a.few = few_on;
+    l.part = 2;
+    if (a.T > kSubspaceSmallT || l.n > kJwMax || !l.fast) {
+        set_error("subspace + Loewdin in one launch: T=%d, n=%d outside the small-kernel range", a.T, l.n);
+        return -1;
+    }
+    const int m = (a.T + 1) & ~1, ml = (l.n + 1) & ~1;
+    const size_t lds_s = sizeof(double) * (size_t)4 * m * m + sizeof(int) * m + jacobi_aux_bytes(m);
+    const size_t lds_l = sizeof(double) * (size_t)3 * ml * ml + jacobi_aux_bytes(ml);
+    static LdsAttr attr;
+    if (int rc = allow_dynamic_lds(subspace_loewdin_kernel, attr, 160 * 1024, "subspace_loewdin")) return rc;
+    hipLaunchKernelGGL(subspace_loewdin_kernel, dim3(2 * count), dim3(kThreads), lds_s > lds_l ? lds_s : lds_l, st, a, l,
+                       count);
+    EVC_LAUNCH_CHECK("subspace_loewdin");
+    return 0;
 }
 
 int launch_subspace_solve(const SolveArgs &a_in, int count, hipStream_t st) {

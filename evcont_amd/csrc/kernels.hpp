@@ -222,6 +222,8 @@ struct SolveArgs {
 };
 constexpr int kSubspaceSmallT = 32;   // up to here: the register / 32 x 32-tile kernel of dense_small.hip
 constexpr int kSubspaceMaxT = 512;    // beyond kSubspaceSmallT: subspace_big.hip (LDS-resident up to 128, then global)
+// subspace solve + the eigendecomposition half of the Loewdin step (part 2) in one launch (dense_small.hip)
+int launch_subspace_loewdin(const SolveArgs &s, const LoewdinArgs &l, int count, hipStream_t st);
 int launch_subspace_solve(const SolveArgs &a, int count, hipStream_t st);
 // subspace_big.hip: T > kSubspaceSmallT (vstd, when given, holds Tp^2 doubles: the eigenvectors as ROWS at pitch Tp)
 size_t subspace_big_scratch_doubles(int T);

@@ -101,7 +101,9 @@ struct Ws {
     bool loewdin_done;   // X, U, s, h1 are already in the workspace (EVC_FLAG_LOEWDIN_DONE)
     void *base;          // the caller's workspace pointer (key of its side stream, side_of)
     int split;           // Loewdin step of this call: 0 = one kernel; 1 = X, h1 by Newton-Schulz on the call's stream and
-                         // U, s by the eigensolver on the device's side stream, joined in front of launch_grad_final
+                         // U, s by the eigensolver on the device's side stream, joined in front of launch_grad_final;
+                         // 3 = the same with the eigensolver riding in the launch of the subspace solve (la_ride)
+    LoewdinArgs la_ride; // split == 3: the eigensolver launch phase_solve still owes
     size_t bytes;    // of ONE geometry
     int64_t stride;  // the same in doubles
     RowProblem rp2, rp1;
@@ -332,13 +334,21 @@ extern "C" int evc_release_workspace(void *ws) {
 }
 
 // which form the Loewdin step of a FULL call (evc_energy_with_grad[_batch]) takes
-static int loewdin_split_mode(int n, int count, bool loewdin_done, bool energy_only, bool warm, hipStream_t st) {
+static int loewdin_split_mode(int n, int ntrain, int count, bool loewdin_done, bool energy_only, bool warm,
+                              hipStream_t st) {
     // EVC_LOEWDIN_SPLIT: calls of fewer than that many geometries take the split form (default 12: the latency regime --
     // MD, small scans; 0: never).  Not the large batches: with several of them in flight on different streams the chip
     // is full anyway and the extra stream costs more than the shorter critical path gains (measured at H30, 32
     // geometries per call: one stream 58 900 -> 64 200 geometries/s, but three streams 87 000 -> 73 700).
     static const int below = getenv("EVC_LOEWDIN_SPLIT") ? atoi(getenv("EVC_LOEWDIN_SPLIT")) : 12;
-    if (count >= below || loewdin_done || !loewdin_split_available(n)) return 0;
+    if (loewdin_done || !loewdin_split_available(n)) return 0;
+    if (count >= below) {
+        // large batches: no second stream (several of them are in flight on the caller's streams: the chip is full and
+        // the hardware queues are taken) -- the eigensolver half rides in the launch of the subspace solve instead, one
+        // workgroup per geometry beside one workgroup per geometry (dense_small.hip subspace_loewdin_kernel); small
+        // kernels only: n <= 32 orbitals, T <= 32 states
+        return (below > 0 && n <= kPairTransformMaxN && ntrain <= kSubspaceSmallT) ? 3 : 0;
+    }
     // warm-started calls at n <= 32: the eigensolver is three or four refinement passes from the previous call's vectors,
     // cheaper than the fork and join around it (H10 along a trajectory: 9 970 steps/s split, 12 000 not)
     if (warm && n <= kPairTransformMaxN) return 0;
@@ -408,6 +418,7 @@ static int phase_hamiltonian(const evc_trdm_set *t, const Geo &g_in, Ws &w, bool
         const int pr = prof_start(EVC_PROF_LOEWDIN, st);
         if ((rc = launch_loewdin(la, cnt, st))) return rc;
         prof_stop(pr, st);
+        if (w.split == 3) w.la_ride = la;
     }
     // (ab|cd) -> K3[jkl][a] -> h2[ijkl]
     const double *v2;
@@ -562,7 +573,7 @@ static int phase_solve(const evc_trdm_set *t, const Geo &g, const double *h2rows
     a.sscratch = sw;
     a.warm = w.warm ? 1 : 0;
     const int pr = prof_start(EVC_PROF_SUBSPACE, st);
-    const int rc = launch_subspace_solve(a, g.count, st);
+    const int rc = w.split == 3 ? launch_subspace_loewdin(a, w.la_ride, g.count, st) : launch_subspace_solve(a, g.count, st);
     prof_stop(pr, st);
     return rc;
 }
@@ -1028,7 +1039,7 @@ extern "C" int evc_energy_with_grad(const evc_trdm_set *t, const evc_geometry *g
     EVC_REQUIRE(energy_only || t->n <= kPairTransformMaxN || !(flags & EVC_FLAG_ERI_S4) == !(flags & EVC_FLAG_IP1_S2KL),
                 "N > 32: EVC_FLAG_ERI_S4 and EVC_FLAG_IP1_S2KL go together (both packed inputs, or neither)");
     w.warm = (flags & EVC_FLAG_WARM_START) != 0;
-    w.split = loewdin_split_mode(t->n, 1, false, energy_only, w.warm, st);
+    w.split = loewdin_split_mode(t->n, t->ntrain, 1, false, energy_only, w.warm, st);
     Geo gg = geo;
     gg.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
     if ((rc = phase_hamiltonian(t, gg, w, false, st))) return rc;
@@ -1109,7 +1120,7 @@ extern "C" int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geome
     EVC_REQUIRE(energy_only || t->n <= kPairTransformMaxN || !(flags & EVC_FLAG_ERI_S4) == !(flags & EVC_FLAG_IP1_S2KL),
                 "N > 32: EVC_FLAG_ERI_S4 and EVC_FLAG_IP1_S2KL go together (both packed inputs, or neither)");
     w.loewdin_done = (flags & EVC_FLAG_LOEWDIN_DONE) != 0;
-    w.split = loewdin_split_mode(t->n, g.count, w.loewdin_done, energy_only, w.warm, st);
+    w.split = loewdin_split_mode(t->n, t->ntrain, g.count, w.loewdin_done, energy_only, w.warm, st);
     g.eri_s4 = (flags & EVC_FLAG_ERI_S4) ? 1 : 0;
     if ((rc = phase_hamiltonian(t, g, w, false, st))) return rc;
     if ((rc = phase_solve(t, g, nullptr, 0, o, nroots, w, st))) return rc;
