@@ -254,15 +254,14 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const double *partial,
     }
 }
 
-// ---- the Loewdin step in two halves (n <= 32) -------------------------------------------------------------
+// ---- the Loewdin step in two halves (n <= 64) -------------------------------------------------------------
 // The energy phase needs X = S^-1/2 and h1 only; the eigenvectors and eigenvalues of S enter at the very end of the
 // gradient (the response term, launch_grad_final).  A full call therefore computes X and h1 by Newton-Schulz on the
-// matrix cores (dense_small.hip loewdin_ns, ~12 us) on its own stream and sends the eigensolver (~65 us) to a side
-// stream, forked at the start of the call and joined in front of launch_grad_final: one geometry at a time (MD) the
-// eigensolver leaves the critical path altogether (H30: 3 780 -> 4 440 steps/s).
-// One side stream per device and two events per workspace, created at the workspace's first such call; the events live
-// until evc_release_workspace.  Not used while the stream is being captured into a graph, nor by the phase calls, nor
-// by large batches (loewdin_split_mode).
+// matrix cores (dense_small.hip loewdin_ns / loewdin_ns64_kernel) and keeps the eigensolver off the critical path
+// (loewdin_split_mode below): either in the launch of the subspace solve (Ws.split = 3) or on a side stream, forked at
+// the start of the call and joined by whichever call reads U and s next (Ws.split = 1):
+// one side stream per device and two events per workspace, created at the workspace's first such call; the events live
+// until evc_release_workspace, the stream until the last workspace that used it is released.
 struct Side {
     hipStream_t s;           // the device's side stream (shared by all workspaces on it: one more hardware queue in use,
                              // not one per workspace -- the runtime multiplexes all streams onto four of them, and a
@@ -336,21 +335,20 @@ extern "C" int evc_release_workspace(void *ws) {
 // which form the Loewdin step of a FULL call (evc_energy_with_grad[_batch]) takes
 static int loewdin_split_mode(int n, int ntrain, int count, bool loewdin_done, bool energy_only, bool warm,
                               hipStream_t st) {
-    // EVC_LOEWDIN_SPLIT: calls of fewer than that many geometries take the split form (default 12: the latency regime --
-    // MD, small scans; 0: never).  Not the large batches: with several of them in flight on different streams the chip
-    // is full anyway and the extra stream costs more than the shorter critical path gains (measured at H30, 32
-    // geometries per call: one stream 58 900 -> 64 200 geometries/s, but three streams 87 000 -> 73 700).
-    static const int below = getenv("EVC_LOEWDIN_SPLIT") ? atoi(getenv("EVC_LOEWDIN_SPLIT")) : 12;
-    if (loewdin_done || !loewdin_split_available(n)) return 0;
-    if (count >= below) {
-        // large batches: no second stream (several of them are in flight on the caller's streams: the chip is full and
-        // the hardware queues are taken) -- the eigensolver half rides in the launch of the subspace solve instead, one
-        // workgroup per geometry beside one workgroup per geometry (dense_small.hip subspace_loewdin_kernel); small
-        // kernels only: n <= 32 orbitals, T <= 32 states
-        return (below > 0 && n <= kPairTransformMaxN && ntrain <= kSubspaceSmallT) ? 3 : 0;
-    }
-    // warm-started calls at n <= 32: the eigensolver is three or four refinement passes from the previous call's vectors,
-    // cheaper than the fork and join around it (H10 along a trajectory: 9 970 steps/s split, 12 000 not)
+    // EVC_LOEWDIN_SPLIT=0: the one-kernel Loewdin step always.
+    static const int knob = getenv("EVC_LOEWDIN_SPLIT") ? atoi(getenv("EVC_LOEWDIN_SPLIT")) : 12;
+    if (knob == 0 || loewdin_done || !loewdin_split_available(n)) return 0;
+    // Small kernels on both sides (n <= 32 orbitals, T <= 32 states), any number of geometries, cold or warm: the
+    // eigensolver half rides in the launch of the subspace solve, one workgroup per geometry beside one workgroup per
+    // geometry (dense_small.hip subspace_loewdin_kernel) -- no second stream.  One geometry per call it performs like the
+    // side stream below (H30: 4 480 against 4 500 steps/s, H10: 11 170 against 11 210) without costing the process a
+    // hardware queue; 32 geometries per call on one stream: 60 700 -> 64 500 geometries/s, three streams unchanged.
+    if (n <= kPairTransformMaxN && ntrain <= kSubspaceSmallT) return 3;
+    // Otherwise (33 ... 64 orbitals: the 1024-thread eigensolver, 550 us at n = 58, has no launch to ride in; or a large
+    // training set) the side stream, for calls of fewer than `knob` geometries (default 12: the latency regime).  Not the
+    // large batches: with several of them in flight on different streams the chip is full anyway and a fifth stream
+    // shares a hardware queue with one of them (measured at H30, 32 geometries per call, three streams: 87 000 -> 73 700).
+    if (count >= knob) return 0;
     if (warm && n <= kPairTransformMaxN) return 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;

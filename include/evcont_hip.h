@@ -288,15 +288,15 @@ typedef struct evc_outputs_batch {
 } evc_outputs_batch;
 
 size_t evc_workspace_bytes_batch(const evc_trdm_set *t, int natm, int count);
-/* For N <= 64, full calls (evc_energy_with_grad, evc_energy_with_grad_batch) of fewer than 12 geometries -- the latency
- * regime: MD, small scans -- compute the Loewdin transformation X = S^-1/2 (electron_integral_utils.py:6-18) by a
- * Newton-Schulz iteration on `stream` and run the eigendecomposition of S, which only the response term of the
- * gradient needs (ab_initio_gradients_loewdin.py:41-134,300-303), on a side stream the library creates per device; the
- * side stream is forked from and joined into `stream` inside the call (two events per workspace, created at its first
- * such call), so the stream semantics of the call are unchanged.  Before freeing a workspace, hand its pointer to
+/* The full calls (evc_energy_with_grad, evc_energy_with_grad_batch) compute the Loewdin transformation X = S^-1/2
+ * (electron_integral_utils.py:6-18) by a Newton-Schulz iteration and keep the eigendecomposition of S, which only the
+ * response term of the gradient needs (ab_initio_gradients_loewdin.py:41-134,300-303), off the critical path: for
+ * N <= 32 and T <= 32 it rides in the launch of the subspace solve; for 33 ... 64 orbitals (or larger training sets)
+ * calls of fewer than 12 geometries run it on a side stream the library creates per device, forked from and joined into
+ * `stream` inside the call (two events per workspace, created at its first such call) -- the stream semantics of the
+ * call are unchanged.  Before freeing a workspace that may have been used that way, hand its pointer to
  * evc_release_workspace: it waits for the last such launch into the workspace and destroys the events (a pointer that
- * owns none: no-op, returns 0).  While `stream` is being captured into a graph the step is one kernel on `stream`;
- * EVC_LOEWDIN_SPLIT=<count> moves the threshold (0: never). */
+ * owns none: no-op, returns 0).  EVC_LOEWDIN_SPLIT=0: one Loewdin kernel always. */
 int evc_release_workspace(void *ws);
 int evc_energy_with_grad_batch(const evc_trdm_set *t, const evc_geometry_batch *gb,
                                const evc_outputs_batch *ob, int nroots, int flags, void *ws,

@@ -1,6 +1,7 @@
 """The Loewdin step in two halves (csrc/pipeline.hip "the Loewdin step in two halves", csrc/dense_small.hip loewdin_ns):
-full calls of a few geometries compute X = S^-1/2 by a Newton-Schulz iteration on the matrix cores and run the
-eigendecomposition of S (needed by the response term only, ab_initio_gradients_loewdin.py:41-134) on a side stream.
+full calls compute X = S^-1/2 by a Newton-Schulz iteration on the matrix cores and run the eigendecomposition of S
+(needed by the response term only, ab_initio_gradients_loewdin.py:41-134) off the critical path -- in the launch of
+the subspace solve (N <= 32, T <= 32) or, for a few geometries of 33 ... 64 orbitals, on a side stream.
 The phase calls keep the one-kernel form (eigensolver for everything): the two routes must agree, and both with the
 oracle, for every matrix size, for well and badly conditioned overlap matrices (where the iteration must decline and
 the kernel falls through to the eigensolver), single geometries and small batches, repeated calls on one workspace."""

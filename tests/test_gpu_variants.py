@@ -20,8 +20,7 @@ SUBSET = ["tests/test_gpu_sym8.py::test_packed_ip1_input", "tests/test_gpu_sym8.
     {"EVC_PT_PIPE": "0", "EVC_PT_DMA": "0"}, # phase-alternating pair transform (pt_kernel) instead of ptd_kernel / pt_pipe_kernel
     {"EVC_PT_DMA": "0"},                      # pt_pipe_kernel (operand rows through registers) instead of ptd_kernel (LDS-DMA)
     {"EVC_SUBSPACE_FEW": "0"},                # subspace kernels: no few-roots route (full eigensolver / Jacobi sweeps always)
-    {"EVC_LOEWDIN_SPLIT": "0"},               # Loewdin step as one kernel always (no Newton-Schulz X, no side stream)
-    {"EVC_LOEWDIN_SPLIT": "4096"},            # ... in two halves for batches of every size
+    {"EVC_LOEWDIN_SPLIT": "0"},               # Loewdin step as one kernel always (no Newton-Schulz X, no riding eigensolver)
     {"EVC_EIGH_F32": "0"},                    # FP64 Jacobi eigensolvers
     {"EVC_EIGH_F32": "1"},                    # FP32 Jacobi start + refinement
     {"EVC_ROWS_LDS": "0"},                    # batched K5 with fragment-shaped loads (gemv_rows_mfma_pipe_kernel)
