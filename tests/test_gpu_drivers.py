@@ -146,6 +146,7 @@ def test_hosted_evaluator_matches_resident_path():
     ("h10_forces.py", ["--radius", "0.2", "--points", "12", "--exact", "0", "--fixture"]),
     ("h30_md.py", ["--atoms", "8", "--train", "4", "--steps", "4"]),
     ("zundel_md.py", ["--demo", "--steps", "4"]),
+    ("h2o_md.py", ["--demo", "--steps", "3"]),
 ])
 def test_example_drivers_run(script, args, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(REPO, "examples", script)] + args, cwd=tmp_path,
