@@ -2331,15 +2331,22 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     }
     for (int idx = tid; idx < 3 * n; idx += kThreads) {
         const int m_ = idx / 3, x = idx - 3 * m_;
+        // (eight loads in flight: the partials of one (m, x) are a chain of nchunk >= n dependent round trips otherwise)
         const double *p = a.t2part + ((int64_t)m_ * 3 + x) * a.nchunk;
-        double s0 = 0.0, s1 = 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
         int ch = 0;
-        for (; ch + 2 <= a.nchunk; ch += 2) {
+        for (; ch + 8 <= a.nchunk; ch += 8) {
             s0 += p[ch];
             s1 += p[ch + 1];
+            s2 += p[ch + 2];
+            s3 += p[ch + 3];
+            s4 += p[ch + 4];
+            s5 += p[ch + 5];
+            s6 += p[ch + 6];
+            s7 += p[ch + 7];
         }
-        if (ch < a.nchunk) s0 += p[ch];
-        t2[x * n + m_] = s0 + s1;
+        for (; ch < a.nchunk; ++ch) s0 += p[ch];
+        t2[x * n + m_] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     }
     __syncthreads();
     // Q = U^T Y
