@@ -202,16 +202,19 @@ __global__ __launch_bounds__(256) void ip1_dh_kernel(Ip1Args a) {
         const int b = blockIdx.x - nb1 - a.natm * 3;
         const int e = b * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
         const double *y2part = a.y2part + g * a.sws;
-        double s0 = 0.0, s1 = 0.0;
+        // (four loads in flight per thread: with one geometry per call the Y2 kernels leave > 100 slabs)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         if (e < n2) {
             int sl = grp;
-            for (; sl + 4 < a.nslab; sl += 8) {
+            for (; sl + 12 < a.nslab; sl += 16) {
                 s0 += y2part[(int64_t)sl * n2 + e];
                 s1 += y2part[(int64_t)(sl + 4) * n2 + e];
+                s2 += y2part[(int64_t)(sl + 8) * n2 + e];
+                s3 += y2part[(int64_t)(sl + 12) * n2 + e];
             }
-            if (sl < a.nslab) s0 += y2part[(int64_t)sl * n2 + e];
+            for (; sl < a.nslab; sl += 4) s0 += y2part[(int64_t)sl * n2 + e];
         }
-        part[grp][threadIdx.x & 63] = s0 + s1;
+        part[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (grp == 0 && e < n2)
             a.y2[g * a.sws + e] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
