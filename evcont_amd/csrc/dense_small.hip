@@ -2264,6 +2264,7 @@ int launch_grad_prep(const GradPrepArgs &a, int count, hipStream_t st) {
 // dE = <dX, Y> + explicit terms, with dX[A,x] = U [ (U^T dS[A,x] U) o F ] U^T (Daleckii-Krein form
 // of gradients_loewdin.py:41-134).  Taking the adjoint once,  <dX,Y> = <dS, W>,
 // W = U [ F o (U^T Y U) ] U^T, removes the (N,N,A,3) tensor altogether.
+template <int NMAX>   // 32: n <= 32 (and n > 64, where nothing is staged); 64: 32 < n <= 64
 __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     extern __shared__ __align__(16) double sm[];
     const int n = a.n;
@@ -2292,17 +2293,19 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     double *add = t2 + 3 * n;  // 3*natm: scale1 * (term3 + gnuc)
     int *sl = reinterpret_cast<int *>(add + 3 * a.natm);   // 2*natm: AO slices
     const int tid = threadIdx.x;
-    // n <= 32: the 3 n^2 overlap derivatives are fetched into registers now and parked in the three product
+    // n <= 64: the 3 n^2 overlap derivatives are fetched into registers now and parked in the three product
     // buffers once those are free, so that the per-atom loop at the end runs out of LDS (it is a chain of
     // dependent global loads otherwise: ~2 us per (atom, x) and wave)
-    const bool stage_ip = n <= 32;
-    double ipf[12];
+    const bool stage_ip = !wide;          // (n <= 64: the three product buffers exist)
+    constexpr int kIpf = (3 * NMAX * NMAX + kThreads - 1) / kThreads;   // 12 values per thread at n = 32, 48 at n = 64
+    double ipf[kIpf];
     if (stage_ip) {
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int idx = tid + kThreads * u;
-            ipf[u] = idx < 3 * n * n ? a.ipovlp[idx] : 0.0;
-        }
+        for (int u = 0; u < kIpf; ++u)
+            if (kThreads * u < 3 * n * n) {   // uniform
+                const int idx = tid + kThreads * u;
+                ipf[u] = idx < 3 * n * n ? a.ipovlp[idx] : 0.0;
+            }
     }
     for (int idx = tid; idx < 2 * a.natm; idx += kThreads) sl[idx] = (int)a.aoslices[idx];
     for (int idx = tid; idx < 3 * a.natm; idx += kThreads) {
@@ -2375,9 +2378,9 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     //             - 1/2 sum_{m in A} t2[x][m] + scale1 * (term3 + gnuc)
     if (stage_ip) {  // Y, Q, Us are free now: ip[x] -> {Y, Q, Us}[x]
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
+        for (int u = 0; u < kIpf; ++u) {
             const int idx = tid + kThreads * u;
-            if (idx < 3 * n * n) {
+            if (kThreads * u < 3 * n * n && idx < 3 * n * n) {
                 const int x = idx / (n * n);
                 (x == 0 ? Y : x == 1 ? Q : Us)[idx - x * n * n] = ipf[u];
             }
@@ -2416,9 +2419,15 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
 int launch_grad_final(const GradFinalArgs &a, int count, hipStream_t st) {
     const size_t lds = sizeof(double) * ((size_t)(a.n > 64 ? 2 : 4) * a.n * a.n + 6 * a.n + 3 * (size_t)a.natm) +
                        sizeof(int) * 2 * (size_t)a.natm + 16;
-    static LdsAttr attr;
-    if (int rc = allow_dynamic_lds(grad_final_kernel, attr, 160 * 1024, "grad_final")) return rc;
-    hipLaunchKernelGGL(grad_final_kernel, dim3(count), dim3(kThreads), lds, st, a);
+    if (a.n > 32 && a.n <= 64) {
+        static LdsAttr attr;
+        if (int rc = allow_dynamic_lds(grad_final_kernel<64>, attr, 160 * 1024, "grad_final")) return rc;
+        hipLaunchKernelGGL(grad_final_kernel<64>, dim3(count), dim3(kThreads), lds, st, a);
+    } else {
+        static LdsAttr attr;
+        if (int rc = allow_dynamic_lds(grad_final_kernel<32>, attr, 160 * 1024, "grad_final")) return rc;
+        hipLaunchKernelGGL(grad_final_kernel<32>, dim3(count), dim3(kThreads), lds, st, a);
+    }
     EVC_LAUNCH_CHECK("grad_final");
     return 0;
 }

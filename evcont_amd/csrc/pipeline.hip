@@ -628,7 +628,9 @@ static int gradient_from_rdms(int n, const Geo &g, const double *D, int64_t sD, 
     p.sD = sD;
     p.scale1 = scale1;
     // (symmetric pipeline without a request for the unpacked 2-RDM: grad_prep rides in the unpack launch below)
-    const bool prep_with_unpack = packed && sym8 && !G && (use_pair_transform(n) || use_pair64(EVC_LAYOUT_SYM8, n, ip1_s2kl != 0));
+    // (n <= 32 only: every block of the shared launch reserves grad_prep's LDS -- 52 KB there, 108 KB at n = 58, where
+    //  the unpack blocks would run one per CU)
+    const bool prep_with_unpack = packed && sym8 && !G && use_pair_transform(n);
     if (!prep_with_unpack && (rc = launch_grad_prep(p, cnt, st))) return rc;
     // 32 < n <= 64: the symmetric pipeline on 64 x 64 matrices when int2e_ip1 came packed (use_pair64)
     const bool p64 = packed && use_pair64(sym8 ? EVC_LAYOUT_SYM8 : 0, n, ip1_s2kl != 0);
