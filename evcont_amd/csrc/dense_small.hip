@@ -1140,11 +1140,13 @@ constexpr int kNsSz = 32 * kNsP;
 constexpr int kNsMaxIter = 64;
 constexpr int kNsDoubles = 6 * kNsSz + 8;
 
-__device__ __forceinline__ d4s ns_tile(const double *A, const double *B, int ao, int bo) {
+// (kmax = 4 for n <= 16: K = 16 covers the matrix, and only the tile (0, 0) is active then)
+__device__ __forceinline__ d4s ns_tile(const double *A, const double *B, int ao, int bo, int kmax) {
     d4s acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk * 4 * kNsP + ao], B[kk * 4 * kNsP + bo], acc, 0, 0, 0);
+        if (kk < kmax)   // uniform
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk * 4 * kNsP + ao], B[kk * 4 * kNsP + bo], acc, 0, 0, 0);
     return acc;
 }
 
@@ -1156,6 +1158,9 @@ __device__ bool loewdin_ns(const double *__restrict__ S, const double *__restric
     const int ti = wave >> 1, tj = wave & 1;
     const int ao = l4 * kNsP + 16 * ti + l15, bo = l4 * kNsP + 16 * tj + l15;
     const int oi = 16 * ti + l4, oj = 16 * tj + l15;   // output element of register r: (oi + 4 r, oj)
+    // n <= 16: one tile holds the matrix -- the other three waves idle (their padding tiles are never read: K = 16)
+    const bool act = 16 * ti < n && 16 * tj < n;
+    const int kmax = n <= 16 ? 4 : 8;
     double hreg[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1190,29 +1195,34 @@ __device__ bool loewdin_ns(const double *__restrict__ S, const double *__restric
     int it = 0;
 #pragma unroll 1
     for (; it < kNsMaxIter; ++it) {
-        const d4s p = ns_tile(Zc, Yc, ao, bo);
         double e = 0.0;
+        if (act) {
+            const d4s p = ns_tile(Zc, Yc, ao, bo, kmax);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double dlt = (oi + 4 * r == oj) ? 1.0 : 0.0;
-            e = nanmax(e, fabs(dlt - p[r]));
-            Tm[(oi + 4 * r) * kNsP + oj] = 1.5 * dlt - 0.5 * p[r];
+            for (int r = 0; r < 4; ++r) {
+                const double dlt = (oi + 4 * r == oj) ? 1.0 : 0.0;
+                e = nanmax(e, fabs(dlt - p[r]));
+                Tm[(oi + 4 * r) * kNsP + oj] = 1.5 * dlt - 0.5 * p[r];
+            }
+            e = wave_max_nan(e);
         }
-        e = wave_max_nan(e);
         if (lane == 0) red[wave] = e;
         __syncthreads();
         e = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
-        d4s yn = {0.0, 0.0, 0.0, 0.0}, zn = {0.0, 0.0, 0.0, 0.0};
+        if (act) {
+            d4s yn = {0.0, 0.0, 0.0, 0.0}, zn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const double b = Tm[kk * 4 * kNsP + bo];
-            yn = __builtin_amdgcn_mfma_f64_16x16x4f64(Yc[kk * 4 * kNsP + ao], b, yn, 0, 0, 0);
-            zn = __builtin_amdgcn_mfma_f64_16x16x4f64(Zc[kk * 4 * kNsP + ao], b, zn, 0, 0, 0);
-        }
+            for (int kk = 0; kk < 8; ++kk)
+                if (kk < kmax) {
+                    const double b = Tm[kk * 4 * kNsP + bo];
+                    yn = __builtin_amdgcn_mfma_f64_16x16x4f64(Yc[kk * 4 * kNsP + ao], b, yn, 0, 0, 0);
+                    zn = __builtin_amdgcn_mfma_f64_16x16x4f64(Zc[kk * 4 * kNsP + ao], b, zn, 0, 0, 0);
+                }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Yn[(oi + 4 * r) * kNsP + oj] = yn[r];
-            Zn[(oi + 4 * r) * kNsP + oj] = zn[r];
+            for (int r = 0; r < 4; ++r) {
+                Yn[(oi + 4 * r) * kNsP + oj] = yn[r];
+                Zn[(oi + 4 * r) * kNsP + oj] = zn[r];
+            }
         }
         __syncthreads();
         double *t0 = Yc;
@@ -1241,31 +1251,33 @@ __device__ bool loewdin_ns(const double *__restrict__ S, const double *__restric
         if (i < n && j < n) Zc[i * kNsP + j] *= rsq;
     }
     __syncthreads();
-    {
-        const d4s wv = ns_tile(S0, Zc, ao, bo);
+    if (act) {
+        const d4s wv = ns_tile(S0, Zc, ao, bo, kmax);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Tm[(oi + 4 * r) * kNsP + oj] = wv[r];
     }
     __syncthreads();
     double res;
     {
-        const d4s p = ns_tile(Zc, Tm, ao, bo);
         double e = 0.0;
+        if (act) {
+            const d4s p = ns_tile(Zc, Tm, ao, bo, kmax);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double dlt = (oi + 4 * r == oj) ? 1.0 : 0.0;
-            e = nanmax(e, fabs(dlt - p[r]));
-            Yn[(oi + 4 * r) * kNsP + oj] = 1.5 * dlt - 0.5 * p[r];
+            for (int r = 0; r < 4; ++r) {
+                const double dlt = (oi + 4 * r == oj) ? 1.0 : 0.0;
+                e = nanmax(e, fabs(dlt - p[r]));
+                Yn[(oi + 4 * r) * kNsP + oj] = 1.5 * dlt - 0.5 * p[r];
+            }
+            e = wave_max_nan(e);
         }
-        e = wave_max_nan(e);
         if (lane == 0) red[wave] = e;
         __syncthreads();
         res = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
     }
     EVC_DBGVAL(51, res);
     if (!(res < 1.0e-7)) return false;   // (after the step: ~res^2)
-    {
-        const d4s xv = ns_tile(Zc, Yn, ao, bo);
+    if (act) {
+        const d4s xv = ns_tile(Zc, Yn, ao, bo, kmax);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Zn[(oi + 4 * r) * kNsP + oj] = xv[r];
     }
@@ -1282,14 +1294,14 @@ __device__ bool loewdin_ns(const double *__restrict__ S, const double *__restric
     }
     if (!(h && h1)) return true;
     __syncthreads();
-    {
-        const d4s wv = ns_tile(Tm, Yc, ao, bo);   // W = h X
+    if (act) {
+        const d4s wv = ns_tile(Tm, Yc, ao, bo, kmax);   // W = h X
 #pragma unroll
         for (int r = 0; r < 4; ++r) Yn[(oi + 4 * r) * kNsP + oj] = wv[r];
     }
     __syncthreads();
-    {
-        const d4s hv = ns_tile(Yc, Yn, ao, bo);   // h1 = X W
+    if (act) {
+        const d4s hv = ns_tile(Yc, Yn, ao, bo, kmax);   // h1 = X W
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (oi + 4 * r < n && oj < n) h1[(oi + 4 * r) * n + oj] = hv[r];
