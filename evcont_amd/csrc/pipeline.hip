@@ -846,6 +846,8 @@ static int phase_gradient(const evc_trdm_set *t, const Geo &g_in, const Out &out
 static int check_geometry(const evc_geometry *g, bool need_grad) {
     EVC_REQUIRE(g != nullptr, "geometry is NULL");
     EVC_REQUIRE(g->S && g->hcore && g->eri, "geometry: S/hcore/eri must be given");
+    // (the pair kernels fetch the rows of the two large arrays through 16-byte windows)
+    EVC_REQUIRE(aligned16(g->eri) && (!g->eri_ip1 || aligned16(g->eri_ip1)), "geometry: eri / eri_ip1 must be 16-byte aligned");
     if (need_grad) {
         EVC_REQUIRE(g->natm >= 1, "geometry: natm=%d", g->natm);
         EVC_REQUIRE(g->ipovlp && g->dhcore && g->eri_ip1 && g->aoslices,
@@ -1055,6 +1057,8 @@ static int setup_batch(const char *who, const evc_trdm_set *t, const evc_geometr
     EVC_REQUIRE(gb, "%s: null batch descriptor", who);
     EVC_REQUIRE(gb->count >= 1 && gb->count <= 4096, "%s: batch count=%d out of range", who, gb->count);
     EVC_REQUIRE(gb->S && gb->hcore && gb->eri && gb->enuc, "%s: batch geometry: S/hcore/eri/enuc must be given", who);
+    EVC_REQUIRE(aligned16(gb->eri) && (!gb->eri_ip1 || aligned16(gb->eri_ip1)),
+                "%s: batch geometry: eri / eri_ip1 must be 16-byte aligned", who);
     if (need_grad) {
         EVC_REQUIRE(gb->natm >= 1 && gb->ipovlp && gb->dhcore && gb->eri_ip1 && gb->aoslices && gb->gnuc,
                     "%s: batch geometry: ipovlp/dhcore/eri_ip1/gnuc/aoslices are required for the gradient", who);

@@ -184,7 +184,7 @@ typedef struct evc_geometry {
     double enuc;             /* mol.energy_nuc() */
     const double *S;         /* (N,N)       int1e_ovlp */
     const double *hcore;     /* (N,N)       scf.hf.get_hcore */
-    const double *eri;       /* (N,N,N,N)   int2e */
+    const double *eri;       /* (N,N,N,N)   int2e; 16-byte aligned (as eri_ip1) */
     const double *ipovlp;    /* (3,N,N)     int1e_ipovlp             (NULL: energy only) */
     const double *dhcore;    /* (A,3,N,N)   hcore_generator()(atom)  (NULL: energy only) */
     const double *eri_ip1;   /* (3,N,N,N,N) int2e_ip1                (NULL: energy only) */
