@@ -356,3 +356,24 @@ def test_spot_check_of_the_integral_symmetries():
     e += 1e-3 * np.random.default_rng(1).standard_normal(e.shape)
     with pytest.raises(_lib.EvcontHipError):
         spot_check_integral_symmetry(e, None, n)
+
+
+def test_packed_input_flags_beyond_32_orbitals():
+    """Host-side rule of the 64-wide pipeline (evaluator._ip1_flag): packed s4 / s2kl inputs are accepted up to 64
+    orbitals on the compressed layout, and beyond 32 orbitals the two large arrays are packed together or not at all."""
+    import types
+    import pytest
+    from evcont_amd import _lib
+    from evcont_amd.evaluator import _ip1_flag
+    both = _lib.FLAG_IP1_S2KL | _lib.FLAG_ERI_S4
+    t58 = types.SimpleNamespace(layout=_lib.LAYOUT_SYM8, n=58)
+    ao = lambda s2kl, s4: types.SimpleNamespace(ip1_s2kl=s2kl, eri_s4=s4, eri_ip1=object())
+    assert _ip1_flag(t58, ao(True, True)) == both
+    assert _ip1_flag(t58, ao(False, False)) == 0
+    with pytest.raises(_lib.EvcontHipError):
+        _ip1_flag(t58, ao(True, False))
+    with pytest.raises(_lib.EvcontHipError):
+        _ip1_flag(types.SimpleNamespace(layout=_lib.LAYOUT_SYM8, n=70), ao(True, True))
+    with pytest.raises(_lib.EvcontHipError):
+        _ip1_flag(types.SimpleNamespace(layout=2, n=20), ao(True, True))
+    assert _ip1_flag(types.SimpleNamespace(layout=_lib.LAYOUT_SYM8, n=20), ao(True, False)) == _lib.FLAG_IP1_S2KL
